@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- NKA accel_update throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 100000000] [--mvec 20]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE nka accel_update on one synthetic correction vector: the hot
+path of /root/reference/src-F08/nka_type.F90:249-419 in steady state (subspace
+full: L = k = mvec), inputs already resident in HBM when the timed region
+starts.  Workload at N=1: BASELINE.json configs[2], n=1e8, mvec=20, fp64.
+With N>1 the SAME global vector is sharded by contiguous slices (strong
+scaling, BASELINE configs[3]); the only exchange is one RCCL all-reduce of 1
+double after P1 and one of 1+2*mvec doubles after P2, on the kernel stream.
+
+Prints ONE JSON line (rank 0) with the driver's keys plus
+  roofline     : algorithmic bytes of one update, 8*n*(11+L+2k),
+                 over the mean device time of an update measured with HIP events
+                 on the kernel stream during the timed steps; per-kernel figures
+                 for P1/P2/P3 under "kernels" (P3 k_combine is the dominant one)
+  cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
+                 oracle port timed on this box's host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 12345
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=None, help="default mvec+4 (fills the subspace)")
+    ap.add_argument("--n", type=float, default=1e8, help="GLOBAL vector length")
+    ap.add_argument("--mvec", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=float, default=4e6, help="vector length of the CPU sample")
+    ap.add_argument("--allreduce", choices=["rccl", "torch"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
+    return ap.parse_args()
+
+
+def cpu_baseline(mvec: int, n: int, timed: int = 6):
+    """Time the reference's own accel_update (compiled from /root/reference into
+    oracle/_ref, if it travelled with the repo) or else the oracle port, serial,
+    on a bounded sample of the same workload: same generator, same mvec, steady
+    state, smaller n (cost is linear in n)."""
+    import numpy as np
+    from nka_amd import synth
+    from oracle import oracle_py as O
+    kind = "port"
+    acc = None
+    if O.have_ref():
+        try:
+            acc = O.RefF08(n, mvec)
+            kind = "reference"
+        except Exception:
+            acc = None
+    if acc is None:
+        acc = O.OracleNKA(n, mvec)
+    t_all = time.perf_counter()
+    for t in range(mvec + 2):
+        f = synth.fill_numpy(SEED, t, 0, n, n)
+        acc.accel_update(f)
+    assert acc.num_vec() == mvec
+    dt = []
+    for t in range(mvec + 2, mvec + 2 + timed):
+        f = synth.fill_numpy(SEED, t, 0, n, n)
+        t0 = time.perf_counter()
+        acc.accel_update(f)
+        dt.append(time.perf_counter() - t0)
+    per = float(np.median(dt))
+    return {
+        "value": 1.0 / per, "unit": "updates/s", "cores": 1, "kind": kind,
+        "sample": f"n={n:d}, mvec={mvec}, {timed} steady-state updates after {mvec + 2} fill calls "
+                  f"({time.perf_counter() - t_all:.1f} s of CPU work); serial like the reference",
+        "n": n, "s_per_update": per,
+        "algorithmic_GBps": 8.0 * n * (11 + 3 * mvec) / per / 1e9,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import nka_amd
+    from nka_amd import dist as nd
+    from nka_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_global, m = int(args.n), args.mvec
+    lo, hi = nd.slice_bounds(n_global, world, rank)
+    n_local = hi - lo
+    K = args.steps
+    W = args.warmup if args.warmup is not None else m + 4
+
+    acc = nka_amd.nka().init(n_local, m)
+    if world > 1:
+        if args.allreduce == "rccl":
+            nd.attach_rccl(acc, rank, world)
+        else:
+            nd.attach_torch_allreduce(acc)
+
+    # ---- inputs: resident in HBM before the timed region ----------------------
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    pool_cap = max(2, int((free_b * 0.85) // (8 * max(n_local + 1, 2))))
+    P = min(W + K, pool_cap)
+    n_pad = n_local + (n_local % 2)            # keep every row 16-byte aligned
+    pool_store = torch.empty((P, max(n_pad, 2)), dtype=torch.float64, device=dev)
+    pool = [pool_store[j, :n_local] for j in range(P)]
+
+    def fill(j, t):
+        synth.fill_torch(pool[j], SEED, t, lo, n_global)
+
+    for t in range(min(P, W + K)):
+        fill(t, t)
+    refill_in_timed_region = (W + K) > P
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- warm-up (fills the subspace: num_vec == mvec from call mvec+1 on) ----
+    for t in range(W):
+        if t >= P:
+            fill(t % P, t)
+        acc.accel_update(pool[t % P])
+    sync_all()
+    nv = acc.num_vec()
+    steady = (nv == m)
+
+    # device-copy ceiling measured in the same run
+    csz = min(n_local, 1 << 27)
+    if csz > 0:
+        src = torch.empty(csz, dtype=torch.float64, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbps = 5 * 2 * 8 * csz / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    else:
+        copy_gbps = None
+
+    # ---- timed region: EXACTLY K updates ------------------------------------
+    acc.set_timing(min(K, 4096))
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(K):
+        t = W + s
+        if t >= P:
+            fill(t % P, t)           # only when HBM cannot hold W+K inputs (reported below)
+        acc.accel_update(pool[t % P])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-phase device times of the timed updates (HIP events on the kernel stream)
+    nrec = min(K, 4096)
+    ph = [acc.timing_ms(b) for b in range(nrec)]
+    mean = [sum(p[i] for p in ph) / nrec for i in range(4)]
+    nv_end = acc.num_vec()
+
+    if rank == 0:
+        L = k = m
+        words = {"P1_k_diffnorm": 2, "P2_k_gram": 5 + L, "P3_k_combine": 4 + 2 * k}
+        b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # per update, per GPU
+        upd_s = mean[3] * 1e-3
+        kernels = {}
+        for (name, w), ms in zip(words.items(), mean[:3]):
+            kernels[name] = {"algorithmic_bytes": 8.0 * n_local * w, "mean_ms": ms,
+                             "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None}
+        achieved = b_alg / upd_s / 1e9 if upd_s > 0 else 0.0
+        out = {
+            "metric": "NKA accel_update throughput (updates/s) at n=%.0e, m=%d, fp64" % (n_global, m),
+            "value": K / elapsed, "unit": "updates/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction "
+                                   f"vectors, n={n_global} (global), mvec={m}, fp64, subspace full (num_vec={nv})",
+                       "n_global": n_global, "n_local": n_local, "mvec": m,
+                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={args.allreduce if world > 1 else 'none'}",
+                       "steady_state": bool(steady and nv_end == m),
+                       "inputs_resident": not refill_in_timed_region},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "what": "whole accel_update on one GPU: algorithmic bytes 8*n_local*(11+L+2k) / mean "
+                                 "device time first-kernel-start..last-kernel-end (HIP events, kernel stream)",
+                         "algorithmic_bytes_per_update": b_alg, "mean_update_ms": mean[3],
+                         "dominant_kernel": "P3_k_combine", "kernels": kernels,
+                         "copy_ceiling_GBps": copy_gbps},
+            "aggregate_algorithmic_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(m, int(args.cpu_n))
+                out["cpu_baseline"]["updates_per_s_scaled_to_n_global"] = \
+                    out["cpu_baseline"]["value"] * int(args.cpu_n) / n_global
+            except Exception as exc:  # the baseline is a reported extra, never the measured path
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * nka_hip.h -- C ABI of the MI355X-native NKA accelerator (libnka_hip.so).
+ *
+ * Drop-in boundary for ONE path of nncarlson/nka: the accelerator object and
+ * its accel_update hot path.  Every entry point names the reference interface
+ * it replaces:
+ *   F08  = /root/reference/src-F08/nka_type.F90
+ *   F08V = /root/reference/src-F08-vector/nka_type.F90, vector_class.F90
+ *   C    = /root/reference/src-C/nonlinear_krylov_accelerator.{h,c}
+ *
+ * Plain C types only: opaque handle, raw DEVICE pointers (memory on the HIP
+ * device the handle was created for), int64 lengths, a hipStream_t passed as
+ * void*.  No status codes exist in the reference (its precondition checks are
+ * ASSERTs, F08:190-191,205,212,257-258); here every call returns 0 on success
+ * or a negative NKA_HIP_E* code, and nka_hip_last_error() gives the text.
+ *
+ * All state-changing calls are ASYNCHRONOUS on the handle's stream (no host
+ * synchronisation inside accel_update); the query calls (num_vec, get_state)
+ * synchronise that stream.  In a multi-rank run every call is collective, like
+ * the reference (F08:58-64).
+ *
+ * Slot numbering, list links and the H matrix layout visible through
+ * nka_hip_get_state are the Fortran ones: slots 1..mvec+1, 0 = end of list.
+ */
+#ifndef NKA_HIP_H
+#define NKA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nka_hip_state *nka_hip_t;
+
+enum {
+  NKA_HIP_OK = 0,
+  NKA_HIP_EINVAL = -1,  /* bad argument (the reference would ASSERT)        */
+  NKA_HIP_EHIP = -2,    /* a HIP runtime call failed                        */
+  NKA_HIP_ENOMEM = -3,  /* device allocation failed                         */
+  NKA_HIP_ECOMM = -4,   /* RCCL / user all-reduce failed                    */
+  NKA_HIP_ESTATE = -5   /* device state failed the defined() invariants     */
+};
+
+/* Which of the reference's three roundings of the elementwise statements is
+ * mirrored:
+ *   F08        w1-f ; x/s          ; (f - c*w) + c*v        F08:266,282-283,397
+ *   F08_VECTOR (-1)*f+w ; (1/s)*x  ; ((-c)*w + c*v) + f     F08V:237,255-256,374
+ *   C          w1-f ; x/s          ; f + c*(v - w)          C .c:299-300,317-320,423 */
+enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2 };
+
+/* ---- lifecycle --------------------------------------------------------- */
+
+/* Replaces  call a%init(vlen, mvec)  (F08:185-200)  /  nka_init(vlen, mvec,
+ * vtol, dp)  (C .h:4, .c:211-258).  vlen_local is THIS rank's slice length
+ * (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).
+ * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = the
+ * library creates its own).  Allocates 2*(mvec+1) slot vectors on the device. */
+int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
+                   int32_t flavor, int32_t device, void *stream);
+
+/* Replaces nka_delete (C .h:5, .c:261-282) / automatic deallocation (F08). */
+int nka_hip_destroy(nka_hip_t a);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/* Replaces  call a%accel_update(f)  (F08:249-419; F08V:219-397; C .h:6,
+ * .c:285-447).  f_dev: vlen_local doubles in device memory, updated in place.
+ * The object keeps copies, never a reference (F08:361,404). */
+int nka_hip_accel_update(nka_hip_t a, double *f_dev);
+
+/* Host-array compatibility entry (the reference signature takes host memory,
+ * F08:252): H2D copy, update, D2H copy, stream synchronised on return. */
+int nka_hip_accel_update_host(nka_hip_t a, double *f_host);
+
+/* Replaces  call a%restart()  (F08:422-436; C .h:7).  */
+int nka_hip_restart(nka_hip_t a);
+/* Replaces  call a%relax()    (F08:439-457; C .h:8).  */
+int nka_hip_relax(nka_hip_t a);
+/* Replaces  call a%set_vec_tol(vtol)  (F08:202-207). */
+int nka_hip_set_vec_tol(nka_hip_t a, double vtol);
+
+/* ---- queries (synchronise the stream) ---------------------------------- */
+
+int nka_hip_num_vec(nka_hip_t a);      /* F08:221-231, C .h:9  ; <0 on error */
+int nka_hip_max_vec(nka_hip_t a);      /* F08:233-236, C .h:10 */
+int64_t nka_hip_vec_len(nka_hip_t a);  /* F08:238-241, C .h:11 (local length) */
+double nka_hip_vec_tol(nka_hip_t a);   /* F08:243-246, C .h:12 */
+int nka_hip_defined(nka_hip_t a);      /* F08:460-524 ; 1 = well defined */
+
+/* List / factor state for parity tests (the reference keeps these private,
+ * F08:155-168).  next, prev: mvec+1 ints (entry k-1 is slot k); h: (mvec+1)^2
+ * doubles, column-major h(i,j) = h[(i-1)+(j-1)*(mvec+1)]; c: mvec+1 doubles,
+ * the coefficients of the last update by slot.  Any pointer may be NULL. */
+int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t *first,
+                      int32_t *last, int32_t *free_, int32_t *next, int32_t *prev,
+                      double *h, double *c);
+/* The reduced dot products of the most recent update as the device solve saw
+ * them: red[0] = |w1-f|^2, red[1] = <f,w1'>, red[2+p] = <w1',w_p>,
+ * red[2+mvec+p] = <f,w_p> for the p-th older list entry (2+2*mvec doubles).
+ * With these a CPU restatement of the scalar step can be checked bit for bit. */
+int nka_hip_get_reductions(nka_hip_t a, double *red_out);
+/* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
+int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);
+int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);
+
+/* ---- distribution hook -------------------------------------------------- */
+
+/* Replaces  call a%set_dot_prod(dot_prod)  (F08:209-214) / the dp argument of
+ * nka_init (C .c:211,227-231).  The reference asks the user for a GLOBAL dot
+ * product; here the local partial sums already live on the device, so the
+ * hook is the global SUM of `count` doubles at device address `buf`, in place,
+ * enqueued on `stream` (hipStream_t).  Must return 0 on success, and must give
+ * bit-identical results on every rank.  Called 2 times per accel_update (count
+ * 1, then 1+2*mvec).  NULL restores the single-rank default (no reduction). */
+typedef int (*nka_hip_allreduce_fn)(void *ctx, double *buf, int32_t count, void *stream);
+int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx);
+
+/* Built-in hook: RCCL all-reduce over xGMI on the handle's stream.
+ * nka_hip_comm_unique_id fills 128 bytes (an ncclUniqueId) on one rank; the
+ * caller broadcasts it by any means; every rank then calls comm_init_rank. */
+int nka_hip_comm_unique_id(void *id128);
+int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank);
+
+/* ---- instrumentation ---------------------------------------------------- */
+
+/* Per-phase device times from HIP events recorded on the handle's stream.
+ * nka_hip_set_timing(a, capacity) keeps the events of the last `capacity`
+ * updates in a ring (0 switches timing off); recording never synchronises.
+ * nka_hip_get_timing(a, back, ms) synchronises and returns, for the update
+ * `back` calls ago (0 = most recent):  ms[0] = P1 difference+norm (with its
+ * final sum and all-reduce), ms[1] = P2 normalise+Gram rows (ditto), ms[2] = P3
+ * combine+ring stores, ms[3] = whole update, first kernel start -> last end. */
+int nka_hip_set_timing(nka_hip_t a, int32_t capacity);
+int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
+
+/* Launch geometry knobs for tuning: blocks per CU of P1, P2, P3 (0 = keep). */
+int nka_hip_set_grid(nka_hip_t a, int32_t p1_blocks_per_cu, int32_t p2_blocks_per_cu,
+                     int32_t p3_blocks_per_cu);
+
+const char *nka_hip_last_error(void);
+/* "gfx950"-style name of the device the handle runs on, CU count. */
+int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
+
+/* ---- vector primitives for the abstract-vector hooks -------------------- */
+/* Device implementations of the deferred procedures a concrete `vector` must
+ * supply (F08V vector_class.F90:92-108; model: grid_vector_type.F90:86-197).
+ * x, y, z are device pointers to n doubles; `ws` is a workspace obtained from
+ * nka_hip_vec_workspace_create (holds the reduction partials).  Elementwise
+ * results are rounded exactly like the Fortran expressions they replace. */
+typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
+int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
+int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
+int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
+int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);
+int nka_hip_vec_copy(nka_hip_vec_ws_t ws, int64_t n, double *dst, const double *src);          /* copy_   */
+int nka_hip_vec_setval(nka_hip_vec_ws_t ws, int64_t n, double *x, double val);                  /* setval  */
+int nka_hip_vec_scale(nka_hip_vec_ws_t ws, int64_t n, double *x, double a);                     /* scale: a*x */
+int nka_hip_vec_update1(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x);  /* a*x + z */
+int nka_hip_vec_update2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, double b); /* a*x + b*z */
+int nka_hip_vec_update3(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
+                        double b, const double *y);                                             /* a*x + b*y + z */
+int nka_hip_vec_update4(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
+                        double b, const double *y, double c);                                   /* a*x + b*y + c*z */
+int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result); /* dot_ */
+int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *host_result);    /* norm2   */
+int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
+int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NKA_HIP_H */

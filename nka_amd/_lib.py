@@ -1,0 +1,87 @@
+"""Loader for libnka_hip.so (built in tree by nka_amd/csrc/Makefile)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i32p = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+# name -> (restype, argtypes): every symbol include/nka_hip.h declares
+SIGNATURES = {
+    "nka_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p]),
+    "nka_hip_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_accel_update": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nka_hip_accel_update_host": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nka_hip_restart": (C.c_int, [C.c_void_p]),
+    "nka_hip_relax": (C.c_int, [C.c_void_p]),
+    "nka_hip_set_vec_tol": (C.c_int, [C.c_void_p, C.c_double]),
+    "nka_hip_num_vec": (C.c_int, [C.c_void_p]),
+    "nka_hip_max_vec": (C.c_int, [C.c_void_p]),
+    "nka_hip_vec_len": (C.c_int64, [C.c_void_p]),
+    "nka_hip_vec_tol": (C.c_double, [C.c_void_p]),
+    "nka_hip_defined": (C.c_int, [C.c_void_p]),
+    "nka_hip_get_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp, _dp]),
+    "nka_hip_get_reductions": (C.c_int, [C.c_void_p, _dp]),
+    "nka_hip_get_w": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "nka_hip_get_v": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "nka_hip_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "nka_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "nka_hip_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "nka_hip_last_error": (C.c_char_p, []),
+    "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
+    "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "nka_hip_vec_workspace_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_vec_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "nka_hip_vec_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nka_hip_vec_copy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nka_hip_vec_setval": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double]),
+    "nka_hip_vec_scale": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double]),
+    "nka_hip_vec_update1": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p]),
+    "nka_hip_vec_update2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double]),
+    "nka_hip_vec_update3": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
+    "nka_hip_vec_update4": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_double]),
+    "nka_hip_vec_dot": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _dp]),
+    "nka_hip_vec_norm2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp]),
+    "nka_hip_vec_h2d": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nka_hip_vec_d2h": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "libnka_hip.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j4"]
+    if force:
+        subprocess.run(args + ["clean"], check=True)
+    subprocess.run(args, check=True)
+    return lib_path()
+
+
+def load() -> C.CDLL:
+    """Load libnka_hip.so.  Fails loudly when it is missing: there is no CPU path."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(nka_amd has no CPU fallback)")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

@@ -1,0 +1,609 @@
+// nka_hip.hip -- host side of the C ABI declared in include/nka_hip.h.
+//
+// The accelerator object (reference: `type nka`, src-F08/nka_type.F90:154-181)
+// keeps ALL of its state on the device: the 2*(mvec+1) slot vectors, the Gram /
+// Cholesky matrix h, the linked lists and the flags.  accel_update enqueues
+//   P1 k_diffnorm -> k_finalize -> [all-reduce 1] ->
+//   P2 k_gram -> k_finalize_gram -> [all-reduce 1+2*mvec] -> k_solve -> P3 k_combine
+// on one HIP stream and returns; nothing is read back.  The host only tracks what
+// it can know without looking: whether a pair is pending, and an upper bound on
+// the list length (used to pick the unroll width of P2/P3).
+#include "../../include/nka_hip.h"
+#include "nka_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nka;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(e_ == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,                \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+  } while (0)
+
+}  // namespace
+
+namespace nka_detail {
+// shared with vec_ops.hip: one thread-local error string per library
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace nka_detail
+
+namespace {
+
+int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+struct nka_hip_state {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int64_t n = 0;
+  int32_t mvec = 0;
+  double vtol = 0.01;
+  int flavor = NKA_HIP_FLAVOR_F08;
+  Vecs vs{};
+  Ctl ctl{};
+  double *partials = nullptr;
+  double *f_stage = nullptr;  // device staging for the host-array entry point
+  // what the host knows without reading the device back
+  bool pending = false;
+  int list_ub = 0;            // upper bound on the list length
+  // launch geometry
+  int num_cu = 256;
+  int bpc[3] = {8, 8, 8};     // caps; the grid also respects each kernel's occupancy
+  char devname[64] = {0};
+  // distribution hook
+  nka_hip_allreduce_fn allreduce = nullptr;
+  void *allreduce_ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  // instrumentation
+  // kTimingEvents events per update, in a ring of timing_cap updates
+  int timing_cap = 0;
+  int64_t timing_count = 0;   // updates recorded since set_timing
+  std::vector<hipEvent_t> ev;
+};
+
+namespace {
+
+// Persistent grid: one block per resident slot (occupancy of THIS instantiation
+// x CU count, capped by the tunable blocks-per-CU and by the number of tiles),
+// so every block is co-resident and the grid-stride loops stay balanced.
+template <typename K>
+int occupancy_of(K kernel) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+
+int grid_for(const nka_hip_state *a, int which, int vec, int occ) {
+  const int64_t ntile = a->n / (kBlock * vec);
+  int64_t g = (int64_t)a->num_cu * std::min(occ, a->bpc[which]);
+  g = std::min<int64_t>(g, std::max<int64_t>(ntile, 1));
+  g = std::min<int64_t>(g, kMaxGrid);
+  return (int)std::max<int64_t>(g, 1);
+}
+
+int rccl_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
+  auto *a = static_cast<nka_hip_state *>(ctx);
+  ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, a->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  return 0;
+}
+
+// ---- kernel dispatch by unroll width ------------------------------------------
+template <int MAXL, int VEC, bool RCP>
+int launch_gram_1(const nka_hip_state *a, const double *f, int pass) {
+  static const int occ = occupancy_of(k_gram<MAXL, VEC, RCP>);
+  const int g = grid_for(a, 1, VEC, occ);
+  hipLaunchKernelGGL((k_gram<MAXL, VEC, RCP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
+  return g;
+}
+
+template <int VEC, bool RCP>
+int launch_gram_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
+#define CASE(L) \
+  case L: return launch_gram_1<L, VEC, RCP>(a, f, pass);
+  switch (maxl) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
+}
+
+void launch_finalize_gram(int maxl, hipStream_t s, Ctl ctl, const double *partials, int G, int pass) {
+#define CASE(L)                                                                                   \
+  case L:                                                                                         \
+    hipLaunchKernelGGL((k_finalize_gram<L>), dim3(1), dim3(kBlock), 0, s, ctl, partials, G, pass); \
+    break;
+  switch (maxl) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+}
+
+template <int MAXK, int VEC, int COMB>
+int launch_combine_1(const nka_hip_state *a, double *f, int pass, int last) {
+  static const int occ = occupancy_of(k_combine<MAXK, VEC, COMB>);
+  const int g = grid_for(a, 2, VEC, occ);
+  hipLaunchKernelGGL((k_combine<MAXK, VEC, COMB>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, pass, last);
+  return g;
+}
+
+template <int VEC, int COMB>
+int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int last) {
+#define CASE(K) \
+  case K: return launch_combine_1<K, VEC, COMB>(a, f, pass, last);
+  switch (maxk) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
+}
+
+template <int VEC>
+int launch_diffnorm(const nka_hip_state *a, const double *f) {
+  static const int occ = occupancy_of(k_diffnorm<VEC>);
+  const int g = grid_for(a, 0, VEC, occ);
+  hipLaunchKernelGGL((k_diffnorm<VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  return g;
+}
+
+int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
+
+constexpr int kTimingEvents = 5;
+
+int record(nka_hip_state *a, int i) {
+  if (a->timing_cap <= 0) return 0;
+  const int slot = (int)(a->timing_count % a->timing_cap);
+  HIP_TRY(hipEventRecord(a->ev[(size_t)slot * kTimingEvents + i], a->stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nka_hip_last_error(void) { return g_err.c_str(); }
+
+int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol, int32_t flavor,
+                   int32_t device, void *stream) {
+  if (!out) return fail(NKA_HIP_EINVAL, "nka_hip_create: out is NULL");
+  *out = nullptr;
+  // the reference ASSERTs these (F08:190-191, 205)
+  if (mvec <= 0) return fail(NKA_HIP_EINVAL, "nka_hip_create: mvec must be > 0");
+  if (vlen_local < 0) return fail(NKA_HIP_EINVAL, "nka_hip_create: vlen must be >= 0");
+  if (!(vtol > 0.0)) return fail(NKA_HIP_EINVAL, "nka_hip_create: vtol must be > 0");
+  if (flavor < 0 || flavor > 2) return fail(NKA_HIP_EINVAL, "nka_hip_create: unknown flavor");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(NKA_HIP_EINVAL, "nka_hip_create: no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+
+  auto *a = new nka_hip_state();
+  a->device = device;
+  a->n = vlen_local;
+  a->mvec = mvec;
+  a->vtol = vtol;
+  a->flavor = flavor;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  a->num_cu = prop.multiProcessorCount;
+  snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
+  a->bpc[0] = env_int("NKA_HIP_P1_BLOCKS_PER_CU", a->bpc[0]);
+  a->bpc[1] = env_int("NKA_HIP_P2_BLOCKS_PER_CU", a->bpc[1]);
+  a->bpc[2] = env_int("NKA_HIP_P3_BLOCKS_PER_CU", a->bpc[2]);
+
+  if (stream) {
+    a->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete a;
+      return fail(NKA_HIP_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    a->own_stream = true;
+  }
+
+  // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
+  // the slot stride is padded to 256 B so every slot base allows 16-B loads,
+  // plus NKA_HIP_SLOT_PAD_BYTES (default 0) to skew slots across HBM channels.
+  const int64_t pad = env_int("NKA_HIP_SLOT_PAD_BYTES", 0) / 8;
+  a->vs.n = vlen_local;
+  a->vs.stride = ((std::max<int64_t>(vlen_local, 1) + 31) / 32) * 32 + (pad / 32) * 32;
+  a->ctl.mvec = mvec;
+  const size_t slot_bytes = (size_t)a->vs.stride * sizeof(double) * (size_t)(mvec + 1);
+  int rc = 0;
+  auto alloc = [&](void **p, size_t bytes) {
+    if (rc) return;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess)
+      rc = fail(NKA_HIP_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+  };
+  alloc((void **)&a->vs.v, slot_bytes);
+  alloc((void **)&a->vs.w, slot_bytes);
+  alloc((void **)&a->ctl.ic, sizeof(int32_t) * a->ctl.ic_count());
+  alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
+  alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 1));
+  if (rc) {
+    nka_hip_destroy(a);
+    return rc;
+  }
+  // zero the control blocks, set vtol, then the device-side restart (F08:198)
+  if (hipMemsetAsync(a->ctl.ic, 0, sizeof(int32_t) * a->ctl.ic_count(), a->stream) != hipSuccess ||
+      hipMemsetAsync(a->ctl.dc, 0, sizeof(double) * a->ctl.dc_count(), a->stream) != hipSuccess ||
+      hipMemcpyAsync(a->ctl.dc + DC_VTOL, &a->vtol, sizeof(double), hipMemcpyHostToDevice, a->stream) != hipSuccess) {
+    nka_hip_destroy(a);
+    return fail(NKA_HIP_EHIP, "initialising the control block failed");
+  }
+  // the memcpy source is a->vtol (heap): safe until the stream reaches it; sync to be simple
+  hipStreamSynchronize(a->stream);
+  rc = nka_hip_restart(a);
+  if (rc) {
+    nka_hip_destroy(a);
+    return rc;
+  }
+  *out = a;
+  return 0;
+}
+
+int nka_hip_destroy(nka_hip_t a) {
+  if (!a) return 0;
+  hipSetDevice(a->device);
+  if (a->stream) hipStreamSynchronize(a->stream);
+  if (a->comm) ncclCommDestroy(a->comm);
+  hipFree(a->vs.v);
+  hipFree(a->vs.w);
+  hipFree(a->ctl.ic);
+  hipFree(a->ctl.dc);
+  hipFree(a->partials);
+  hipFree(a->f_stage);
+  for (auto &e : a->ev)
+    if (e) hipEventDestroy(e);
+  a->ev.clear();
+  if (a->own_stream && a->stream) hipStreamDestroy(a->stream);
+  delete a;
+  return 0;
+}
+
+int nka_hip_restart(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(a->device));
+  hipLaunchKernelGGL(k_restart, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), a->stream, a->ctl);
+  HIP_TRY(hipGetLastError());
+  a->pending = false;
+  a->list_ub = 0;
+  return 0;
+}
+
+int nka_hip_relax(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(a->device));
+  hipLaunchKernelGGL(k_relax, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), a->stream, a->ctl);
+  HIP_TRY(hipGetLastError());
+  if (a->pending) {
+    a->pending = false;
+    a->list_ub = std::max(a->list_ub - 1, 0);
+  }
+  return 0;
+}
+
+int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (!(vtol > 0.0)) return fail(NKA_HIP_EINVAL, "set_vec_tol: vtol must be > 0");  // F08:205
+  HIP_TRY(hipSetDevice(a->device));
+  a->vtol = vtol;
+  HIP_TRY(hipMemcpyAsync(a->ctl.dc + DC_VTOL, &a->vtol, sizeof(double), hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
+int nka_hip_accel_update(nka_hip_t a, double *f) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
+  HIP_TRY(hipSetDevice(a->device));
+  hipStream_t s = a->stream;
+  const bool aligned = (reinterpret_cast<uintptr_t>(f) % 16) == 0;
+  const int vec = aligned ? 2 : 1;
+  const bool rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR);
+  if (int rc = record(a, 0)) return rc;
+  const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
+
+  // ---- P1: s^2 = |w1 - f|^2 (only if a pair is pending, F08:263-267) ----
+  if (a->pending) {
+    const int g = (vec == 2) ? launch_diffnorm<2>(a, f) : launch_diffnorm<1>(a, f);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, s, a->partials, g, 1, 1, a->ctl.red());
+    HIP_TRY(hipGetLastError());
+    if (a->allreduce)
+      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+  }
+  if (int rc = record(a, 1)) return rc;
+
+  // ---- P2: normalise + both Gram rows (F08:282-290, 371) ----
+  // Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
+  if (a->pending || older_ub > 0) {
+    const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
+    const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
+    for (int p = 0; p < npass; p++) {
+      int g;
+      if (vec == 2) g = rcp ? launch_gram_w<2, true>(maxl, a, f, p) : launch_gram_w<2, false>(maxl, a, f, p);
+      else g = rcp ? launch_gram_1<4, 1, true>(a, f, p) : launch_gram_1<4, 1, false>(a, f, p);
+      launch_finalize_gram(maxl, s, a->ctl, a->partials, g, p);
+    }
+    HIP_TRY(hipGetLastError());
+    if (a->allreduce)
+      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red() + 1, 1 + 2 * a->mvec, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+  }
+  if (int rc = record(a, 2)) return rc;
+
+  // ---- scalar part on one wavefront (F08:275, 295-358, 366-392, 406-417) ----
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl);
+  HIP_TRY(hipGetLastError());
+  if (int rc = record(a, 3)) return rc;
+
+  // ---- P3: combine + ring stores (F08:361, 395-404) ----
+  // after the subspace update the list holds at most min(list_ub, mvec) vectors
+  const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
+  {
+    const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
+    const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
+    for (int p = 0; p < npass; p++) {
+      const int last = (p == npass - 1);
+      if (vec == 2) {
+        switch (a->flavor) {
+          case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_w<2, 1>(maxk, a, f, p, last); break;
+          case NKA_HIP_FLAVOR_C: launch_combine_w<2, 2>(maxk, a, f, p, last); break;
+          default: launch_combine_w<2, 0>(maxk, a, f, p, last);
+        }
+      } else {
+        switch (a->flavor) {
+          case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_1<4, 1, 1>(a, f, p, last); break;
+          case NKA_HIP_FLAVOR_C: launch_combine_1<4, 1, 2>(a, f, p, last); break;
+          default: launch_combine_1<4, 1, 0>(a, f, p, last);
+        }
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  if (int rc = record(a, 4)) return rc;
+
+  if (a->timing_cap > 0) a->timing_count++;
+  a->list_ub = comb_ub + 1;
+  a->pending = true;
+  return 0;
+}
+
+int nka_hip_accel_update_host(nka_hip_t a, double *f_host) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (!f_host && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update_host: f is NULL");
+  HIP_TRY(hipSetDevice(a->device));
+  if (!a->f_stage) HIP_TRY(hipMalloc((void **)&a->f_stage, sizeof(double) * (size_t)std::max<int64_t>(a->n, 1)));
+  HIP_TRY(hipMemcpyAsync(a->f_stage, f_host, sizeof(double) * (size_t)a->n, hipMemcpyHostToDevice, a->stream));
+  if (int rc = nka_hip_accel_update(a, a->f_stage)) return rc;
+  HIP_TRY(hipMemcpyAsync(f_host, a->f_stage, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
+// ---- queries --------------------------------------------------------------------
+
+static int fetch_state(nka_hip_t a, std::vector<int32_t> &ic, std::vector<double> &dc) {
+  HIP_TRY(hipSetDevice(a->device));
+  ic.resize(a->ctl.ic_count());
+  dc.resize(a->ctl.dc_count());
+  HIP_TRY(hipMemcpyAsync(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipMemcpyAsync(dc.data(), a->ctl.dc, sizeof(double) * dc.size(), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
+int nka_hip_num_vec(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  std::vector<int32_t> ic;
+  std::vector<double> dc;
+  if (int rc = fetch_state(a, ic, dc)) return rc;
+  const int32_t *next = ic.data() + IC_HEADER;
+  int n = 0;
+  for (int k = ic[IC_FIRST]; k != 0 && n <= a->mvec + 1; k = next[k]) n++;  // F08:224-229
+  return ic[IC_PENDING] ? n - 1 : n;                                          // F08:230
+}
+
+int nka_hip_max_vec(nka_hip_t a) { return a ? a->mvec : fail(NKA_HIP_EINVAL, "null handle"); }
+int64_t nka_hip_vec_len(nka_hip_t a) { return a ? a->n : (int64_t)fail(NKA_HIP_EINVAL, "null handle"); }
+double nka_hip_vec_tol(nka_hip_t a) { return a ? a->vtol : 0.0; }
+
+int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t *first, int32_t *last,
+                      int32_t *free_, int32_t *next, int32_t *prev, double *h, double *c) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  std::vector<int32_t> ic;
+  std::vector<double> dc;
+  if (int rc = fetch_state(a, ic, dc)) return rc;
+  const int m1 = a->mvec + 1;
+  if (subspace) *subspace = ic[IC_SUBSPACE];
+  if (pending) *pending = ic[IC_PENDING];
+  if (first) *first = ic[IC_FIRST];
+  if (last) *last = ic[IC_LAST];
+  if (free_) *free_ = ic[IC_FREE];
+  const int32_t *nx = ic.data() + IC_HEADER, *pv = nx + (m1 + 1);
+  const double *hh = dc.data() + DC_HEADER, *cc = hh + (m1 + 1) * (m1 + 1);
+  for (int k = 1; k <= m1; k++) {
+    if (next) next[k - 1] = nx[k];
+    if (prev) prev[k - 1] = pv[k];
+    if (c) c[k - 1] = cc[k];
+  }
+  if (h)
+    for (int j = 1; j <= m1; j++)
+      for (int i = 1; i <= m1; i++) h[(i - 1) + (size_t)(j - 1) * m1] = hh[i * (m1 + 1) + j];
+  return 0;
+}
+
+int nka_hip_get_reductions(nka_hip_t a, double *red_out) {
+  if (!a || !red_out) return fail(NKA_HIP_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(a->device));
+  HIP_TRY(hipMemcpyAsync(red_out, a->ctl.red(), sizeof(double) * a->ctl.red_count(), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
+// F08:460-524 on a snapshot of the device state
+int nka_hip_defined(nka_hip_t a) {
+  if (!a) return 0;
+  std::vector<int32_t> ic;
+  std::vector<double> dc;
+  if (fetch_state(a, ic, dc)) return 0;
+  const int n = a->mvec + 1;
+  if (a->mvec < 1 || !a->vs.v || !a->vs.w) return 0;
+  if (!(dc[DC_VTOL] > 0.0)) return 0;
+  const int32_t *next = ic.data() + IC_HEADER, *prev = next + (n + 1);
+  const int first = ic[IC_FIRST], last = ic[IC_LAST], fr = ic[IC_FREE];
+  for (int k = 1; k <= n; k++)
+    if (next[k] < 0 || next[k] > n) return 0;
+  if (first < 0 || first > n || fr < 0 || fr > n) return 0;
+  std::vector<char> tag(n + 1, 0);
+  if (first == 0) {
+    if (last != 0) return 0;
+  } else {
+    int k = first;
+    if (prev[k] != 0) return 0;
+    tag[k] = 1;
+    while (next[k] != 0) {
+      if (prev[next[k]] != k) return 0;
+      k = next[k];
+      if (tag[k]) return 0;
+      tag[k] = 1;
+    }
+    if (last != k) return 0;
+  }
+  for (int k = fr; k != 0; k = next[k]) {
+    if (tag[k]) return 0;
+    tag[k] = 1;
+  }
+  for (int k = 1; k <= n; k++)
+    if (!tag[k]) return 0;
+  return 1;
+}
+
+static int get_slot(nka_hip_t a, const double *base, int32_t slot, double *host_out) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (slot < 1 || slot > a->mvec + 1) return fail(NKA_HIP_EINVAL, "slot out of range");
+  HIP_TRY(hipSetDevice(a->device));
+  HIP_TRY(hipMemcpyAsync(host_out, base + (size_t)(slot - 1) * a->vs.stride, sizeof(double) * (size_t)a->n,
+                         hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, a ? a->vs.w : nullptr, slot, host_out); }
+int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, a ? a->vs.v : nullptr, slot, host_out); }
+
+// ---- distribution hook ---------------------------------------------------------
+
+int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  a->allreduce = fn;
+  a->allreduce_ctx = ctx;
+  return 0;
+}
+
+int nka_hip_comm_unique_id(void *id128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  if (!id128) return fail(NKA_HIP_EINVAL, "id buffer is NULL");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank) {
+  if (!a || !id128) return fail(NKA_HIP_EINVAL, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "bad rank / nranks");
+  HIP_TRY(hipSetDevice(a->device));
+  if (a->comm) {
+    ncclCommDestroy(a->comm);
+    a->comm = nullptr;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t r = ncclCommInitRank(&a->comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    a->comm = nullptr;
+    return fail(NKA_HIP_ECOMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  a->allreduce = rccl_allreduce;
+  a->allreduce_ctx = a;
+  return 0;
+}
+
+// ---- instrumentation -------------------------------------------------------------
+
+int nka_hip_set_timing(nka_hip_t a, int32_t capacity) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (capacity < 0 || capacity > 4096) return fail(NKA_HIP_EINVAL, "timing capacity out of range");
+  HIP_TRY(hipSetDevice(a->device));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  for (auto &e : a->ev)
+    if (e) hipEventDestroy(e);
+  a->ev.assign((size_t)capacity * kTimingEvents, nullptr);
+  for (auto &e : a->ev) HIP_TRY(hipEventCreate(&e));
+  a->timing_cap = capacity;
+  a->timing_count = 0;
+  return 0;
+}
+
+int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
+  if (!a || !ms) return fail(NKA_HIP_EINVAL, "null argument");
+  for (int i = 0; i < 4; i++) ms[i] = 0.f;
+  if (a->timing_cap <= 0 || back < 0 || back >= a->timing_cap || back >= a->timing_count)
+    return fail(NKA_HIP_ESTATE, "no such timed update recorded");
+  HIP_TRY(hipSetDevice(a->device));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  const int slot = (int)((a->timing_count - 1 - back) % a->timing_cap);
+  hipEvent_t *e = a->ev.data() + (size_t)slot * kTimingEvents;
+  HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
+  HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
+  HIP_TRY(hipEventElapsedTime(&ms[2], e[3], e[4]));
+  HIP_TRY(hipEventElapsedTime(&ms[3], e[0], e[4]));
+  return 0;
+}
+
+int nka_hip_set_grid(nka_hip_t a, int32_t p1, int32_t p2, int32_t p3) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  const int32_t v[3] = {p1, p2, p3};
+  for (int i = 0; i < 3; i++) {
+    if (v[i] < 0 || v[i] * a->num_cu > kMaxGrid) return fail(NKA_HIP_EINVAL, "blocks per CU out of range");
+    if (v[i] > 0) a->bpc[i] = v[i];
+  }
+  return 0;
+}
+
+int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (name64) snprintf(name64, 64, "%s", a->devname);
+  if (num_cu) *num_cu = a->num_cu;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,612 @@
+// nka_kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the NKA accel_update hot path.
+//
+// One update is three HBM-streaming passes separated by the three data-dependent
+// synchronisation points of the reference:
+//   P1  k_diffnorm : sum (w1 - f)^2                      (F08:266-267)     reads 2n
+//   P2  k_gram     : w1' = (w1-f)/s, v1' = v1/s, and BOTH Gram rows while the
+//                    stored w's stream past once:  <w1',w_k> (F08:286-290) and
+//                    <f,w_j> (F08:371)                                      reads (3+L)n, writes 2n
+//   P3  k_combine  : f <- f - sum c_k w_k + sum c_k v_k (F08:395-399), and the
+//                    two ring stores w_new = f_in (F08:361), v_new = f_out
+//                    (F08:404) fused into the same pass                     reads (1+2k)n, writes 3n
+// plus single-block scalar kernels: k_finalize (fixed-order sum of the per-block
+// partials => bitwise reproducible dots) and k_solve (list surgery, Cholesky
+// with drops F08:295-351, both substitutions F08:369-392) on ONE wavefront.
+//
+// Everything is fp64 and bandwidth bound (0.29 flop/byte): no MFMA.  Vectors are
+// slot-major, each slot contiguous and 256-B aligned, read with 16-B/lane loads
+// (1 KiB per wave instruction).  Compiled with -ffp-contract=off: the elementwise
+// statements are rounded exactly like the reference expressions; the dot
+// products use explicit fma().
+//
+// F08 = /root/reference/src-F08/nka_type.F90.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nka {
+
+constexpr int kBlock = 256;  // 4 wavefronts of 64
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kMaxGrid = 4096;  // upper bound on persistent grid size (partials buffer)
+
+// ---- indices into the small device-resident control arrays -----------------
+// int32 control block
+enum {
+  IC_SUBSPACE = 0,
+  IC_PENDING = 1,
+  IC_FIRST = 2,
+  IC_LAST = 3,
+  IC_FREE = 4,
+  IC_NEW = 5,          // slot that receives (f_in, f_out) in the current update
+  IC_NCOMB = 6,        // number of (slot, coefficient) pairs in the combine plan
+  IC_PLAN_PENDING = 7, // plan for P1/P2 of the NEXT update: `pending` at its entry
+  IC_PLAN_FIRST = 8,   //   slot holding the pending pair
+  IC_PLAN_NOLDER = 9,  //   number of list entries to dot against
+  IC_NRELAX = 10,      // count of s == 0 events (diagnostic)
+  IC_HEADER = 16
+};
+// double control block
+enum { DC_VTOL = 0, DC_S = 1, DC_HEADER = 2 };
+
+constexpr int kMaxPerPass = 32;  // largest MAXL / MAXK instantiated
+
+struct Ctl {
+  int32_t *ic;         // header, then next[M1+1], prev[M1+1], plan_slots[M1+pad], comb_slots[M1+pad]
+  double *dc;          // header, then h[(M1+1)^2], c[M1+1], comb_c[M1+pad], red[2+2*mvec]
+  int32_t mvec;
+  // plan_slots / comb_slots / comb_c are padded by one pass width: the unrolled
+  // kernels read (and ignore) entries up to the end of their last pass.
+  __host__ __device__ int m1() const { return mvec + 1; }
+  __host__ __device__ int m1p() const { return mvec + 1 + kMaxPerPass; }
+  __host__ __device__ int32_t *next() const { return ic + IC_HEADER; }
+  __host__ __device__ int32_t *prev() const { return next() + (m1() + 1); }
+  __host__ __device__ int32_t *plan_slots() const { return prev() + (m1() + 1); }
+  __host__ __device__ int32_t *comb_slots() const { return plan_slots() + m1p(); }
+  __host__ __device__ int ic_count() const { return IC_HEADER + 2 * (m1() + 1) + 2 * m1p(); }
+  __host__ __device__ double *h() const { return dc + DC_HEADER; }
+  __host__ __device__ double *c() const { return h() + (m1() + 1) * (m1() + 1); }
+  __host__ __device__ double *comb_c() const { return c() + (m1() + 1); }
+  __host__ __device__ double *red() const { return comb_c() + m1p(); }
+  __host__ __device__ int red_count() const { return 2 + 2 * mvec; }
+  __host__ __device__ int dc_count() const {
+    return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count();
+  }
+};
+// red[] layout: [0] sum d^2, [1] <f,w1'>, [2+p] <w1',w_older(p)>, [2+mvec+p] <f,w_older(p)>
+
+struct Vecs {
+  double *v, *w;       // slot k (1-based) at base + (k-1)*stride
+  int64_t stride;      // in doubles, multiple of 32 (256 B)
+  int64_t n;           // local vector length
+};
+
+// ---- reductions ---------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;  // valid in lane 0
+}
+
+// Sum NACC per-thread accumulators over the block (fixed order: lanes by
+// butterfly, then waves 0..3) and store column a at partials[a*G + block].
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[NACC], double *partials, int G) {
+  __shared__ double sm[kWavesPerBlock][NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < NACC; a++) {
+    double r = wave_sum(acc[a]);
+    if (lane == 0) sm[wv][a] = r;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < NACC; a += kBlock) {
+    double r = sm[0][a];
+#pragma unroll
+    for (int q = 1; q < kWavesPerBlock; q++) r += sm[q][a];
+    partials[(size_t)a * G + blockIdx.x] = r;
+  }
+}
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = double; };
+template <> struct VecT<2> { using type = double2; };
+
+template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type ld(const double *p);
+template <> __device__ __forceinline__ double ld<1>(const double *p) { return *p; }
+template <> __device__ __forceinline__ double2 ld<2>(const double *p) {
+  return *reinterpret_cast<const double2 *>(p);
+}
+__device__ __forceinline__ void st(double *p, double x) { *p = x; }
+__device__ __forceinline__ void st(double *p, double2 x) { *reinterpret_cast<double2 *>(p) = x; }
+
+__device__ __forceinline__ double ex(double x, int) { return x; }
+__device__ __forceinline__ double ex(double2 x, int i) { return i ? x.y : x.x; }
+__device__ __forceinline__ void setc(double &x, int, double val) { x = val; }
+__device__ __forceinline__ void setc(double2 &x, int i, double val) {
+  if (i) x.y = val; else x.x = val;
+}
+
+// ---- P1: s^2 = sum (w1 - f)^2 ---------------------------------------------------
+// F08:266-267.  The difference is NOT stored: P2 recomputes it in registers, so
+// this pass reads 2n words and writes nothing.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_diffnorm(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                     double *__restrict__ partials) {
+  const int G = gridDim.x;
+  double acc[1] = {0.0};
+  if (ctl.ic[IC_PLAN_PENDING]) {
+    const double *w1 = vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride;
+    const int64_t ntile = vs.n / (kBlock * VEC);  // full tiles
+    for (int64_t t = blockIdx.x; t < ntile; t += G) {
+      const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+      auto a = ld<VEC>(w1 + e);
+      auto b = ld<VEC>(f + e);
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        double d = ex(a, q) - ex(b, q);
+        acc[0] = fma(d, d, acc[0]);
+      }
+    }
+    if (blockIdx.x == G - 1) {  // ragged tail, scalar
+      const int64_t e = ntile * (kBlock * VEC) + threadIdx.x;
+      for (int64_t i = e; i < vs.n; i += kBlock) {
+        double d = w1[i] - f[i];
+        acc[0] = fma(d, d, acc[0]);
+      }
+    }
+  }
+  block_reduce_store<1>(acc, partials, G);
+}
+
+// ---- fixed-order final sum of per-block partials ---------------------------------
+// out[c] = sum_b partials[c*G + b] for c < ncols ; 0 for ncols <= c < ncols_out.
+// One block; wave w takes columns w, w+4, ...; each lane sums its strided
+// share sequentially, then a butterfly: the order never depends on timing.
+static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_finalize(const double *__restrict__ partials, int G, int ncols,
+                                                     int ncols_out, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = wv; c < ncols_out; c += kWavesPerBlock) {
+    double r = 0.0;
+    if (c < ncols) {
+      for (int b = lane; b < G; b += 64) r += partials[(size_t)c * G + b];
+      r = wave_sum(r);
+    }
+    if (lane == 0) out[c] = r;
+  }
+}
+
+// ---- P2: normalise the pending pair and compute both Gram rows -----------------
+// RCP = false : x / s           (F08:282-283, C)
+// RCP = true  : (1/s) * x       (F08V:255-256 scale(1/s))
+// MAXL older vectors per pass; entries beyond the actual count re-read f (cache
+// hit) into accumulators that are discarded, which keeps every load of a tile
+// unconditional so that all MAXL+3 of them are in flight together.
+template <int MAXL, int VEC, bool RCP>
+__global__ __launch_bounds__(kBlock) void k_gram(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                 double *__restrict__ partials, int pass) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const double *red = ctl.red();
+  const double s = pending ? sqrt(red[0]) : 0.0;
+  const bool norm = pending && (s != 0.0);   // s == 0 -> relax: nothing to normalise (F08:275)
+  const bool first_pass = (pass == 0);
+  const int base = pass * MAXL;
+  const int32_t *slots = ctl.plan_slots();
+
+  double *w1 = vs.w, *v1 = vs.v;
+  if (pending) {
+    const size_t off = (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride;
+    w1 += off;
+    v1 += off;
+  }
+  const double *wk[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; j++) {
+    const int p = base + j;
+    wk[j] = (p < nolder) ? vs.w + (size_t)(slots[p] - 1) * vs.stride : f;
+  }
+  const double rs = 1.0 / s;
+
+  double acc[2 * MAXL + 1];
+#pragma unroll
+  for (int a = 0; a < 2 * MAXL + 1; a++) acc[a] = 0.0;
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V fv = ld<VEC>(f + e);
+    V wn = fv;  // placeholder when !norm (its dots are discarded)
+    V wkv[MAXL];
+#pragma unroll
+    for (int j = 0; j < MAXL; j++) wkv[j] = ld<VEC>(wk[j] + e);
+    if (norm) {
+      V a = ld<VEC>(w1 + e);
+      if (first_pass) {
+        V b = ld<VEC>(v1 + e);
+        V vn;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          const double d = ex(a, q) - ex(fv, q);
+          setc(wn, q, RCP ? rs * d : d / s);
+          setc(vn, q, RCP ? rs * ex(b, q) : ex(b, q) / s);
+        }
+        st(w1 + e, wn);
+        st(v1 + e, vn);
+      } else {
+        wn = a;  // already normalised by pass 0
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; q++) acc[0] = fma(ex(fv, q), ex(wn, q), acc[0]);
+#pragma unroll
+    for (int j = 0; j < MAXL; j++) {
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        acc[1 + j] = fma(ex(wn, q), ex(wkv[j], q), acc[1 + j]);
+        acc[1 + MAXL + j] = fma(ex(fv, q), ex(wkv[j], q), acc[1 + MAXL + j]);
+      }
+    }
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    const int64_t e0 = ntile * (kBlock * VEC) + threadIdx.x;
+    for (int64_t i = e0; i < vs.n; i += kBlock) {
+      const double fv = f[i];
+      double wn = fv;
+      if (norm) {
+        if (first_pass) {
+          const double d = w1[i] - fv;
+          wn = RCP ? rs * d : d / s;
+          const double vn = RCP ? rs * v1[i] : v1[i] / s;
+          w1[i] = wn;
+          v1[i] = vn;
+        } else {
+          wn = w1[i];
+        }
+      }
+      acc[0] = fma(fv, wn, acc[0]);
+#pragma unroll
+      for (int j = 0; j < MAXL; j++) {
+        const double x = wk[j][i];
+        acc[1 + j] = fma(wn, x, acc[1 + j]);
+        acc[1 + MAXL + j] = fma(fv, x, acc[1 + MAXL + j]);
+      }
+    }
+  }
+  block_reduce_store<2 * MAXL + 1>(acc, partials, G);
+}
+
+// Final sums of one P2 pass scattered into red[] (see layout above).
+template <int MAXL>
+__global__ __launch_bounds__(kBlock) void k_finalize_gram(Ctl ctl, const double *__restrict__ partials, int G,
+                                                          int pass) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  double *red = ctl.red();
+  const bool norm = pending && (red[0] != 0.0);  // sqrt(x) == 0 <=> x == 0
+  const int base = pass * MAXL;
+  for (int c = wv; c < 2 * MAXL + 1; c += kWavesPerBlock) {
+    // column -> destination
+    int dst = -1;
+    bool live = false;
+    if (c == 0) {
+      if (pass == 0) { dst = 1; live = norm; }
+    } else if (c <= MAXL) {
+      const int p = base + (c - 1);
+      if (p < ctl.mvec) { dst = 2 + p; live = norm && p < nolder; }
+    } else {
+      const int p = base + (c - 1 - MAXL);
+      if (p < ctl.mvec) { dst = 2 + ctl.mvec + p; live = p < nolder; }
+    }
+    if (dst < 0) continue;
+    double r = 0.0;
+    if (live) {
+      for (int b = lane; b < G; b += 64) r += partials[(size_t)c * G + b];
+      r = wave_sum(r);
+    }
+    if (lane == 0) red[dst] = r;
+  }
+}
+
+// ---- P3: combine + both ring stores --------------------------------------------
+// COMB 0: (f - c*w) + c*v     F08:397
+// COMB 1: ((-c)*w + c*v) + f  F08V:374 via update3_ (grid_vector_type.F90:151)
+// COMB 2: f + c*(v - w)       C .c:423
+// The k loop runs in list order with the reference's association, so given the
+// same coefficients the result is bit-identical to the reference's k passes.
+// MAXK (slot, coefficient) pairs per pass, fully unrolled: offsets and
+// coefficients sit in SGPRs and all 2*MAXK+1 loads of a tile are issued
+// together.  Pairs beyond the actual count re-read f and are not applied.
+// Pass 0 stores w_new = f_in; the last pass stores v_new = f_out.
+template <int COMB>
+__device__ __forceinline__ double comb1(double x, double c, double w, double v) {
+  if (COMB == 0) return (x - c * w) + c * v;
+  if (COMB == 1) return ((-c) * w + c * v) + x;
+  return x + c * (v - w);
+}
+
+template <int MAXK, int VEC, int COMB>
+__global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass,
+                                                    int last_pass) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  const int ncomb = ctl.ic[IC_NCOMB];
+  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
+  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
+  const int32_t *cs = ctl.comb_slots();
+  const double *cc = ctl.comb_c();
+  const int base = pass * MAXK;
+  const bool store_w = (pass == 0), store_v = (last_pass != 0);
+  const bool store_f = store_v ? (ncomb > 0) : true;  // nothing to combine: f stays as it is
+
+  const double *wk[MAXK], *vk[MAXK];
+  double ck[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; j++) {
+    const int k = base + j;
+    const bool live = k < ncomb;
+    const size_t off = live ? (size_t)(cs[k] - 1) * vs.stride : 0;
+    wk[j] = live ? vs.w + off : f;
+    vk[j] = live ? vs.v + off : f;
+    ck[j] = cc[k];
+  }
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const V fin = ld<VEC>(f + e);
+    V wv[MAXK], vv[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; j++) {
+      wv[j] = ld<VEC>(wk[j] + e);
+      vv[j] = ld<VEC>(vk[j] + e);
+    }
+    V x = fin;
+#pragma unroll
+    for (int j = 0; j < MAXK; j++) {
+      if (base + j < ncomb) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wv[j], q), ex(vv[j], q)));
+      }
+    }
+    if (store_w) st(wnew + e, fin);
+    if (store_v) st(vnew + e, x);
+    if (store_f) st(f + e, x);
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    const int64_t e0 = ntile * (kBlock * VEC) + threadIdx.x;
+    for (int64_t i = e0; i < vs.n; i += kBlock) {
+      const double fin = f[i];
+      double x = fin;
+#pragma unroll
+      for (int j = 0; j < MAXK; j++)
+        if (base + j < ncomb) x = comb1<COMB>(x, ck[j], wk[j][i], vk[j][i]);
+      if (store_w) wnew[i] = fin;
+      if (store_v) vnew[i] = x;
+      if (store_f) f[i] = x;
+    }
+  }
+}
+
+// ---- scalar kernels: list surgery + Cholesky + substitutions on one wavefront ----
+// Working copy of the control arrays in LDS (indices as in the Fortran: slots
+// 1..M1, 0 = end of list).
+struct Lst {
+  int32_t *next, *prev;
+  double *h;   // h[i*(M1+1)+j] == reference h(i,j)
+  double *c;
+  int first, last, free_, subspace, pending, m1, mvec;
+  double vtol;
+  __device__ double &H(int i, int j) { return h[i * (m1 + 1) + j]; }
+};
+
+// F08:439-457
+__device__ inline void lst_relax(Lst &L) {
+  if (!L.pending) return;
+  const int dropped = L.first;
+  L.first = L.next[dropped];
+  if (L.first == 0) L.last = 0; else L.prev[L.first] = 0;
+  L.next[dropped] = L.free_;
+  L.free_ = dropped;
+  L.pending = 0;
+}
+
+// F08:422-436
+__device__ inline void lst_restart(Lst &L) {
+  L.subspace = 0;
+  L.pending = 0;
+  L.first = 0;
+  L.last = 0;
+  L.free_ = 1;
+  for (int k = 1; k < L.m1; k++) L.next[k] = k + 1;
+  L.next[L.m1] = 0;
+}
+
+// F08:295-351.  Row-by-row Cholesky of the Gram matrix in list order; capacity
+// drop of the last entry; dependence drop when the pivot hkk <= vtol^2.  The
+// subtraction order of the inner loop (i ascending in list order) is preserved:
+// with equal dot products the decisions equal the reference's bit for bit.
+__device__ inline void lst_factor(Lst &L) {
+  L.H(L.first, L.first) = 1.0;
+  int k = L.next[L.first];
+  int nvec = 1;
+  while (k != 0) {
+    nvec++;
+    if (nvec > L.mvec) {
+      L.next[L.last] = L.free_;
+      L.free_ = k;
+      L.last = L.prev[k];
+      L.next[L.last] = 0;
+      break;
+    }
+    double hkk = 1.0;
+    for (int j = L.first; j != k; j = L.next[j]) {
+      double hkj = L.H(j, k);
+      for (int i = L.first; i != j; i = L.next[i]) hkj = hkj - L.H(k, i) * L.H(j, i);
+      hkj = hkj / L.H(j, j);
+      hkk = hkk - hkj * hkj;
+      L.H(k, j) = hkj;
+    }
+    if (hkk > L.vtol * L.vtol) {
+      L.H(k, k) = sqrt(hkk);
+    } else {
+      const int p = L.prev[k], nx = L.next[k];
+      L.next[p] = nx;
+      if (nx == 0) L.last = p; else L.prev[nx] = p;
+      L.next[k] = L.free_;
+      L.free_ = k;
+      k = p;
+      nvec--;
+    }
+    k = L.next[k];
+  }
+  L.subspace = 1;
+  L.pending = 0;
+}
+
+// F08:369-392 (c holds the right-hand side on entry)
+__device__ inline void lst_solve(Lst &L) {
+  for (int j = L.first; j != 0; j = L.next[j]) {
+    double cj = L.c[j];
+    for (int i = L.first; i != j; i = L.next[i]) cj = cj - L.H(j, i) * L.c[i];
+    L.c[j] = cj / L.H(j, j);
+  }
+  for (int j = L.last; j != 0; j = L.prev[j]) {
+    double cj = L.c[j];
+    for (int i = L.last; i != j; i = L.prev[i]) cj = cj - L.H(i, j) * L.c[i];
+    L.c[j] = cj / L.H(j, j);
+  }
+}
+
+// F08:406-417
+__device__ inline void lst_prepend(Lst &L, int slot) {
+  L.prev[slot] = 0;
+  L.next[slot] = L.first;
+  if (L.first == 0) L.last = slot; else L.prev[L.first] = slot;
+  L.first = slot;
+  L.pending = 1;
+}
+
+constexpr int kSolveThreads = 64;  // ONE wavefront
+
+// dynamic LDS: next[M1+1], prev[M1+1] (int32) then h[(M1+1)^2], c[M1+1] (double)
+__device__ inline void lst_load(Lst &L, const Ctl &ctl, unsigned char *smem) {
+  const int m1 = ctl.m1(), nh = (m1 + 1) * (m1 + 1);
+  L.m1 = m1;
+  L.mvec = ctl.mvec;
+  L.h = reinterpret_cast<double *>(smem);
+  L.c = L.h + nh;
+  L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
+  L.prev = L.next + (m1 + 1);
+  for (int i = threadIdx.x; i < nh; i += kSolveThreads) L.h[i] = ctl.h()[i];
+  for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
+    L.c[i] = ctl.c()[i];
+    L.next[i] = ctl.next()[i];
+    L.prev[i] = ctl.prev()[i];
+  }
+  L.subspace = ctl.ic[IC_SUBSPACE];
+  L.pending = ctl.ic[IC_PENDING];
+  L.first = ctl.ic[IC_FIRST];
+  L.last = ctl.ic[IC_LAST];
+  L.free_ = ctl.ic[IC_FREE];
+  L.vtol = ctl.dc[DC_VTOL];
+  __syncthreads();
+}
+
+__host__ __device__ inline size_t lst_smem_bytes(int mvec) {
+  const int m1 = mvec + 1;
+  return (size_t)((m1 + 1) * (m1 + 1) + (m1 + 1)) * sizeof(double) + 2 * (size_t)(m1 + 1) * sizeof(int32_t);
+}
+
+// Lane 0 writes the scalars and the plan for the next update; all lanes copy
+// the arrays back.
+__device__ inline void lst_store(Lst &L, const Ctl &ctl) {
+  __syncthreads();
+  const int m1 = L.m1, nh = (m1 + 1) * (m1 + 1);
+  for (int i = threadIdx.x; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
+  for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
+    ctl.c()[i] = L.c[i];
+    ctl.next()[i] = L.next[i];
+    ctl.prev()[i] = L.prev[i];
+  }
+  if (threadIdx.x == 0) {
+    ctl.ic[IC_SUBSPACE] = L.subspace;
+    ctl.ic[IC_PENDING] = L.pending;
+    ctl.ic[IC_FIRST] = L.first;
+    ctl.ic[IC_LAST] = L.last;
+    ctl.ic[IC_FREE] = L.free_;
+    // plan for the next update's P1/P2
+    ctl.ic[IC_PLAN_PENDING] = L.pending;
+    ctl.ic[IC_PLAN_FIRST] = L.first;
+    int n = 0;
+    int32_t *ps = ctl.plan_slots();
+    for (int k = L.pending ? L.next[L.first] : L.first; k != 0; k = L.next[k]) ps[n++] = k;
+    ctl.ic[IC_PLAN_NOLDER] = n;
+  }
+}
+
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_restart(Ctl ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lst L;
+  lst_load(L, ctl, smem);
+  if (threadIdx.x == 0) lst_restart(L);
+  lst_store(L, ctl);
+}
+
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_relax(Ctl ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lst L;
+  lst_load(L, ctl, smem);
+  if (threadIdx.x == 0) lst_relax(L);
+  lst_store(L, ctl);
+}
+
+// The scalar part of accel_update between P2 and P3.
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lst L;
+  lst_load(L, ctl, smem);
+  if (threadIdx.x == 0) {
+    const double *red = ctl.red();
+    const int32_t *ps = ctl.plan_slots();
+    const int nolder = ctl.ic[IC_PLAN_NOLDER];
+    const int entry_first = L.first;
+    bool normed = false;
+    if (L.pending) {
+      const double s = sqrt(red[0]);
+      ctl.dc[DC_S] = s;
+      if (s == 0.0) {
+        lst_relax(L);
+        ctl.ic[IC_NRELAX] += 1;
+      }
+    }
+    if (L.pending) {
+      normed = true;
+      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = red[2 + p];
+      lst_factor(L);
+    }
+    const int slot = L.free_;
+    L.free_ = L.next[slot];
+    int ncomb = 0;
+    if (L.subspace) {
+      if (normed) L.c[entry_first] = red[1];
+      for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
+      lst_solve(L);
+      for (int k = L.first; k != 0; k = L.next[k]) {
+        ctl.comb_slots()[ncomb] = k;
+        ctl.comb_c()[ncomb] = L.c[k];
+        ncomb++;
+      }
+    }
+    ctl.ic[IC_NCOMB] = ncomb;
+    ctl.ic[IC_NEW] = slot;
+    lst_prepend(L, slot);
+  }
+  lst_store(L, ctl);
+}
+
+}  // namespace nka

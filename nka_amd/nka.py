@@ -1,0 +1,233 @@
+"""Python mirror of the reference's accelerator object.
+
+Same method names, argument meaning and call-order rules as `type nka` of
+/root/reference/src-F08/nka_type.F90:154-181 (init, set_vec_tol, set_dot_prod,
+accel_update, relax, restart, num_vec, max_vec, vec_len, vec_tol, defined), so
+the parity tests read like the reference's usage.  All arithmetic happens in
+libnka_hip.so on the GPU; this file is plumbing (ctypes + torch for device
+memory and streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FLAVOR_F08, FLAVOR_F08_VECTOR, FLAVOR_C = 0, 1, 2
+
+
+class NKAError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = _lib.load().nka_hip_last_error()
+        raise NKAError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class State:
+    """Snapshot of the private list state (Fortran numbering; 0 = end of list)."""
+
+    def __init__(self, subspace, pending, first, last, free, next_, prev, h, c):
+        self.subspace, self.pending = bool(subspace), bool(pending)
+        self.first, self.last, self.free = int(first), int(last), int(free)
+        self.next, self.prev, self.h, self.c = next_, prev, h, c
+
+    def list_order(self):
+        out, k = [], self.first
+        while k != 0 and len(out) <= len(self.next):
+            out.append(k)
+            k = int(self.next[k - 1])
+        return out
+
+    def free_order(self):
+        out, k = [], self.free
+        while k != 0 and len(out) <= len(self.next):
+            out.append(k)
+            k = int(self.next[k - 1])
+        return out
+
+
+class nka:  # noqa: N801  (the reference's type name)
+    """MI355X accelerator object; see module docstring."""
+
+    def __init__(self):
+        self._h = None
+        self._L = None
+        self._cb = None
+
+    # -- call a%init(vlen, mvec)                      F08:185-200
+    def init(self, vlen: int, mvec: int, *, flavor: int = FLAVOR_F08, device: int | None = None,
+             stream: int | None = None):
+        """vlen is THIS rank's slice length.  Like the Fortran intent(out) dummy,
+        init resets vtol (0.01) and the dot-product hook.  `stream` is a raw
+        hipStream_t (default: torch's current stream on `device`)."""
+        import torch
+
+        self.delete()
+        self._L = _lib.load()
+        if not torch.cuda.is_available():
+            raise NKAError("no HIP device visible: nka_amd has no CPU path")
+        if device is None:
+            device = torch.cuda.current_device()
+        if stream is None:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        _check(self._L.nka_hip_create(C.byref(h), int(vlen), int(mvec), 0.01, int(flavor), int(device),
+                                      C.c_void_p(stream)), "nka_hip_create")
+        self._h, self._device, self._vlen, self._mvec = h, device, int(vlen), int(mvec)
+        return self
+
+    def delete(self):
+        if self._h is not None:
+            self._L.nka_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.delete()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._h is None:
+            raise NKAError("nka object used before init")  # the reference would ASSERT in defined()
+        return self._h
+
+    # -- call a%set_vec_tol(vtol)                     F08:202-207
+    def set_vec_tol(self, vtol: float):
+        _check(self._L.nka_hip_set_vec_tol(self._handle(), float(vtol)), "set_vec_tol")
+
+    # -- call a%set_dot_prod(dot_prod)                F08:209-214
+    def set_dot_prod(self, allreduce):
+        """Distribution hook.  The reference asks for a global dot product; the
+        device build keeps the local partial sums on the GPU and asks only for
+        their global SUM: allreduce(ptr:int, count:int, stream:int) -> None must
+        sum `count` doubles at device address `ptr` over all ranks in place,
+        ordered on `stream`.  None restores the single-rank default."""
+        if allreduce is None:
+            self._cb = None
+            _check(self._L.nka_hip_set_allreduce(self._handle(), C.cast(None, _lib.ALLREDUCE_FN), None), "set_allreduce")
+            return
+
+        def tramp(_ctx, buf, count, stream):
+            try:
+                allreduce(int(buf), int(count), int(stream or 0))
+                return 0
+            except Exception as exc:  # surface as NKA_HIP_ECOMM
+                import sys
+                print(f"nka_amd: allreduce hook raised: {exc!r}", file=sys.stderr)
+                return 1
+
+        self._cb = _lib.ALLREDUCE_FN(tramp)
+        _check(self._L.nka_hip_set_allreduce(self._handle(), self._cb, None), "set_allreduce")
+
+    def use_rccl(self, unique_id: bytes, nranks: int, rank: int):
+        """Built-in hook: one RCCL all-reduce per Gram row on the object's stream."""
+        buf = C.create_string_buffer(unique_id, 128)
+        _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank")
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(_lib.load().nka_hip_comm_unique_id(buf), "comm_unique_id")
+        return buf.raw
+
+    # -- call a%accel_update(f)                       F08:249-419
+    def accel_update(self, f):
+        """f: torch.float64 CUDA tensor of vec_len() elements (updated in place,
+        asynchronously on the object's stream), or a numpy float64 array (host
+        compatibility path: copied to the device and back, synchronous)."""
+        h = self._handle()
+        if isinstance(f, np.ndarray):
+            if f.dtype != np.float64 or not f.flags["C_CONTIGUOUS"] or f.size != self._vlen:
+                raise NKAError("accel_update: need a contiguous float64 array of vec_len() elements")
+            _check(self._L.nka_hip_accel_update_host(h, C.c_void_p(f.ctypes.data)), "accel_update_host")
+            return f
+        import torch
+        if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float64 and f.is_contiguous()
+                and f.numel() == self._vlen):
+            raise NKAError("accel_update: need a contiguous float64 CUDA tensor of vec_len() elements")
+        if f.device.index != self._device:
+            raise NKAError("accel_update: tensor lives on another device than the accelerator")
+        _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update")
+        return f
+
+    # -- call a%restart() / a%relax()                 F08:422-457
+    def restart(self):
+        _check(self._L.nka_hip_restart(self._handle()), "restart")
+
+    def relax(self):
+        _check(self._L.nka_hip_relax(self._handle()), "relax")
+
+    # -- accessors                                    F08:221-246
+    def num_vec(self) -> int:
+        n = self._L.nka_hip_num_vec(self._handle())
+        if n < 0:
+            _check(n, "num_vec")
+        return n
+
+    def max_vec(self) -> int:
+        return self._L.nka_hip_max_vec(self._handle())
+
+    def vec_len(self) -> int:
+        return self._L.nka_hip_vec_len(self._handle())
+
+    def vec_tol(self) -> float:
+        return self._L.nka_hip_vec_tol(self._handle())
+
+    # -- a%defined()                                  F08:460-524
+    def defined(self) -> bool:
+        return self._h is not None and bool(self._L.nka_hip_defined(self._h))
+
+    # -- test / bench instrumentation (not in the reference) ---------------
+    def state(self) -> State:
+        n = self._mvec + 1
+        ints = [C.c_int32() for _ in range(5)]
+        nxt = np.zeros(n, np.int32)
+        prv = np.zeros(n, np.int32)
+        h = np.zeros((n, n), np.float64)
+        c = np.zeros(n, np.float64)
+        _check(self._L.nka_hip_get_state(self._handle(), *[C.byref(i) for i in ints],
+                                         nxt.ctypes.data_as(_lib._i32p), prv.ctypes.data_as(_lib._i32p),
+                                         h.ctypes.data_as(_lib._dp), c.ctypes.data_as(_lib._dp)), "get_state")
+        return State(ints[0].value, ints[1].value, ints[2].value, ints[3].value, ints[4].value, nxt, prv,
+                     h.T.copy(), c)
+
+    def reductions(self) -> np.ndarray:
+        """[|w1-f|^2, <f,w1'>, <w1',w_p>..., <f,w_p>...] of the most recent update."""
+        out = np.zeros(2 + 2 * self._mvec)
+        _check(self._L.nka_hip_get_reductions(self._handle(), out.ctypes.data_as(_lib._dp)), "get_reductions")
+        return out
+
+    def w(self, slot: int) -> np.ndarray:
+        out = np.zeros(self._vlen)
+        _check(self._L.nka_hip_get_w(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_w")
+        return out
+
+    def v(self, slot: int) -> np.ndarray:
+        out = np.zeros(self._vlen)
+        _check(self._L.nka_hip_get_v(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_v")
+        return out
+
+    def set_timing(self, capacity: int = 1):
+        """Keep HIP-event timings of the last `capacity` updates (0 = off)."""
+        _check(self._L.nka_hip_set_timing(self._handle(), int(capacity)), "set_timing")
+
+    def timing_ms(self, back: int = 0):
+        """(P1, P2, P3, whole update) in ms for the update `back` calls ago."""
+        ms = (C.c_float * 4)()
+        _check(self._L.nka_hip_get_timing(self._handle(), int(back), ms), "get_timing")
+        return tuple(ms)
+
+    def set_grid(self, p1=0, p2=0, p3=0):
+        _check(self._L.nka_hip_set_grid(self._handle(), p1, p2, p3), "set_grid")
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        ncu = C.c_int32()
+        _check(self._L.nka_hip_device_info(self._handle(), name, C.byref(ncu)), "device_info")
+        return name.value.decode(), ncu.value

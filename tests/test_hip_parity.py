@@ -1,0 +1,338 @@
+"""Parity of the HIP path (through the C ABI of libnka_hip.so) against the oracle
+and against the fixtures generated from the compiled reference.
+
+The bar:
+  * decisions -- num_vec trace, list order, slot ids, free list, s == 0 -- EXACT;
+  * the scalar step (Cholesky with drops + substitutions) BIT-EXACT given the
+    same dot products;
+  * the elementwise statements BIT-EXACT given the same scalars;
+  * dot products and the returned f within fp64 tolerance:
+        ||f_hip - f_ref||_2 / ||f_in||_2 <= 1e-12   (n <= 1e5)
+    (the reductions are summed in a different -- blocked, fixed -- order).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+TOL_SMALL = 1e-12   # n <= 1e5
+FLAVORS = {0: "f_out_f08", 2: "f_out_c", 1: "f_out_f08vec"}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def make_acc(n, m, flavor=0):
+    import nka_amd
+    return nka_amd.nka().init(n, m, flavor=flavor)
+
+
+def dev_update(torch):
+    def update(acc, f):
+        t = torch.from_numpy(f).cuda()
+        acc.accel_update(t)
+        return t.cpu().numpy()
+    return update
+
+
+@pytest.mark.parametrize("name", S.scenario_names())
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+def test_scenarios_decisions_exact_values_within_tolerance(torch_cuda, oracle, name, flavor):
+    g = S.load(name)
+    key = FLAVORS[flavor]
+    if key not in g.files:
+        pytest.skip("fixture has no output for this flavour")
+    n, m = int(g["n"]), int(g["mvec"])
+    acc = make_acc(n, m, flavor)
+    states = []
+    outs, trace = S.replay(acc, g, update=dev_update(torch_cuda), after_update=lambda u, a: states.append(a.state()))
+    assert acc.defined()
+    assert np.array_equal(trace, g["num_vec"])                       # decisions: exact
+    inputs = [g["inputs"][int(i)] for op, i, _ in g["ops"] if int(op) == S.OP_UPDATE]
+    for u in range(len(outs)):
+        assert S.rel_err(outs[u], g[key][u], inputs[u]) <= TOL_SMALL, (name, u)
+    if "first" in g.files:                                           # list state of the C reference
+        for u, st in enumerate(states):
+            assert (st.first, st.last, st.free) == (g["first"][u], g["last"][u], g["free"][u]), (name, u)
+            assert st.subspace == bool(g["subspace"][u]) and st.pending
+            assert np.array_equal(st.next, g["next"][u]), (name, u)
+            order = st.list_order()
+            for k in order:
+                assert st.prev[k - 1] == g["prev"][u][k - 1]
+            live = order[1:]
+            hh, gg = st.h[np.ix_([k - 1 for k in live], [k - 1 for k in live])], \
+                g["h"][u][np.ix_([k - 1 for k in live], [k - 1 for k in live])]
+            assert np.allclose(hh, gg, rtol=0, atol=1e-12), (name, u)
+
+
+@pytest.mark.parametrize("name", ["S2_dependence", "S3_zero_difference", "S9_near_dependence", "S1_capacity"])
+def test_scalar_step_bit_exact_given_same_dots(torch_cuda, oracle, name):
+    """Feed the oracle's scalar step the dot products the device produced: the
+    device solve kernel (one wavefront) must then agree BIT FOR BIT on the
+    factor h, the coefficients c and every list decision."""
+    g = S.load(name)
+    n, m = int(g["n"]), int(g["mvec"])
+    acc = make_acc(n, m, 0)
+    ora = oracle.OracleNKA(n, m, oracle.F08)
+
+    def check(u, a):
+        red = a.reductions()
+        so = ora.state()                      # oracle state at entry of this update
+        hrow = np.zeros(m + 2)
+        b = np.zeros(m + 2)
+        order = so.list_order()
+        older = order[1:] if so.pending else order
+        for p, k in enumerate(older):
+            hrow[k] = red[2 + p]
+            b[k] = red[2 + m + p]
+        s = np.sqrt(red[0]) if so.pending else 0.0
+        if so.pending:
+            b[so.first] = red[1]
+        new = ora.scalar_step(float(s), hrow, b)
+        sd, sn = a.state(), ora.state()
+        assert (sd.first, sd.last, sd.free, sd.subspace, sd.pending) == (sn.first, sn.last, sn.free, sn.subspace, sn.pending)
+        assert sd.first == new
+        assert np.array_equal(sd.next, sn.next)
+        live = sn.list_order()[1:]
+        for i in live:
+            assert sd.prev[i - 1] == sn.prev[i - 1]
+            assert sd.c[i - 1] == sn.c[i - 1], (name, u, i)            # bit for bit
+            for j in live:
+                assert sd.h[i - 1, j - 1] == sn.h[i - 1, j - 1], (name, u, i, j)
+
+    u = 0
+    for op, idx, val in g["ops"]:
+        op = int(op)
+        if op == S.OP_UPDATE:
+            t = torch_cuda.from_numpy(g["inputs"][int(idx)].copy()).cuda()
+            acc.accel_update(t)
+            check(u, acc)
+            u += 1
+        elif op == S.OP_RESTART:
+            acc.restart(); ora.restart()
+        elif op == S.OP_RELAX:
+            acc.relax(); ora.relax()
+        elif op == S.OP_SET_VEC_TOL:
+            acc.set_vec_tol(float(val)); ora.set_vec_tol(float(val))
+        assert acc.num_vec() == ora.num_vec()
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 2, 255, 513, 4099])
+def test_elementwise_statements_bit_exact_given_same_scalars(torch_cuda, flavor, n):
+    """w1' = (w1-f)/s, v1' = v1/s, the combine and both ring stores, recomputed
+    with numpy (IEEE, no FMA) from the device's own scalars, must match the
+    device bit for bit -- including ragged tails and the 1-element case."""
+    m = 3
+    rng = np.random.default_rng(100 + n)
+    acc = make_acc(n, m, flavor)
+    prev_in = None
+    for t in range(7):
+        f_in = rng.standard_normal(n)
+        st0 = acc.state()
+        first0 = st0.first
+        w1_raw = acc.w(first0) if st0.pending else None
+        v1_raw = acc.v(first0) if st0.pending else None
+        ft = torch_cuda.from_numpy(f_in.copy()).cuda()
+        acc.accel_update(ft)
+        f_out = ft.cpu().numpy()
+        st = acc.state()
+        red = acc.reductions()
+        new = st.first
+        assert np.array_equal(acc.w(new), f_in)                    # w(:,new) = f       F08:361
+        assert np.array_equal(acc.v(new), f_out)                   # v(:,new) = f_out   F08:404
+        if st0.pending:
+            assert np.array_equal(w1_raw, prev_in)
+            s = np.sqrt(red[0])
+            d = w1_raw - f_in
+            if flavor == 1:
+                r = 1.0 / s
+                wn, vn = r * d, r * v1_raw
+            else:
+                wn, vn = d / s, v1_raw / s
+            assert np.array_equal(acc.w(first0), wn)
+            assert np.array_equal(acc.v(first0), vn)
+        x = f_in.copy()
+        for k in st.list_order()[1:]:
+            c, wk, vk = st.c[k - 1], acc.w(k), acc.v(k)
+            if flavor == 0:
+                x = (x - c * wk) + c * vk
+            elif flavor == 1:
+                x = ((-c) * wk + c * vk) + x
+            else:
+                x = x + c * (vk - wk)
+        assert np.array_equal(f_out, x)
+        prev_in = f_in
+
+
+def test_dot_products_within_tolerance(torch_cuda):
+    n, m = 100003, 6
+    rng = np.random.default_rng(5)
+    acc = make_acc(n, m)
+    for t in range(9):
+        f_in = rng.standard_normal(n)
+        st0 = acc.state()
+        order0 = st0.list_order()
+        olders = order0[1:] if st0.pending else order0
+        W = {k: acc.w(k) for k in olders}
+        w1_raw = acc.w(st0.first) if st0.pending else None
+        ft = torch_cuda.from_numpy(f_in.copy()).cuda()
+        acc.accel_update(ft)
+        red = acc.reductions()
+        if st0.pending:
+            d = w1_raw - f_in
+            assert red[0] == pytest.approx(float(d @ d), rel=1e-13)
+            wn = acc.w(st0.first)
+            assert red[1] == pytest.approx(float(f_in @ wn), abs=1e-13 * np.linalg.norm(f_in))
+            for p, k in enumerate(olders):
+                assert red[2 + p] == pytest.approx(float(wn @ W[k]), abs=1e-13)
+                assert red[2 + m + p] == pytest.approx(float(f_in @ W[k]), abs=1e-13 * np.linalg.norm(f_in))
+
+
+def test_medium_case_against_f08_reference_fixture(torch_cuda):
+    g = np.load(os.path.join(S.GOLD, "medium_n100000_m10.npz"))
+    n, m, calls = int(g["n"]), int(g["mvec"]), int(g["calls"])
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    acc = make_acc(n, m)
+    probe = np.cos(np.arange(n) * 0.001)
+    for t in range(calls):
+        f = rng.random(n) * 2.0 - 1.0
+        fin_norm = np.linalg.norm(f)
+        ft = torch_cuda.from_numpy(f).cuda()
+        acc.accel_update(ft)
+        out = ft.cpu().numpy()
+        assert acc.num_vec() == g["num_vec"][t]
+        # sampled entries / norm / probe functional of the reference output
+        assert np.linalg.norm(out[g["idx"]] - g["out_samples"][t]) <= TOL_SMALL * fin_norm
+        assert abs(np.linalg.norm(out) - g["out_norm"][t]) <= TOL_SMALL * fin_norm
+        assert abs(float(out @ probe) - g["out_probe"][t]) <= TOL_SMALL * fin_norm * np.linalg.norm(probe)
+
+
+@pytest.mark.parametrize("n,m", [(0, 2), (1, 1), (7, 8), (1000, 1), (777, 40), (2048, 33), (5000, 64)])
+def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m):
+    """Empty and tiny vectors, mvec = 1, and mvec beyond one unrolled pass (the
+    P2/P3 kernels then run several passes of 32)."""
+    rng = np.random.default_rng(n * 131 + m)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    ncall = min(m + 4, 45)
+    basis = rng.standard_normal((3, n))
+    for t in range(ncall):
+        x = rng.standard_normal(n) if (t % 5) else rng.standard_normal(3) @ basis
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        out = ft.cpu().numpy()
+        assert acc.num_vec() == ora.num_vec(), (t,)
+        assert acc.state().list_order() == ora.state().list_order()
+        assert acc.state().free_order() == ora.state().free_order()
+        if n:
+            assert S.rel_err(out, f, x) <= 1e-11, (t, S.rel_err(out, f, x))
+    assert acc.defined()
+
+
+def test_unaligned_device_pointer_takes_scalar_path(torch_cuda, oracle):
+    n, m = 3001, 5
+    rng = np.random.default_rng(9)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    buf = torch_cuda.zeros(n + 1, dtype=torch_cuda.float64, device="cuda")
+    view = buf[1:]                                   # 8-byte but not 16-byte aligned
+    assert view.data_ptr() % 16 == 8
+    for t in range(9):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        view.copy_(torch_cuda.from_numpy(x))
+        acc.accel_update(view)
+        assert acc.num_vec() == ora.num_vec()
+        assert S.rel_err(view.cpu().numpy(), f, x) <= TOL_SMALL
+
+
+def test_host_array_compat_entry_and_config1_example(torch_cuda, oracle):
+    """BASELINE config 1: the 50x50 example driven through the HIP path (host
+    array entry point, like the reference signature) reproduces reference_output."""
+    import json
+    with open(os.path.join(S.GOLD, "example_tables.json")) as fh:
+        tables = json.load(fh)
+    for mvec, nsweep, key in ((5, 2, "f08 --nka-vec 5"), (5, 4, "f08 --sweeps 4 --nka-vec 5")):
+        acc = make_acc(2500, mvec)
+        rn, _ = oracle.example_solve(nsweep=nsweep, accel=acc)
+        lines = [f"{0:3d}:{rn[0]:14.6E}"] + [oracle.format_example_line(i, rn[i], rn[0]) for i in range(1, len(rn))]
+        assert lines[-1] == tables[key][-1]
+        assert lines == tables[key][1:]
+
+
+def test_api_surface_defaults_and_errors(torch_cuda):
+    import nka_amd
+    a = nka_amd.nka()
+    with pytest.raises(nka_amd.NKAError):
+        a.num_vec()                                   # used before init
+    with pytest.raises(nka_amd.NKAError):
+        a.init(10, 0)                                 # mvec > 0      (F08:190)
+    with pytest.raises(nka_amd.NKAError):
+        a.init(-1, 3)                                 # vlen >= 0     (F08:191)
+    a.init(10, 3)
+    assert (a.vec_len(), a.max_vec(), a.num_vec(), a.vec_tol()) == (10, 3, 0, 0.01)
+    assert a.defined()
+    with pytest.raises(nka_amd.NKAError):
+        a.set_vec_tol(0.0)                            # vtol > 0      (F08:205)
+    a.set_vec_tol(0.5)
+    assert a.vec_tol() == 0.5
+    f = torch_cuda.arange(10, dtype=torch_cuda.float64, device="cuda")
+    g = f.clone()
+    a.accel_update(g)
+    assert torch_cuda.equal(f, g) and a.num_vec() == 0      # first call returns f unchanged
+    a.relax()
+    assert a.num_vec() == 0 and a.state().first == 0 and a.defined()
+    with pytest.raises(nka_amd.NKAError):
+        a.accel_update(torch_cuda.zeros(11, dtype=torch_cuda.float64, device="cuda"))   # size(f) == vlen (F08:258)
+    a.init(10, 3)                                     # re-init resets vtol (intent(out), F08:186)
+    assert a.vec_tol() == 0.01
+
+
+def test_runs_are_bitwise_reproducible(torch_cuda):
+    n, m = 200001, 7
+    outs = []
+    for rep in range(2):
+        rng = np.random.default_rng(77)
+        acc = make_acc(n, m)
+        res = []
+        for t in range(12):
+            ft = torch_cuda.from_numpy(rng.standard_normal(n)).cuda()
+            acc.accel_update(ft)
+            res.append(ft.cpu().numpy())
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_rccl_hook_single_rank_and_python_hook(torch_cuda, oracle):
+    """The distribution hook with one rank: the built-in RCCL all-reduce and a
+    Python hook must both leave the results unchanged."""
+    import nka_amd
+    n, m = 5003, 4
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((8, n))
+    ref = make_acc(n, m)
+    a_rccl = make_acc(n, m)
+    a_rccl.use_rccl(nka_amd.nka.rccl_unique_id(), 1, 0)
+    a_py = make_acc(n, m)
+    calls = []
+    a_py.set_dot_prod(lambda ptr, count, stream: calls.append(count))
+    for t in range(8):
+        outs = []
+        for acc in (ref, a_rccl, a_py):
+            ft = torch_cuda.from_numpy(X[t].copy()).cuda()
+            acc.accel_update(ft)
+            outs.append(ft.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert set(calls) == {1, 1 + 2 * m}
