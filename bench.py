@@ -9,14 +9,15 @@ path of /root/reference/src-F08/nka_type.F90:249-419 in steady state (subspace
 full: L = k = mvec), inputs already resident in HBM when the timed region
 starts.  Workload at N=1: BASELINE.json configs[2], n=1e8, mvec=20, fp64.
 With N>1 the SAME global vector is sharded by contiguous slices (strong
-scaling, BASELINE configs[3]); the only exchange is one RCCL all-reduce of 1
-double after P1 and one of 1+2*mvec doubles after P2, on the kernel stream.
+scaling, BASELINE configs[3]); the only exchange is ONE RCCL all-reduce of
+2+2*mvec doubles per update (the norm and both Gram rows), on the kernel stream.
 
 Prints ONE JSON line (rank 0) with the driver's keys plus
   roofline     : algorithmic bytes of one update, 8*n*(11+L+2k),
                  over the mean device time of an update measured with HIP events
                  on the kernel stream during the timed steps; per-kernel figures
-                 for P1/P2/P3 under "kernels" (P3 k_combine is the dominant one)
+                 for PA k_dots / PB k_combine under "kernels" with the bytes each
+                 launch actually moves (PB is the dominant kernel)
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
                  oracle port timed on this box's host on a bounded sample.
 """
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--n", type=float, default=1e8, help="GLOBAL vector length")
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=float, default=4e6, help="vector length of the CPU sample")
+    ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")
     ap.add_argument("--allreduce", choices=["rccl", "torch"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
     return ap.parse_args()
 
@@ -194,13 +195,16 @@ def main():
 
     if rank == 0:
         L = k = m
-        words = {"P1_k_diffnorm": 2, "P2_k_gram": 5 + L, "P3_k_combine": 4 + 2 * k}
-        b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # per update, per GPU
+        # words (8 B) per element each launch moves: PA reads w1, f and L stored w's;
+        # PB reads f + k (w,v) pairs and writes w1', v1', w_new, v_new, f
+        words = {"PA_k_dots": 2 + L, "PB_k_combine": (1 + 2 * k) + 5}
+        b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # SURVEY.md 8(d), per update, per GPU
         upd_s = mean[3] * 1e-3
         kernels = {}
-        for (name, w), ms in zip(words.items(), mean[:3]):
-            kernels[name] = {"algorithmic_bytes": 8.0 * n_local * w, "mean_ms": ms,
+        for (name, w), ms in zip(words.items(), (mean[0], mean[2])):
+            kernels[name] = {"bytes_moved": 8.0 * n_local * w, "mean_ms": ms,
                              "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None}
+        kernels["k_solve"] = {"mean_ms": mean[1]}
         achieved = b_alg / upd_s / 1e9 if upd_s > 0 else 0.0
         out = {
             "metric": "NKA accel_update throughput (updates/s) at n=%.0e, m=%d, fp64" % (n_global, m),
@@ -218,7 +222,8 @@ def main():
                          "what": "whole accel_update on one GPU: algorithmic bytes 8*n_local*(11+L+2k) / mean "
                                  "device time first-kernel-start..last-kernel-end (HIP events, kernel stream)",
                          "algorithmic_bytes_per_update": b_alg, "mean_update_ms": mean[3],
-                         "dominant_kernel": "P3_k_combine", "kernels": kernels,
+                         "bytes_moved_per_update": 8.0 * n_local * (8 + L + 2 * k),
+                         "dominant_kernel": "PB_k_combine", "kernels": kernels,
                          "copy_ceiling_GBps": copy_gbps},
             "aggregate_algorithmic_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
         }

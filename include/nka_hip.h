@@ -54,8 +54,8 @@ enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C =
 /* Replaces  call a%init(vlen, mvec)  (F08:185-200)  /  nka_init(vlen, mvec,
  * vtol, dp)  (C .h:4, .c:211-258).  vlen_local is THIS rank's slice length
  * (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).
- * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = the
- * library creates its own).  Allocates 2*(mvec+1) slot vectors on the device. */
+ * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = HIP's
+ * default stream).  Allocates 2*(mvec+1) slot vectors on the device. */
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
 
@@ -95,10 +95,12 @@ int nka_hip_defined(nka_hip_t a);      /* F08:460-524 ; 1 = well defined */
 int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t *first,
                       int32_t *last, int32_t *free_, int32_t *next, int32_t *prev,
                       double *h, double *c);
-/* The reduced dot products of the most recent update as the device solve saw
- * them: red[0] = |w1-f|^2, red[1] = <f,w1'>, red[2+p] = <w1',w_p>,
- * red[2+mvec+p] = <f,w_p> for the p-th older list entry (2+2*mvec doubles).
- * With these a CPU restatement of the scalar step can be checked bit for bit. */
+/* The reduced inner products of the most recent update as the device solve saw
+ * them, with d = w1 - f the new (not yet normalised) difference:
+ * red[0] = <d,d>, red[1] = <f,d>, red[2+p] = <d,w_p>, red[2+mvec+p] = <f,w_p>
+ * for the p-th older list entry (2+2*mvec doubles).  The solve divides the d
+ * rows by s = sqrt(red[0]).  With these a CPU restatement of the scalar step
+ * can be checked bit for bit. */
 int nka_hip_get_reductions(nka_hip_t a, double *red_out);
 /* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
 int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);
@@ -111,8 +113,9 @@ int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);
  * product; here the local partial sums already live on the device, so the
  * hook is the global SUM of `count` doubles at device address `buf`, in place,
  * enqueued on `stream` (hipStream_t).  Must return 0 on success, and must give
- * bit-identical results on every rank.  Called 2 times per accel_update (count
- * 1, then 1+2*mvec).  NULL restores the single-rank default (no reduction). */
+ * bit-identical results on every rank.  Called ONCE per accel_update (count
+ * 2+2*mvec: the norm, and both Gram rows).  NULL restores the single-rank
+ * default (no reduction). */
 typedef int (*nka_hip_allreduce_fn)(void *ctx, double *buf, int32_t count, void *stream);
 int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx);
 
@@ -128,15 +131,14 @@ int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32
  * nka_hip_set_timing(a, capacity) keeps the events of the last `capacity`
  * updates in a ring (0 switches timing off); recording never synchronises.
  * nka_hip_get_timing(a, back, ms) synchronises and returns, for the update
- * `back` calls ago (0 = most recent):  ms[0] = P1 difference+norm (with its
- * final sum and all-reduce), ms[1] = P2 normalise+Gram rows (ditto), ms[2] = P3
- * combine+ring stores, ms[3] = whole update, first kernel start -> last end. */
+ * `back` calls ago (0 = most recent):  ms[0] = PA k_dots (with its final sums
+ * and the all-reduce), ms[1] = k_solve, ms[2] = PB k_combine, ms[3] = whole
+ * update, first kernel start -> last kernel end. */
 int nka_hip_set_timing(nka_hip_t a, int32_t capacity);
 int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 
-/* Launch geometry knobs for tuning: blocks per CU of P1, P2, P3 (0 = keep). */
-int nka_hip_set_grid(nka_hip_t a, int32_t p1_blocks_per_cu, int32_t p2_blocks_per_cu,
-                     int32_t p3_blocks_per_cu);
+/* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = keep). */
+int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
 const char *nka_hip_last_error(void);
 /* "gfx950"-style name of the device the handle runs on, CU count. */

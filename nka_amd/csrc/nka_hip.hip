@@ -3,8 +3,7 @@
 // The accelerator object (reference: `type nka`, src-F08/nka_type.F90:154-181)
 // keeps ALL of its state on the device: the 2*(mvec+1) slot vectors, the Gram /
 // Cholesky matrix h, the linked lists and the flags.  accel_update enqueues
-//   P1 k_diffnorm -> k_finalize -> [all-reduce 1] ->
-//   P2 k_gram -> k_finalize_gram -> [all-reduce 1+2*mvec] -> k_solve -> P3 k_combine
+//   PA k_dots -> k_finalize_dots -> [all-reduce 2+2*mvec] -> k_solve -> PB k_combine
 // on one HIP stream and returns; nothing is read back.  The host only tracks what
 // it can know without looking: whether a pair is pending, and an upper bound on
 // the list length (used to pick the unroll width of P2/P3).
@@ -60,7 +59,6 @@ int env_int(const char *name, int dflt) {
 struct nka_hip_state {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool own_stream = false;
   int64_t n = 0;
   int32_t mvec = 0;
   double vtol = 0.01;
@@ -74,7 +72,7 @@ struct nka_hip_state {
   int list_ub = 0;            // upper bound on the list length
   // launch geometry
   int num_cu = 256;
-  int bpc[3] = {8, 8, 8};     // caps; the grid also respects each kernel's occupancy
+  int bpc[2] = {2, 2};        // blocks per CU of PA, PB (caps; the grid also respects occupancy)
   char devname[64] = {0};
   // distribution hook
   nka_hip_allreduce_fn allreduce = nullptr;
@@ -115,18 +113,19 @@ int rccl_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
 }
 
 // ---- kernel dispatch by unroll width ------------------------------------------
-template <int MAXL, int VEC, bool RCP>
-int launch_gram_1(const nka_hip_state *a, const double *f, int pass) {
-  static const int occ = occupancy_of(k_gram<MAXL, VEC, RCP>);
-  const int g = grid_for(a, 1, VEC, occ);
-  hipLaunchKernelGGL((k_gram<MAXL, VEC, RCP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
+template <int MAXL, int VEC>
+int launch_dots_1(const nka_hip_state *a, const double *f, int pass) {
+  static const int occ = occupancy_of(k_dots<MAXL, VEC>);
+  const int g = grid_for(a, 0, VEC, occ);
+  hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
+  hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
+                     a->partials, g, pass);
   return g;
 }
 
-template <int VEC, bool RCP>
-int launch_gram_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
+int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
 #define CASE(L) \
-  case L: return launch_gram_1<L, VEC, RCP>(a, f, pass);
+  case L: return launch_dots_1<L, 2>(a, f, pass);
   switch (maxl) {
     CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
   }
@@ -134,21 +133,10 @@ int launch_gram_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
   return 0;
 }
 
-void launch_finalize_gram(int maxl, hipStream_t s, Ctl ctl, const double *partials, int G, int pass) {
-#define CASE(L)                                                                                   \
-  case L:                                                                                         \
-    hipLaunchKernelGGL((k_finalize_gram<L>), dim3(1), dim3(kBlock), 0, s, ctl, partials, G, pass); \
-    break;
-  switch (maxl) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
-  }
-#undef CASE
-}
-
 template <int MAXK, int VEC, int COMB>
 int launch_combine_1(const nka_hip_state *a, double *f, int pass, int last) {
   static const int occ = occupancy_of(k_combine<MAXK, VEC, COMB>);
-  const int g = grid_for(a, 2, VEC, occ);
+  const int g = grid_for(a, 1, VEC, occ);
   hipLaunchKernelGGL((k_combine<MAXK, VEC, COMB>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, pass, last);
   return g;
 }
@@ -164,17 +152,9 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
   return 0;
 }
 
-template <int VEC>
-int launch_diffnorm(const nka_hip_state *a, const double *f) {
-  static const int occ = occupancy_of(k_diffnorm<VEC>);
-  const int g = grid_for(a, 0, VEC, occ);
-  hipLaunchKernelGGL((k_diffnorm<VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
-  return g;
-}
-
 int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
 
-constexpr int kTimingEvents = 5;
+constexpr int kTimingEvents = 4;
 
 int record(nka_hip_state *a, int i) {
   if (a->timing_cap <= 0) return 0;
@@ -213,20 +193,12 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   a->num_cu = prop.multiProcessorCount;
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
-  a->bpc[0] = env_int("NKA_HIP_P1_BLOCKS_PER_CU", a->bpc[0]);
-  a->bpc[1] = env_int("NKA_HIP_P2_BLOCKS_PER_CU", a->bpc[1]);
-  a->bpc[2] = env_int("NKA_HIP_P3_BLOCKS_PER_CU", a->bpc[2]);
+  a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
+  a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
-  if (stream) {
-    a->stream = (hipStream_t)stream;
-  } else {
-    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      delete a;
-      return fail(NKA_HIP_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-    }
-    a->own_stream = true;
-  }
+  // NULL is HIP's default (null) stream, as everywhere in HIP: work is ordered
+  // with whatever else the caller enqueues there.
+  a->stream = (hipStream_t)stream;
 
   // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
   // the slot stride is padded to 256 B so every slot base allows 16-B loads,
@@ -273,7 +245,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
 int nka_hip_destroy(nka_hip_t a) {
   if (!a) return 0;
   hipSetDevice(a->device);
-  if (a->stream) hipStreamSynchronize(a->stream);
+  hipStreamSynchronize(a->stream);
   if (a->comm) ncclCommDestroy(a->comm);
   hipFree(a->vs.v);
   hipFree(a->vs.w);
@@ -284,7 +256,6 @@ int nka_hip_destroy(nka_hip_t a) {
   for (auto &e : a->ev)
     if (e) hipEventDestroy(e);
   a->ev.clear();
-  if (a->own_stream && a->stream) hipStreamDestroy(a->stream);
   delete a;
   return 0;
 }
@@ -332,39 +303,28 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = record(a, 0)) return rc;
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
 
-  // ---- P1: s^2 = |w1 - f|^2 (only if a pair is pending, F08:263-267) ----
-  if (a->pending) {
-    const int g = (vec == 2) ? launch_diffnorm<2>(a, f) : launch_diffnorm<1>(a, f);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, s, a->partials, g, 1, 1, a->ctl.red());
-    HIP_TRY(hipGetLastError());
-    if (a->allreduce)
-      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
-  }
-  if (int rc = record(a, 1)) return rc;
-
-  // ---- P2: normalise + both Gram rows (F08:282-290, 371) ----
+  // ---- PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371) ----
   // Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
   if (a->pending || older_ub > 0) {
     const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
     const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
     for (int p = 0; p < npass; p++) {
-      int g;
-      if (vec == 2) g = rcp ? launch_gram_w<2, true>(maxl, a, f, p) : launch_gram_w<2, false>(maxl, a, f, p);
-      else g = rcp ? launch_gram_1<4, 1, true>(a, f, p) : launch_gram_1<4, 1, false>(a, f, p);
-      launch_finalize_gram(maxl, s, a->ctl, a->partials, g, p);
+      if (vec == 2) launch_dots_w(maxl, a, f, p);
+      else launch_dots_1<4, 1>(a, f, p);
     }
     HIP_TRY(hipGetLastError());
+    // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
     if (a->allreduce)
-      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red() + 1, 1 + 2 * a->mvec, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), a->ctl.red_count(), s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
   }
+  if (int rc = record(a, 1)) return rc;
+
+  // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
+  HIP_TRY(hipGetLastError());
   if (int rc = record(a, 2)) return rc;
 
-  // ---- scalar part on one wavefront (F08:275, 295-358, 366-392, 406-417) ----
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl);
-  HIP_TRY(hipGetLastError());
-  if (int rc = record(a, 3)) return rc;
-
-  // ---- P3: combine + ring stores (F08:361, 395-404) ----
+  // ---- PB: normalise + combine + ring stores (F08:282-283, 361, 395-404) ----
   // after the subspace update the list holds at most min(list_ub, mvec) vectors
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
   {
@@ -388,7 +348,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
     }
     HIP_TRY(hipGetLastError());
   }
-  if (int rc = record(a, 4)) return rc;
+  if (int rc = record(a, 3)) return rc;
 
   if (a->timing_cap > 0) a->timing_count++;
   a->list_ub = comb_ub + 1;
@@ -584,15 +544,15 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
   hipEvent_t *e = a->ev.data() + (size_t)slot * kTimingEvents;
   HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
   HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
-  HIP_TRY(hipEventElapsedTime(&ms[2], e[3], e[4]));
-  HIP_TRY(hipEventElapsedTime(&ms[3], e[0], e[4]));
+  HIP_TRY(hipEventElapsedTime(&ms[2], e[2], e[3]));
+  HIP_TRY(hipEventElapsedTime(&ms[3], e[0], e[3]));
   return 0;
 }
 
-int nka_hip_set_grid(nka_hip_t a, int32_t p1, int32_t p2, int32_t p3) {
+int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
-  const int32_t v[3] = {p1, p2, p3};
-  for (int i = 0; i < 3; i++) {
+  const int32_t v[2] = {pa, pb};
+  for (int i = 0; i < 2; i++) {
     if (v[i] < 0 || v[i] * a->num_cu > kMaxGrid) return fail(NKA_HIP_EINVAL, "blocks per CU out of range");
     if (v[i] > 0) a->bpc[i] = v[i];
   }

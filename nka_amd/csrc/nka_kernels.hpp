@@ -1,29 +1,45 @@
 // nka_kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the NKA accel_update hot path.
 //
-// One update is three HBM-streaming passes separated by the three data-dependent
-// synchronisation points of the reference:
-//   P1  k_diffnorm : sum (w1 - f)^2                      (F08:266-267)     reads 2n
-//   P2  k_gram     : w1' = (w1-f)/s, v1' = v1/s, and BOTH Gram rows while the
-//                    stored w's stream past once:  <w1',w_k> (F08:286-290) and
-//                    <f,w_j> (F08:371)                                      reads (3+L)n, writes 2n
-//   P3  k_combine  : f <- f - sum c_k w_k + sum c_k v_k (F08:395-399), and the
-//                    two ring stores w_new = f_in (F08:361), v_new = f_out
-//                    (F08:404) fused into the same pass                     reads (1+2k)n, writes 3n
-// plus single-block scalar kernels: k_finalize (fixed-order sum of the per-block
-// partials => bitwise reproducible dots) and k_solve (list surgery, Cholesky
-// with drops F08:295-351, both substitutions F08:369-392) on ONE wavefront.
+// One update is TWO HBM-streaming passes around one scalar step:
+//   PA  k_dots    : pure-read pass.  While w1 (the raw previous f), f and the L
+//                   stored w's stream past once it accumulates ALL the inner
+//                   products the update needs:  sum d^2 with d = w1 - f
+//                   (F08:266-267), <f,d>, <d,w_k> (F08:286-290) and <f,w_k>
+//                   (F08:371).  The Gram row of the normalised w1' = d/s follows
+//                   by one scalar division per entry in k_solve.  Reads (2+L)n
+//                   words, writes nothing -- a kernel without stores streams at
+//                   ~6.8 TB/s on MI355X, one with any store at ~5.3 TB/s
+//                   (tools/hbm_probe.hip), so every store of the update is
+//                   concentrated in PB.
+//   --  k_finalize_dots (fixed-order sums => bitwise reproducible), [one
+//       all-reduce of 2+2*mvec doubles], k_solve (s, s == 0 -> relax F08:275,
+//       Cholesky with drops F08:295-351, both substitutions F08:369-392, list
+//       surgery) on ONE wavefront.
+//   PB  k_combine : w1' = (w1-f)/s and v1' = v1/s (F08:282-283) formed in
+//                   registers and stored, f <- f - sum c_k w_k + sum c_k v_k in
+//                   list order (F08:395-399), and the two ring stores w_new = f_in
+//                   (F08:361), v_new = f_out (F08:404).  Reads (1+2k)n, writes 5n.
+// That moves 8n(8+L+2k) bytes per update against the 8n(11+L+2k) of the
+// three-pass schedule of SURVEY.md 8(d), with ONE synchronisation point.
 //
 // Everything is fp64 and bandwidth bound (0.29 flop/byte): no MFMA.  Vectors are
-// slot-major, each slot contiguous and 256-B aligned, read with 16-B/lane loads
-// (1 KiB per wave instruction).  Compiled with -ffp-contract=off: the elementwise
-// statements are rounded exactly like the reference expressions; the dot
-// products use explicit fma().
+// slot-major, each slot contiguous and 256-B aligned, read with 16-B/lane
+// non-temporal loads (1 KiB per wave instruction).  Compiled with
+// -ffp-contract=off: the elementwise statements are rounded exactly like the
+// reference expressions; the dot products use explicit fma().
 //
 // F08 = /root/reference/src-F08/nka_type.F90.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifndef NKA_NT_LOADS
+#define NKA_NT_LOADS 1      // streaming reads: non-temporal (nt) loads
+#endif
+#ifndef NKA_STORE_POLICY
+#define NKA_STORE_POLICY 0  // 0 plain, 1 nt, 2 write-through "sc0 sc1 nt" (inline asm)
+#endif
 
 namespace nka {
 
@@ -45,6 +61,7 @@ enum {
   IC_PLAN_FIRST = 8,   //   slot holding the pending pair
   IC_PLAN_NOLDER = 9,  //   number of list entries to dot against
   IC_NRELAX = 10,      // count of s == 0 events (diagnostic)
+  IC_NORMED = 11,      // this update normalises the pending pair (pending && s != 0)
   IC_HEADER = 16
 };
 // double control block
@@ -74,7 +91,8 @@ struct Ctl {
     return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count();
   }
 };
-// red[] layout: [0] sum d^2, [1] <f,w1'>, [2+p] <w1',w_older(p)>, [2+mvec+p] <f,w_older(p)>
+// red[] layout (raw sums of PA, d = w1 - f NOT yet divided by s):
+//   [0] sum d^2, [1] <f,d>, [2+p] <d,w_older(p)>, [2+mvec+p] <f,w_older(p)>
 
 struct Vecs {
   double *v, *w;       // slot k (1-based) at base + (k-1)*stride
@@ -109,63 +127,56 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NACC], do
   }
 }
 
+// ---- 8-B / 16-B per lane streaming accesses ---------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = double; };
-template <> struct VecT<2> { using type = double2; };
+template <> struct VecT<2> { using type = d2; };
 
 template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type ld(const double *p);
-template <> __device__ __forceinline__ double ld<1>(const double *p) { return *p; }
-template <> __device__ __forceinline__ double2 ld<2>(const double *p) {
-  return *reinterpret_cast<const double2 *>(p);
+template <> __device__ __forceinline__ double ld<1>(const double *p) {
+#if NKA_NT_LOADS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
 }
-__device__ __forceinline__ void st(double *p, double x) { *p = x; }
-__device__ __forceinline__ void st(double *p, double2 x) { *reinterpret_cast<double2 *>(p) = x; }
+template <> __device__ __forceinline__ d2 ld<2>(const double *p) {
+#if NKA_NT_LOADS
+  return __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
+#else
+  return *reinterpret_cast<const d2 *>(p);
+#endif
+}
+__device__ __forceinline__ void st(double *p, double x) {
+#if NKA_STORE_POLICY == 1
+  __builtin_nontemporal_store(x, p);
+#else
+  *p = x;
+#endif
+}
+__device__ __forceinline__ void st(double *p, d2 x) {
+#if NKA_STORE_POLICY == 1
+  __builtin_nontemporal_store(x, reinterpret_cast<d2 *>(p));
+#elif NKA_STORE_POLICY == 2
+  // write-through streaming store; a store needs no later wait in this wave
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(x) : "memory");
+#else
+  *reinterpret_cast<d2 *>(p) = x;
+#endif
+}
 
 __device__ __forceinline__ double ex(double x, int) { return x; }
-__device__ __forceinline__ double ex(double2 x, int i) { return i ? x.y : x.x; }
+__device__ __forceinline__ double ex(d2 x, int i) { return x[i]; }
 __device__ __forceinline__ void setc(double &x, int, double val) { x = val; }
-__device__ __forceinline__ void setc(double2 &x, int i, double val) {
-  if (i) x.y = val; else x.x = val;
-}
+__device__ __forceinline__ void setc(d2 &x, int i, double val) { x[i] = val; }
 
-// ---- P1: s^2 = sum (w1 - f)^2 ---------------------------------------------------
-// F08:266-267.  The difference is NOT stored: P2 recomputes it in registers, so
-// this pass reads 2n words and writes nothing.
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_diffnorm(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                     double *__restrict__ partials) {
-  const int G = gridDim.x;
-  double acc[1] = {0.0};
-  if (ctl.ic[IC_PLAN_PENDING]) {
-    const double *w1 = vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride;
-    const int64_t ntile = vs.n / (kBlock * VEC);  // full tiles
-    for (int64_t t = blockIdx.x; t < ntile; t += G) {
-      const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-      auto a = ld<VEC>(w1 + e);
-      auto b = ld<VEC>(f + e);
-#pragma unroll
-      for (int q = 0; q < VEC; q++) {
-        double d = ex(a, q) - ex(b, q);
-        acc[0] = fma(d, d, acc[0]);
-      }
-    }
-    if (blockIdx.x == G - 1) {  // ragged tail, scalar
-      const int64_t e = ntile * (kBlock * VEC) + threadIdx.x;
-      for (int64_t i = e; i < vs.n; i += kBlock) {
-        double d = w1[i] - f[i];
-        acc[0] = fma(d, d, acc[0]);
-      }
-    }
-  }
-  block_reduce_store<1>(acc, partials, G);
-}
-
-// ---- fixed-order final sum of per-block partials ---------------------------------
+// ---- fixed-order final sum of per-block partials (vector hooks: dot, norm2) -------
 // out[c] = sum_b partials[c*G + b] for c < ncols ; 0 for ncols <= c < ncols_out.
 // One block; wave w takes columns w, w+4, ...; each lane sums its strided
 // share sequentially, then a butterfly: the order never depends on timing.
-static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_finalize(const double *__restrict__ partials, int G, int ncols,
-                                                     int ncols_out, double *__restrict__ out) {
+static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_finalize(
+    const double *__restrict__ partials, int G, int ncols, int ncols_out, double *__restrict__ out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int c = wv; c < ncols_out; c += kWavesPerBlock) {
     double r = 0.0;
@@ -177,151 +188,117 @@ static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_final
   }
 }
 
-// ---- P2: normalise the pending pair and compute both Gram rows -----------------
-// RCP = false : x / s           (F08:282-283, C)
-// RCP = true  : (1/s) * x       (F08V:255-256 scale(1/s))
-// MAXL older vectors per pass; entries beyond the actual count re-read f (cache
+// ---- PA: every inner product of the update in one pure-read pass --------------------
+// MAXL stored vectors per pass; entries beyond the actual count re-read f (cache
 // hit) into accumulators that are discarded, which keeps every load of a tile
-// unconditional so that all MAXL+3 of them are in flight together.
-template <int MAXL, int VEC, bool RCP>
-__global__ __launch_bounds__(kBlock) void k_gram(Ctl ctl, Vecs vs, const double *__restrict__ f,
+// unconditional so that all MAXL+2 of them are in flight together.
+// acc: [0] sum d^2, [1] <f,d>, [2+j] <d,w_j>, [2+MAXL+j] <f,w_j>.
+template <int MAXL, int VEC>
+__global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double *__restrict__ f,
                                                  double *__restrict__ partials, int pass) {
   using V = typename VecT<VEC>::type;
+  constexpr int NACC = 2 * MAXL + 2;
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  const double *red = ctl.red();
-  const double s = pending ? sqrt(red[0]) : 0.0;
-  const bool norm = pending && (s != 0.0);   // s == 0 -> relax: nothing to normalise (F08:275)
-  const bool first_pass = (pass == 0);
   const int base = pass * MAXL;
   const int32_t *slots = ctl.plan_slots();
-
-  double *w1 = vs.w, *v1 = vs.v;
-  if (pending) {
-    const size_t off = (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride;
-    w1 += off;
-    v1 += off;
-  }
+  // no pending pair: d = f - f = 0 and its sums are discarded by k_finalize_dots
+  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
   const double *wk[MAXL];
 #pragma unroll
   for (int j = 0; j < MAXL; j++) {
     const int p = base + j;
     wk[j] = (p < nolder) ? vs.w + (size_t)(slots[p] - 1) * vs.stride : f;
   }
-  const double rs = 1.0 / s;
-
-  double acc[2 * MAXL + 1];
+  double acc[NACC];
 #pragma unroll
-  for (int a = 0; a < 2 * MAXL + 1; a++) acc[a] = 0.0;
+  for (int a = 0; a < NACC; a++) acc[a] = 0.0;
 
   const int64_t ntile = vs.n / (kBlock * VEC);
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    V fv = ld<VEC>(f + e);
-    V wn = fv;  // placeholder when !norm (its dots are discarded)
+    const V fv = ld<VEC>(f + e);
+    const V w1v = ld<VEC>(w1 + e);
     V wkv[MAXL];
 #pragma unroll
     for (int j = 0; j < MAXL; j++) wkv[j] = ld<VEC>(wk[j] + e);
-    if (norm) {
-      V a = ld<VEC>(w1 + e);
-      if (first_pass) {
-        V b = ld<VEC>(v1 + e);
-        V vn;
 #pragma unroll
-        for (int q = 0; q < VEC; q++) {
-          const double d = ex(a, q) - ex(fv, q);
-          setc(wn, q, RCP ? rs * d : d / s);
-          setc(vn, q, RCP ? rs * ex(b, q) : ex(b, q) / s);
-        }
-        st(w1 + e, wn);
-        st(v1 + e, vn);
-      } else {
-        wn = a;  // already normalised by pass 0
-      }
-    }
+    for (int q = 0; q < VEC; q++) {
+      const double fq = ex(fv, q);
+      const double d = ex(w1v, q) - fq;            // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+      acc[0] = fma(d, d, acc[0]);
+      acc[1] = fma(fq, d, acc[1]);
 #pragma unroll
-    for (int q = 0; q < VEC; q++) acc[0] = fma(ex(fv, q), ex(wn, q), acc[0]);
-#pragma unroll
-    for (int j = 0; j < MAXL; j++) {
-#pragma unroll
-      for (int q = 0; q < VEC; q++) {
-        acc[1 + j] = fma(ex(wn, q), ex(wkv[j], q), acc[1 + j]);
-        acc[1 + MAXL + j] = fma(ex(fv, q), ex(wkv[j], q), acc[1 + MAXL + j]);
+      for (int j = 0; j < MAXL; j++) {
+        acc[2 + j] = fma(d, ex(wkv[j], q), acc[2 + j]);
+        acc[2 + MAXL + j] = fma(fq, ex(wkv[j], q), acc[2 + MAXL + j]);
       }
     }
   }
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
-    const int64_t e0 = ntile * (kBlock * VEC) + threadIdx.x;
-    for (int64_t i = e0; i < vs.n; i += kBlock) {
-      const double fv = f[i];
-      double wn = fv;
-      if (norm) {
-        if (first_pass) {
-          const double d = w1[i] - fv;
-          wn = RCP ? rs * d : d / s;
-          const double vn = RCP ? rs * v1[i] : v1[i] / s;
-          w1[i] = wn;
-          v1[i] = vn;
-        } else {
-          wn = w1[i];
-        }
-      }
-      acc[0] = fma(fv, wn, acc[0]);
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+      const double fq = f[i];
+      const double d = w1[i] - fq;
+      acc[0] = fma(d, d, acc[0]);
+      acc[1] = fma(fq, d, acc[1]);
 #pragma unroll
       for (int j = 0; j < MAXL; j++) {
         const double x = wk[j][i];
-        acc[1 + j] = fma(wn, x, acc[1 + j]);
-        acc[1 + MAXL + j] = fma(fv, x, acc[1 + MAXL + j]);
+        acc[2 + j] = fma(d, x, acc[2 + j]);
+        acc[2 + MAXL + j] = fma(fq, x, acc[2 + MAXL + j]);
       }
     }
   }
-  block_reduce_store<2 * MAXL + 1>(acc, partials, G);
+  block_reduce_store<NACC>(acc, partials, G);
 }
 
-// Final sums of one P2 pass scattered into red[] (see layout above).
+// Final sums of one PA pass scattered into red[] (layout above).  One wavefront
+// per column (grid = 2*MAXL+2 blocks of 64): each lane sums its strided share in
+// order, then a butterfly -- the same bits on every run.
+constexpr int kFinThreads = 64;
 template <int MAXL>
-__global__ __launch_bounds__(kBlock) void k_finalize_gram(Ctl ctl, const double *__restrict__ partials, int G,
-                                                          int pass) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const double *__restrict__ partials, int G,
+                                                               int pass) {
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x;
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int pending = ctl.ic[IC_PLAN_PENDING];
-  double *red = ctl.red();
-  const bool norm = pending && (red[0] != 0.0);  // sqrt(x) == 0 <=> x == 0
   const int base = pass * MAXL;
-  for (int c = wv; c < 2 * MAXL + 1; c += kWavesPerBlock) {
-    // column -> destination
-    int dst = -1;
-    bool live = false;
-    if (c == 0) {
-      if (pass == 0) { dst = 1; live = norm; }
-    } else if (c <= MAXL) {
-      const int p = base + (c - 1);
-      if (p < ctl.mvec) { dst = 2 + p; live = norm && p < nolder; }
-    } else {
-      const int p = base + (c - 1 - MAXL);
-      if (p < ctl.mvec) { dst = 2 + ctl.mvec + p; live = p < nolder; }
-    }
-    if (dst < 0) continue;
-    double r = 0.0;
-    if (live) {
-      for (int b = lane; b < G; b += 64) r += partials[(size_t)c * G + b];
-      r = wave_sum(r);
-    }
-    if (lane == 0) red[dst] = r;
+  int dst = -1;
+  bool live = false;
+  if (c < 2) {
+    if (pass == 0) { dst = c; live = pending != 0; }
+  } else if (c < 2 + MAXL) {
+    const int p = base + (c - 2);
+    if (p < ctl.mvec) { dst = 2 + p; live = pending && p < nolder; }
+  } else {
+    const int p = base + (c - 2 - MAXL);
+    if (p < ctl.mvec) { dst = 2 + ctl.mvec + p; live = p < nolder; }
   }
+  if (dst < 0) return;
+  double r = 0.0;
+  if (live) {
+    for (int b = lane; b < G; b += kFinThreads) r += partials[(size_t)c * G + b];
+    r = wave_sum(r);
+  }
+  if (lane == 0) ctl.red()[dst] = r;
 }
 
-// ---- P3: combine + both ring stores --------------------------------------------
-// COMB 0: (f - c*w) + c*v     F08:397
-// COMB 1: ((-c)*w + c*v) + f  F08V:374 via update3_ (grid_vector_type.F90:151)
-// COMB 2: f + c*(v - w)       C .c:423
+// ---- PB: normalise the pending pair, combine, and all five stores -----------------
+// COMB 0: x/s          ; (f - c*w) + c*v       F08:282-283, 397
+// COMB 1: (1/s)*x      ; ((-c)*w + c*v) + f    F08V:255-256 scale(1/s), :374 update3_
+//                                              (grid_vector_type.F90:117,151)
+// COMB 2: x/s          ; f + c*(v - w)         C .c:317-320, 423
 // The k loop runs in list order with the reference's association, so given the
 // same coefficients the result is bit-identical to the reference's k passes.
 // MAXK (slot, coefficient) pairs per pass, fully unrolled: offsets and
 // coefficients sit in SGPRs and all 2*MAXK+1 loads of a tile are issued
 // together.  Pairs beyond the actual count re-read f and are not applied.
-// Pass 0 stores w_new = f_in; the last pass stores v_new = f_out.
+// Pass 0 stores w_new = f_in and, if this update normalises (IC_NORMED), treats
+// pair 0 -- the pending slot, still holding the raw previous f and update -- as
+// w1' = (w1-f)/s, v1' = v1/s formed in registers and stored back.  The last pass
+// stores v_new = f_out.
 template <int COMB>
 __device__ __forceinline__ double comb1(double x, double c, double w, double v) {
   if (COMB == 0) return (x - c * w) + c * v;
@@ -330,9 +307,9 @@ __device__ __forceinline__ double comb1(double x, double c, double w, double v) 
 }
 
 template <int MAXK, int VEC, int COMB>
-__global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass,
-                                                    int last_pass) {
+__global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass, int last_pass) {
   using V = typename VecT<VEC>::type;
+  constexpr bool RCP = (COMB == 1);
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
   const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
@@ -342,8 +319,11 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   const int base = pass * MAXK;
   const bool store_w = (pass == 0), store_v = (last_pass != 0);
   const bool store_f = store_v ? (ncomb > 0) : true;  // nothing to combine: f stays as it is
+  const bool norm0 = (pass == 0) && ctl.ic[IC_NORMED];
+  const double s = ctl.dc[DC_S];
+  const double rs = 1.0 / s;
 
-  const double *wk[MAXK], *vk[MAXK];
+  double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
 #pragma unroll
   for (int j = 0; j < MAXK; j++) {
@@ -365,6 +345,16 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
       wv[j] = ld<VEC>(wk[j] + e);
       vv[j] = ld<VEC>(vk[j] + e);
     }
+    if (norm0) {
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        const double d = ex(wv[0], q) - ex(fin, q);
+        setc(wv[0], q, RCP ? rs * d : d / s);
+        setc(vv[0], q, RCP ? rs * ex(vv[0], q) : ex(vv[0], q) / s);
+      }
+      st(wk[0] + e, wv[0]);
+      st(vk[0] + e, vv[0]);
+    }
     V x = fin;
 #pragma unroll
     for (int j = 0; j < MAXK; j++) {
@@ -378,13 +368,23 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
     if (store_f) st(f + e, x);
   }
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
-    const int64_t e0 = ntile * (kBlock * VEC) + threadIdx.x;
-    for (int64_t i = e0; i < vs.n; i += kBlock) {
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fin = f[i];
       double x = fin;
 #pragma unroll
-      for (int j = 0; j < MAXK; j++)
-        if (base + j < ncomb) x = comb1<COMB>(x, ck[j], wk[j][i], vk[j][i]);
+      for (int j = 0; j < MAXK; j++) {
+        if (base + j < ncomb) {
+          double w = wk[j][i], v = vk[j][i];
+          if (j == 0 && norm0) {
+            const double d = w - fin;
+            w = RCP ? rs * d : d / s;
+            v = RCP ? rs * v : v / s;
+            wk[0][i] = w;
+            vk[0][i] = v;
+          }
+          x = comb1<COMB>(x, ck[j], w, v);
+        }
+      }
       if (store_w) wnew[i] = fin;
       if (store_v) vnew[i] = x;
       if (store_f) f[i] = x;
@@ -565,8 +565,9 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
   lst_store(L, ctl);
 }
 
-// The scalar part of accel_update between P2 and P3.
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl) {
+// The scalar part of accel_update between PA and PB.  `rcp` selects the
+// F08-vector flavour, whose normalisation is a multiplication by 1/s.
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int rcp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem);
@@ -576,24 +577,27 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     const int nolder = ctl.ic[IC_PLAN_NOLDER];
     const int entry_first = L.first;
     bool normed = false;
+    double s = 0.0;
     if (L.pending) {
-      const double s = sqrt(red[0]);
+      s = sqrt(red[0]);                       // F08:267
       ctl.dc[DC_S] = s;
-      if (s == 0.0) {
+      if (s == 0.0) {                         // F08:275
         lst_relax(L);
         ctl.ic[IC_NRELAX] += 1;
       }
     }
+    const double rs = 1.0 / s;
     if (L.pending) {
       normed = true;
-      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = red[2 + p];
+      // Gram row of w1' = d/s from the raw sums <d,w_k> of PA (F08:286-290)
+      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = rcp ? rs * red[2 + p] : red[2 + p] / s;
       lst_factor(L);
     }
     const int slot = L.free_;
     L.free_ = L.next[slot];
     int ncomb = 0;
     if (L.subspace) {
-      if (normed) L.c[entry_first] = red[1];
+      if (normed) L.c[entry_first] = rcp ? rs * red[1] : red[1] / s;   // <f,w1'> = <f,d>/s
       for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
       lst_solve(L);
       for (int k = L.first; k != 0; k = L.next[k]) {
@@ -604,6 +608,7 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     }
     ctl.ic[IC_NCOMB] = ncomb;
     ctl.ic[IC_NEW] = slot;
+    ctl.ic[IC_NORMED] = normed ? 1 : 0;
     lst_prepend(L, slot);
   }
   lst_store(L, ctl);

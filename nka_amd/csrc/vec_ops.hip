@@ -27,7 +27,6 @@ int set_error(int code, const std::string &msg);
 struct nka_hip_vec_ws {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool own_stream = false;
   int num_cu = 256;
   double *partials = nullptr;  // kMaxGrid
   double *result = nullptr;    // 1 double, device
@@ -143,12 +142,7 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   hipDeviceProp_t prop;
   HIP_TRYV(hipGetDeviceProperties(&prop, device));
   ws->num_cu = prop.multiProcessorCount;
-  if (stream) {
-    ws->stream = (hipStream_t)stream;
-  } else {
-    HIP_TRYV(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
-    ws->own_stream = true;
-  }
+  ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
   HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid));
   HIP_TRYV(hipMalloc((void **)&ws->result, sizeof(double)));
   HIP_TRYV(hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault));
@@ -159,11 +153,10 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   if (!ws) return 0;
   hipSetDevice(ws->device);
-  if (ws->stream) hipStreamSynchronize(ws->stream);
+  hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
   hipFree(ws->result);
   hipHostFree(ws->host_result);
-  if (ws->own_stream) hipStreamDestroy(ws->stream);
   delete ws;
   return 0;
 }

@@ -56,7 +56,7 @@ class nka:  # noqa: N801  (the reference's type name)
 
     def __init__(self):
         self._h = None
-        self._L = None
+        self._L = _lib.load()      # raises if the HIP library is missing: no CPU path
         self._cb = None
 
     # -- call a%init(vlen, mvec)                      F08:185-200
@@ -68,7 +68,6 @@ class nka:  # noqa: N801  (the reference's type name)
         import torch
 
         self.delete()
-        self._L = _lib.load()
         if not torch.cuda.is_available():
             raise NKAError("no HIP device visible: nka_amd has no CPU path")
         if device is None:
@@ -198,7 +197,7 @@ class nka:  # noqa: N801  (the reference's type name)
                      h.T.copy(), c)
 
     def reductions(self) -> np.ndarray:
-        """[|w1-f|^2, <f,w1'>, <w1',w_p>..., <f,w_p>...] of the most recent update."""
+        """[<d,d>, <f,d>, <d,w_p>..., <f,w_p>...] (d = w1 - f) of the most recent update."""
         out = np.zeros(2 + 2 * self._mvec)
         _check(self._L.nka_hip_get_reductions(self._handle(), out.ctypes.data_as(_lib._dp)), "get_reductions")
         return out
@@ -218,13 +217,13 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_set_timing(self._handle(), int(capacity)), "set_timing")
 
     def timing_ms(self, back: int = 0):
-        """(P1, P2, P3, whole update) in ms for the update `back` calls ago."""
+        """(PA dots, solve, PB combine, whole update) in ms for the update `back` calls ago."""
         ms = (C.c_float * 4)()
         _check(self._L.nka_hip_get_timing(self._handle(), int(back), ms), "get_timing")
         return tuple(ms)
 
-    def set_grid(self, p1=0, p2=0, p3=0):
-        _check(self._L.nka_hip_set_grid(self._handle(), p1, p2, p3), "set_grid")
+    def set_grid(self, pa=0, pb=0):
+        _check(self._L.nka_hip_set_grid(self._handle(), pa, pb), "set_grid")
 
     def device_info(self):
         name = C.create_string_buffer(64)

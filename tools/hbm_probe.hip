@@ -1,0 +1,115 @@
+// tools/hbm_probe.hip -- what HBM rate can a streaming kernel reach on this chip?
+// Measurement aid (not part of the product).  Reads S streams of `n` doubles
+// (separate slots of one big allocation, like the NKA slot storage) with
+// 16-B/lane loads and sums them; optional W streams written.  Variants:
+// plain vs non-temporal loads/stores, tiles per iteration (loads in flight),
+// grid size.  Prints GB/s per variant.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <bool NT> __device__ __forceinline__ double2 ld2(const double *p) {
+  if (NT) {
+    double2 r;
+    r.x = __builtin_nontemporal_load(p);
+    r.y = __builtin_nontemporal_load(p + 1);
+    return r;
+  }
+  return *reinterpret_cast<const double2 *>(p);
+}
+typedef double nd2 __attribute__((ext_vector_type(2)));
+// store policy: 0 plain, 1 nt (builtin), 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
+template <int POL> __device__ __forceinline__ void st2(double *p, double2 v) {
+  if (POL == 1) {
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+  } else if (POL == 2) {
+    nd2 q = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  } else if (POL == 3) {
+    nd2 q = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
+  } else if (POL == 4) {
+    nd2 q = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(q) : "memory");
+  } else {
+    *reinterpret_cast<double2 *>(p) = v;
+  }
+}
+
+// S read streams, W write streams, T tiles (of 256 x 16 B) per block iteration.
+template <int S, int W, int T, bool NTL, int NTS, int MAP>
+__global__ __launch_bounds__(256) void k_stream(const double *base, double *wbase, size_t stride, size_t n, double *out) {
+  const size_t ntile = n / 512 / T;
+  double acc = 0.0;
+  const size_t per = (ntile + gridDim.x - 1) / gridDim.x;
+  const size_t tb = MAP ? blockIdx.x * per : blockIdx.x, te = MAP ? (tb + per < ntile ? tb + per : ntile) : ntile;
+  const size_t step = MAP ? 1 : gridDim.x;
+  for (size_t t = tb; t < te; t += step) {
+    double2 v[S > 0 ? S : 1][T];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+      for (int q = 0; q < T; q++) v[s][q] = ld2<NTL>(base + s * stride + (t * T + q) * 512 + threadIdx.x * 2);
+    double2 sum = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+      for (int q = 0; q < T; q++) { sum.x += v[s][q].x; sum.y += v[s][q].y; }
+    acc += sum.x + sum.y;
+#pragma unroll
+    for (int w = 0; w < W; w++)
+#pragma unroll
+      for (int q = 0; q < T; q++) st2<NTS>(wbase + w * stride + (t * T + q) * 512 + threadIdx.x * 2, sum);
+  }
+  if (S > 0 && acc == 12345.678) out[0] = acc;  // keep the loads alive
+}
+
+template <int S, int W, int T, bool NTL, int NTS, int MAP>
+void run(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 3;
+  hipLaunchKernelGGL((k_stream<S, W, T, NTL, NTS, MAP>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream<S, W, T, NTL, NTS, MAP>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+  const size_t n = argc > 1 ? (size_t)atof(argv[1]) : 100000000;
+  const size_t stride = ((n + 31) / 32) * 32 + (argc > 2 ? atoi(argv[2]) / 8 : 0);
+  const int NS = 42;
+  double *rd, *wr, *out;
+  CK(hipMalloc(&rd, stride * 8 * NS));
+  CK(hipMalloc(&wr, stride * 8 * 3));
+  CK(hipMalloc(&out, 64));
+  CK(hipMemset(rd, 0, stride * 8 * NS));
+  CK(hipMemset(wr, 0, stride * 8 * 3));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cu = prop.multiProcessorCount;
+  printf("device %s, %d CUs, n=%zu, slot stride %zu B\n", prop.gcnArchName, cu, n, stride * 8);
+#define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
+  for (int g : {cu * 2, cu * 4, cu * 8}) {
+    R(8, 0, 1, true, 0, 0, g);  R(8, 1, 1, true, 0, 0, g);  R(8, 1, 1, true, 4, 0, g); R(8, 1, 1, false, 0, 0, g);
+    R(8, 2, 1, true, 4, 0, g);
+    R(4, 1, 1, true, 4, 0, g);  R(4, 1, 2, true, 4, 0, g);
+    R(16, 0, 1, true, 0, 0, g); R(16, 1, 1, true, 0, 0, g); R(16, 1, 1, true, 4, 0, g);
+    R(16, 3, 1, true, 4, 0, g);
+    R(12, 0, 1, true, 0, 0, g); R(12, 3, 1, true, 4, 0, g); R(12, 3, 1, true, 0, 0, g);
+  }
+  return 0;
+}
