@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
     V wkv[MAXL];
 #pragma unroll
     for (int j = 0; j < MAXL; j++) wkv[j] = ld<VEC>(wk[j] + e);
+    // keep all MAXL+2 loads of the tile in flight: no FMA may be scheduled
+    // between them (hipcc otherwise serialises load/wait/use to save registers)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < VEC; q++) {
       const double fq = ex(fv, q);
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
       wv[j] = ld<VEC>(wk[j] + e);
       vv[j] = ld<VEC>(vk[j] + e);
     }
+    __builtin_amdgcn_sched_barrier(0);  // all 2*MAXK+1 loads in flight before any arithmetic
     if (norm0) {
 #pragma unroll
       for (int q = 0; q < VEC; q++) {
