@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")
+    ap.add_argument("--flavor", choices=["c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "c"),
+                    help="which reference rounding is mirrored; 'c' (src-C) uses compact storage")
     ap.add_argument("--allreduce", choices=["rccl", "torch"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
     return ap.parse_args()
 
@@ -116,7 +118,8 @@ def main():
     K = args.steps
     W = args.warmup if args.warmup is not None else m + 4
 
-    acc = nka_amd.nka().init(n_local, m)
+    flavor = {"f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR, "c": nka_amd.FLAVOR_C}[args.flavor]
+    acc = nka_amd.nka().init(n_local, m, flavor=flavor)
     if world > 1:
         if args.allreduce == "rccl":
             nd.attach_rccl(acc, rank, world)
@@ -197,7 +200,8 @@ def main():
         L = k = m
         # words (8 B) per element each launch moves: PA reads w1, f and L stored w's;
         # PB reads f + k (w,v) pairs and writes w1', v1', w_new, v_new, f
-        words = {"PA_k_dots": 2 + L, "PB_k_combine": (1 + 2 * k) + 5}
+        pb_reads = (2 + k) if args.flavor == "c" else (1 + 2 * k)   # compact storage reads one vector per pair
+        words = {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + 5}
         b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # SURVEY.md 8(d), per update, per GPU
         upd_s = mean[3] * 1e-3
         kernels = {}
@@ -214,6 +218,9 @@ def main():
             "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction "
                                    f"vectors, n={n_global} (global), mvec={m}, fp64, subspace full (num_vec={nv})",
                        "n_global": n_global, "n_local": n_local, "mvec": m,
+                       "flavor": {"c": "src-C rounding f += c*(v-w), compact storage",
+                                  "f08": "src-F08 rounding (f - c*w) + c*v",
+                                  "f08vec": "src-F08-vector rounding"}[args.flavor],
                        "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={args.allreduce if world > 1 else 'none'}",
                        "steady_state": bool(steady and nv_end == m),
                        "inputs_resident": not refill_in_timed_region},
@@ -222,7 +229,8 @@ def main():
                          "what": "whole accel_update on one GPU: algorithmic bytes 8*n_local*(11+L+2k) / mean "
                                  "device time first-kernel-start..last-kernel-end (HIP events, kernel stream)",
                          "algorithmic_bytes_per_update": b_alg, "mean_update_ms": mean[3],
-                         "bytes_moved_per_update": 8.0 * n_local * (8 + L + 2 * k),
+                         "bytes_moved_per_update": 8.0 * n_local * sum(words.values()),
+                         "frac_of_bytes_moved": 8.0 * n_local * sum(words.values()) / upd_s / 1e9 / HBM_PEAK_GBPS,
                          "dominant_kernel": "PB_k_combine", "kernels": kernels,
                          "copy_ceiling_GBps": copy_gbps},
             "aggregate_algorithmic_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,

@@ -46,7 +46,13 @@ enum {
  * mirrored:
  *   F08        w1-f ; x/s          ; (f - c*w) + c*v        F08:266,282-283,397
  *   F08_VECTOR (-1)*f+w ; (1/s)*x  ; ((-c)*w + c*v) + f     F08V:237,255-256,374
- *   C          w1-f ; x/s          ; f + c*(v - w)          C .c:299-300,317-320,423 */
+ *   C          w1-f ; x/s          ; f + c*(v - w)          C .c:299-300,317-320,423
+ * The C flavour uses COMPACT storage: its combine only ever needs the difference
+ * v_k - w_k of a normalised pair, so that difference is formed once, when the
+ * pair is normalised, and kept in the v array in place of v_k.  f + c*(v-w) is
+ * then evaluated with bit-identical operands while the combine pass reads one
+ * vector per pair instead of two.  (nka_hip_get_v on a normalised slot returns
+ * v_k - w_k in this flavour; the pending slot holds the raw update.) */
 enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2 };
 
 /* ---- lifecycle --------------------------------------------------------- */

@@ -18,9 +18,11 @@
 //   PB  k_combine : w1' = (w1-f)/s and v1' = v1/s (F08:282-283) formed in
 //                   registers and stored, f <- f - sum c_k w_k + sum c_k v_k in
 //                   list order (F08:395-399), and the two ring stores w_new = f_in
-//                   (F08:361), v_new = f_out (F08:404).  Reads (1+2k)n, writes 5n.
-// That moves 8n(8+L+2k) bytes per update against the 8n(11+L+2k) of the
-// three-pass schedule of SURVEY.md 8(d), with ONE synchronisation point.
+//                   (F08:361), v_new = f_out (F08:404).  Reads (1+2k)n, writes 5n;
+//                   in the C flavour's compact storage (see k_combine) (2+k)n.
+// That moves 8n(8+L+2k) bytes per update -- 8n(9+L+k) compact -- against the
+// 8n(11+L+2k) of the three-pass schedule of SURVEY.md 8(d), with ONE
+// synchronisation point.
 //
 // Everything is fp64 and bandwidth bound (0.29 flop/byte): no MFMA.  Vectors are
 // slot-major, each slot contiguous and 256-B aligned, read with 16-B/lane
@@ -295,11 +297,19 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
 // COMB 2: x/s          ; f + c*(v - w)         C .c:317-320, 423
 // The k loop runs in list order with the reference's association, so given the
 // same coefficients the result is bit-identical to the reference's k passes.
+//
+// COMPACT storage (COMB 2 only).  The C reference combines with the DIFFERENCE
+// v_k - w_k (f += c*(v - w), .c:423).  For a normalised pair that difference
+// never changes, so this flavour stores u_k = fl(v_k' - w_k') in the v array
+// when the pair is normalised and reads ONE vector per pair ever after:
+// f + c*u_k is bit-identical to the C statement, and PB reads k+2 vectors
+// instead of 2k+1.  (The pending slot still holds the raw w = f_in, v = f_out.)
+//
 // MAXK (slot, coefficient) pairs per pass, fully unrolled: offsets and
-// coefficients sit in SGPRs and all 2*MAXK+1 loads of a tile are issued
-// together.  Pairs beyond the actual count re-read f and are not applied.
-// Pass 0 stores w_new = f_in and, if this update normalises (IC_NORMED), treats
-// pair 0 -- the pending slot, still holding the raw previous f and update -- as
+// coefficients sit in SGPRs and all loads of a tile are issued together.  Pairs
+// beyond the actual count re-read f and are not applied.  Pass 0 stores
+// w_new = f_in and, if this update normalises (IC_NORMED), treats pair 0 -- the
+// pending slot, still holding the raw previous f and update -- as
 // w1' = (w1-f)/s, v1' = v1/s formed in registers and stored back.  The last pass
 // stores v_new = f_out.
 template <int COMB>
@@ -313,6 +323,8 @@ template <int MAXK, int VEC, int COMB>
 __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass, int last_pass) {
   using V = typename VecT<VEC>::type;
   constexpr bool RCP = (COMB == 1);
+  constexpr bool COMPACT = (COMB == 2);
+  constexpr int NW = COMPACT ? 1 : MAXK;   // w vectors loaded per tile
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
   const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
@@ -342,19 +354,21 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     const V fin = ld<VEC>(f + e);
-    V wv[MAXK], vv[MAXK];
+    V wv[NW], vv[MAXK];
+    if (!COMPACT || norm0) wv[0] = ld<VEC>(wk[0] + e); else wv[0] = fin;
 #pragma unroll
-    for (int j = 0; j < MAXK; j++) {
-      wv[j] = ld<VEC>(wk[j] + e);
-      vv[j] = ld<VEC>(vk[j] + e);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // all 2*MAXK+1 loads in flight before any arithmetic
+    for (int j = 1; j < NW; j++) wv[j] = ld<VEC>(wk[j] + e);
+#pragma unroll
+    for (int j = 0; j < MAXK; j++) vv[j] = ld<VEC>(vk[j] + e);
+    __builtin_amdgcn_sched_barrier(0);  // every load of the tile in flight before any arithmetic
     if (norm0) {
 #pragma unroll
       for (int q = 0; q < VEC; q++) {
         const double d = ex(wv[0], q) - ex(fin, q);
-        setc(wv[0], q, RCP ? rs * d : d / s);
-        setc(vv[0], q, RCP ? rs * ex(vv[0], q) : ex(vv[0], q) / s);
+        const double wn = RCP ? rs * d : d / s;
+        const double vn = RCP ? rs * ex(vv[0], q) : ex(vv[0], q) / s;
+        setc(wv[0], q, wn);
+        setc(vv[0], q, COMPACT ? vn - wn : vn);
       }
       st(wk[0] + e, wv[0]);
       st(vk[0] + e, vv[0]);
@@ -364,7 +378,10 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
     for (int j = 0; j < MAXK; j++) {
       if (base + j < ncomb) {
 #pragma unroll
-        for (int q = 0; q < VEC; q++) setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wv[j], q), ex(vv[j], q)));
+        for (int q = 0; q < VEC; q++) {
+          if (COMPACT) setc(x, q, ex(x, q) + ck[j] * ex(vv[j], q));
+          else setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wv[j < NW ? j : 0], q), ex(vv[j], q)));
+        }
       }
     }
     if (store_w) st(wnew + e, fin);
@@ -378,15 +395,17 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
 #pragma unroll
       for (int j = 0; j < MAXK; j++) {
         if (base + j < ncomb) {
-          double w = wk[j][i], v = vk[j][i];
+          double v = vk[j][i];
+          double w = (!COMPACT || (j == 0 && norm0)) ? wk[j][i] : 0.0;
           if (j == 0 && norm0) {
             const double d = w - fin;
             w = RCP ? rs * d : d / s;
             v = RCP ? rs * v : v / s;
+            if (COMPACT) v = v - w;
             wk[0][i] = w;
             vk[0][i] = v;
           }
-          x = comb1<COMB>(x, ck[j], w, v);
+          x = COMPACT ? x + ck[j] * v : comb1<COMB>(x, ck[j], w, v);
         }
       }
       if (store_w) wnew[i] = fin;

@@ -174,6 +174,8 @@ def test_elementwise_statements_bit_exact_given_same_scalars(torch_cuda, flavor,
                 wn, vn = r * d, r * v1_raw
             else:
                 wn, vn = d / s, v1_raw / s
+            if flavor == 2:
+                vn = vn - wn          # compact storage: the v array keeps v' - w' (C .c:423 operand)
             assert np.array_equal(acc.w(first0), wn)
             assert np.array_equal(acc.v(first0), vn)
         x = f_in.copy()
@@ -184,7 +186,7 @@ def test_elementwise_statements_bit_exact_given_same_scalars(torch_cuda, flavor,
             elif flavor == 1:
                 x = ((-c) * wk + c * vk) + x
             else:
-                x = x + c * (vk - wk)
+                x = x + c * vk        # vk is the stored difference v' - w'
         assert np.array_equal(f_out, x)
         prev_in = f_in
 
