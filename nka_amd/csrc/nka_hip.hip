@@ -74,6 +74,7 @@ struct nka_hip_state {
   int num_cu = 256;
   int bpc[2] = {2, 2};        // blocks per CU of PA, PB (caps; the grid also respects occupancy)
   char devname[64] = {0};
+  bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   // distribution hook
   nka_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_ctx = nullptr;
@@ -193,6 +194,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   a->num_cu = prop.multiProcessorCount;
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
+  a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
@@ -320,7 +322,10 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = record(a, 1)) return rc;
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
+  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve)
+    hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(kSolveThreads), solve_wave_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (int rc = record(a, 2)) return rc;
 

@@ -637,4 +637,210 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
   lst_store(L, ctl);
 }
 
+// ---- the same scalar step with the O(m^3) arithmetic spread over the wavefront ----
+// k_solve above runs the reference loops verbatim on one lane (~130 us at m=20:
+// every step waits on an LDS-resident linked list).  Here the list is first
+// linearised, the Gram entries gathered into a dense position-indexed matrix,
+// and the Cholesky factorisation done RIGHT-LOOKING: when column i is reached
+// its pivot is final (decide keep / drop exactly as F08:326), the column is
+// scaled by one division per row (lanes = rows) and every trailing entry gets
+//      a(p,q) <- a(p,q) - a(p,i)*a(q,i)
+// Each entry thus receives the same subtractions in the same (ascending i)
+// order as the reference's inner loop F08:316-319, then the same division
+// F08:320 -- bit-identical results, ~m sequential steps instead of ~m^3/3.  The
+// two substitutions (F08:369-392) are done the same way.  List surgery (drops,
+// free-list pushes in list order, new slot, prepend) stays on lane 0.
+// Requires mvec+1 <= kSolveWaveMax; larger subspaces use k_solve.
+constexpr int kSolveWaveMax = 48;
+
+__host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
+  const int nl = mvec + 1;
+  size_t b = (lst_smem_bytes(mvec) + 15) / 16 * 16;
+  b += (size_t)(nl * (nl + 1) + 3 * nl) * sizeof(double);
+  b += (size_t)(2 * nl + 8) * sizeof(int32_t);
+  return b;
+}
+
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve_wave(Ctl ctl, int rcp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lst L;
+  lst_load(L, ctl, smem);
+  const int lane = threadIdx.x;
+  const int NL = ctl.m1(), LDA = NL + 1;
+  double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
+  double *dd = A + NL * LDA;   // running pivots 1 - sum l^2
+  double *Ld = dd + NL;        // accepted pivots sqrt(hkk)
+  double *bb = Ld + NL;        // right-hand side / solution by list position
+  int32_t *ord = reinterpret_cast<int32_t *>(bb + NL);  // list position -> slot
+  int32_t *alive = ord + NL;
+  int32_t *shi = alive + NL;   // [0] nl, [1] normed, [2] entry_first, [3] nk, [4] subspace
+  const double *red = ctl.red();
+  const int32_t *ps = ctl.plan_slots();
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const double vtol2 = L.vtol * L.vtol;
+
+  // ---- phase 0 (lane 0): norm, s == 0 -> relax, raw Gram row, linearise the list
+  if (lane == 0) {
+    const int entry_first = L.first;
+    int normed = 0;
+    double s = 0.0;
+    if (L.pending) {
+      s = sqrt(red[0]);                       // F08:267
+      ctl.dc[DC_S] = s;
+      if (s == 0.0) {                         // F08:275
+        lst_relax(L);
+        ctl.ic[IC_NRELAX] += 1;
+      }
+    }
+    if (L.pending) {
+      normed = 1;
+      const double rs = 1.0 / s;
+      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = rcp ? rs * red[2 + p] : red[2 + p] / s;
+      L.c[entry_first] = rcp ? rs * red[1] : red[1] / s;   // <f,w1'> = <f,d>/s
+    }
+    for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
+    int nl = 0;
+    for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;
+    shi[0] = nl;
+    shi[1] = normed;
+    shi[2] = entry_first;
+  }
+  __syncthreads();
+  const int nl = shi[0];
+  const int normed = shi[1];
+  int capdrop = -1;
+
+  if (normed) {
+    // ---- phase 1: right-looking Cholesky with drops (F08:295-347)
+    for (int idx = lane; idx < nl * nl; idx += kSolveThreads) {
+      const int p = idx / nl, q = idx - p * nl;
+      if (p > q) A[p * LDA + q] = L.H(ord[q], ord[p]);   // raw <w_q, w_p>, q newer than p
+    }
+    for (int p = lane; p < nl; p += kSolveThreads) {
+      dd[p] = 1.0;
+      alive[p] = 1;
+    }
+    __syncthreads();
+    int kept = 0;
+    for (int i = 0; i < nl; i++) {
+      bool keep;
+      double Lii = 1.0;
+      if (i == 0) {
+        keep = true;                           // F08:295 h(first,first) = 1
+      } else if (kept + 1 > L.mvec) {
+        keep = false;                          // F08:301-308 capacity: i is the last entry
+        capdrop = i;
+      } else {
+        const double hkk = dd[i];
+        keep = hkk > vtol2;                    // F08:326
+        if (keep) Lii = sqrt(hkk);
+      }
+      if (!keep) {
+        if (lane == 0) alive[i] = 0;
+        if (capdrop >= 0) break;
+        continue;
+      }
+      kept++;
+      if (lane == 0) Ld[i] = Lii;
+      for (int p = i + 1 + lane; p < nl; p += kSolveThreads) {
+        const double l = A[p * LDA + i] / Lii;   // F08:320
+        A[p * LDA + i] = l;
+        dd[p] = dd[p] - l * l;                   // F08:321
+      }
+      __syncthreads();
+      const int r = nl - i - 1;
+      for (int idx = lane; idx < r * r; idx += kSolveThreads) {
+        const int pp = idx / r, qq = idx - pp * r;
+        if (pp > qq) {
+          const int p = i + 1 + pp, q = i + 1 + qq;
+          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];   // F08:317
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    // ---- phase 2: scatter the factor back by slot; drops in list order on lane 0
+    for (int idx = lane; idx < nl * nl; idx += kSolveThreads) {
+      const int p = idx / nl, q = idx - p * nl;
+      if (alive[p] && alive[q]) {
+        if (p > q) L.H(ord[p], ord[q]) = A[p * LDA + q];
+        else if (p == q) L.H(ord[p], ord[p]) = Ld[p];
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int p = 1; p < nl; p++) {
+        if (alive[p]) continue;
+        const int k = ord[p];
+        if (p == capdrop) {                    // F08:303-307
+          L.next[L.last] = L.free_;
+          L.free_ = k;
+          L.last = L.prev[k];
+          L.next[L.last] = 0;
+        } else {                               // F08:331-340
+          const int pv = L.prev[k], nx = L.next[k];
+          L.next[pv] = nx;
+          if (nx == 0) L.last = pv; else L.prev[nx] = pv;
+          L.next[k] = L.free_;
+          L.free_ = k;
+        }
+      }
+      L.subspace = 1;
+      L.pending = 0;
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 3: new slot, then both substitutions on the current list
+  if (lane == 0) {
+    const int slot = L.free_;                  // F08:357-358
+    L.free_ = L.next[slot];
+    ctl.ic[IC_NEW] = slot;
+    int nk = 0;
+    if (L.subspace)
+      for (int k = L.first; k != 0; k = L.next[k]) {
+        ord[nk] = k;
+        bb[nk] = L.c[k];
+        nk++;
+      }
+    shi[3] = nk;
+    shi[4] = slot;
+  }
+  __syncthreads();
+  const int nk = shi[3];
+  if (nk > 0) {
+    for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
+      const int p = idx / nk, q = idx - p * nk;
+      if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
+    }
+    __syncthreads();
+    for (int i = 0; i < nk; i++) {             // forward, F08:369-379
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
+      __syncthreads();
+    }
+    for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
+      __syncthreads();
+    }
+    for (int p = lane; p < nk; p += kSolveThreads) {
+      ctl.comb_slots()[p] = ord[p];
+      ctl.comb_c()[p] = bb[p];
+      L.c[ord[p]] = bb[p];
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    ctl.ic[IC_NCOMB] = nk;
+    ctl.ic[IC_NORMED] = normed;
+    lst_prepend(L, shi[4]);                    // F08:406-417
+  }
+  lst_store(L, ctl);
+}
+
 }  // namespace nka

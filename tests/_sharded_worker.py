@@ -1,0 +1,70 @@
+"""Worker of tests/test_sharded_cpu.py: one rank of a world-size-N gloo run.
+
+Checks the sharded contract of the accel_update path on the CPU: every rank
+drives the ORACLE (checker code; no product arithmetic runs on the CPU) on its
+contiguous slice with a dot-product hook that all-reduces the local partial sum,
+exactly the reference's parallel contract (src-F08/nka_type.F90:58-64), and
+compares with the unsharded oracle on the full vector."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from nka_amd import dist as nd  # noqa: E402
+from nka_amd import synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, m, calls = 1001, 5, 14
+    lo, hi = nd.slice_bounds(n, world, rank)
+
+    # every rank must see the same bytes of the (fake) communicator id
+    uid = nd.broadcast_unique_id(lambda: bytes(range(128)), rank)
+    assert uid == bytes(range(128))
+
+    def global_dot(x, y):
+        t = torch.tensor([float(np.dot(x, y))], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    shard = O.OracleNKA(hi - lo, m)
+    shard.set_dot_prod(global_dot)
+    full = O.OracleNKA(n, m)
+    basis = np.stack([synth.fill_numpy(7, 100 + j, 0, n, n) for j in range(3)])
+    for t in range(calls):
+        if t % 4 == 3:      # dependent input now and then: forces dependence drops
+            coef = synth.fill_numpy(9, t, 0, 3, 3)
+            x = coef @ basis
+        else:
+            x = synth.fill_numpy(12345, t, 0, n, n)
+        f_full = x.copy()
+        f_loc = x[lo:hi].copy()
+        full.accel_update(f_full)
+        shard.accel_update(f_loc)
+        assert shard.num_vec() == full.num_vec(), (rank, t)
+        assert shard.state().list_order() == full.state().list_order(), (rank, t)
+        assert shard.state().free_order() == full.state().free_order(), (rank, t)
+        # replicated scalars must be bitwise identical on all ranks
+        c = torch.from_numpy(shard.state().c.copy())
+        cmax, cmin = c.clone(), c.clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        assert torch.equal(cmax, cmin), (rank, t)
+        err = np.linalg.norm(f_loc - f_full[lo:hi]) / np.linalg.norm(x)
+        assert err <= 1e-11, (rank, t, err)
+        if t == 8:
+            shard.relax(); full.relax()
+    print(f"rank {rank}/{world} slice [{lo},{hi}) OK", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

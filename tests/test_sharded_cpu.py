@@ -1,0 +1,69 @@
+"""N > 1 path on the CPU (gloo): slicing, id broadcast, and the sharded contract
+(row (e) of SURVEY.md 8).  The GPU arithmetic itself is covered by -m gpu tests;
+the 8-GPU RCCL run is the driver's."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_slice_bounds_partition_and_alignment():
+    from nka_amd.dist import slice_bounds
+    for n in (0, 1, 7, 1000, 1001, 10**8, 10**8 + 3):
+        for world in (1, 2, 3, 4, 8):
+            prev_hi = 0
+            for r in range(world):
+                lo, hi = slice_bounds(n, world, r)
+                assert lo == prev_hi and hi >= lo          # contiguous, ordered, complete
+                if r > 0:
+                    assert lo % 2 == 0                      # 16-byte aligned slice starts
+                prev_hi = hi
+            assert prev_hi == n
+            sizes = [slice_bounds(n, world, r)[1] - slice_bounds(n, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 3
+    with pytest.raises(ValueError):
+        slice_bounds(10, 2, 2)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_contract_world_size_n_gloo(world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_sharded_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.stdout.count(" OK") == world
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/nka_hip.h vs the built library: loadable on a CPU-only box and
+    exporting every entry point the header declares (no compute calls here)."""
+    import re
+    import nka_amd
+    from nka_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nka_hip.h")).read()
+    declared = set(re.findall(r"\b(nka_hip_[a-z0-9_]+)\s*\(", hdr)) - {"nka_hip_allreduce_fn"}
+    L = nka_amd.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libnka_hip.so lacks {name}"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    import nka_amd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(nka_amd.NKAError):
+        nka_amd.nka().init(10, 3)
