@@ -1,0 +1,181 @@
+!! nka_type (array flavour) -- Fortran host side of the MI355X NKA accelerator.
+!!
+!! Drop-in for module nka_type of the reference (src-F08/nka_type.F90:148-181):
+!! the same derived type name, the same type-bound procedure names and argument
+!! meaning --
+!!   init(vlen, mvec)  set_vec_tol(vtol)  accel_update(f)  restart()  relax()
+!!   num_vec()  max_vec()  vec_len()  vec_tol()  defined()
+!! -- but the object is only a handle: every vector, the Gram/Cholesky matrix
+!! and the linked lists live on the GPU, and each call goes through the C ABI of
+!! libnka_hip.so (module nka_hip_c, iso_c_binding).
+!!
+!! Differences a caller can see:
+!!  * accel_update(f) with a host array keeps the reference signature
+!!    (real(r8), intent(inout) :: f(:), F08:252) and copies f to the device and
+!!    back; accel_update_dev(f_dev) takes device memory (type(c_ptr)) and is the
+!!    entry a GPU-resident solver uses (no PCIe traffic, asynchronous).
+!!  * set_dot_prod (F08:209-214) becomes set_allreduce / use_rccl: the local
+!!    partial sums are already on the device, so the distribution hook is their
+!!    global SUM (one call per update, 2+2*mvec doubles), not a dot product.
+!!  * init takes optional flavor / device / stream arguments.
+
+module nka_type
+
+  use, intrinsic :: iso_fortran_env, only: r8 => real64
+  use, intrinsic :: iso_c_binding
+  use nka_hip_c
+  implicit none
+  private
+
+  type, public :: nka
+    private
+    type(c_ptr) :: handle = c_null_ptr
+  contains
+    procedure :: init
+    procedure :: set_vec_tol
+    procedure :: set_allreduce
+    procedure :: use_rccl
+    procedure :: vec_len
+    procedure :: num_vec
+    procedure :: max_vec
+    procedure :: vec_tol
+    procedure :: accel_update
+    procedure :: accel_update_dev
+    procedure :: relax
+    procedure :: restart
+    procedure :: defined
+    procedure :: set_timing
+    procedure :: get_timing
+    final :: nka_delete
+  end type nka
+
+  public :: NKA_HIP_FLAVOR_F08, NKA_HIP_FLAVOR_F08_VECTOR, NKA_HIP_FLAVOR_C
+
+contains
+
+  !! call a%init(vlen, mvec)                                  F08:185-200
+  subroutine init(this, vlen, mvec, flavor, device, stream)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: vlen, mvec
+    integer, intent(in), optional :: flavor, device
+    type(c_ptr), intent(in), optional :: stream
+    integer(c_int32_t) :: fl, dev
+    type(c_ptr) :: st
+    call nka_delete_handle(this)       ! intent(out) semantics: a re-init starts afresh
+    fl = NKA_HIP_FLAVOR_F08
+    dev = 0
+    st = c_null_ptr
+    if (present(flavor)) fl = int(flavor, c_int32_t)
+    if (present(device)) dev = int(device, c_int32_t)
+    if (present(stream)) st = stream
+    call nka_hip_check(nka_hip_create(this%handle, int(vlen, c_int64_t), int(mvec, c_int32_t), &
+                                      0.01_c_double, fl, dev, st), 'nka%init')
+  end subroutine
+
+  subroutine nka_delete_handle(this)
+    class(nka), intent(inout) :: this
+    integer(c_int) :: rc
+    if (c_associated(this%handle)) rc = nka_hip_destroy(this%handle)
+    this%handle = c_null_ptr
+  end subroutine
+
+  subroutine nka_delete(this)
+    type(nka), intent(inout) :: this
+    call nka_delete_handle(this)
+  end subroutine
+
+  !! call a%set_vec_tol(vtol)                                 F08:202-207
+  subroutine set_vec_tol(this, vtol)
+    class(nka), intent(inout) :: this
+    real(r8), intent(in) :: vtol
+    call nka_hip_check(nka_hip_set_vec_tol(this%handle, vtol), 'nka%set_vec_tol')
+  end subroutine
+
+  !! Replaces set_dot_prod (F08:209-214).  fn is a bind(C) function
+  !!   integer(c_int) function fn(ctx, buf, count, stream)
+  !! that sums `count` doubles at device address buf over all ranks, in place,
+  !! ordered on the given hipStream_t.
+  subroutine set_allreduce(this, fn, ctx)
+    class(nka), intent(inout) :: this
+    type(c_funptr), intent(in) :: fn
+    type(c_ptr), intent(in) :: ctx
+    call nka_hip_check(nka_hip_set_allreduce(this%handle, fn, ctx), 'nka%set_allreduce')
+  end subroutine
+
+  !! Built-in hook: one RCCL all-reduce per update over xGMI.
+  subroutine use_rccl(this, id128, nranks, rank)
+    class(nka), intent(inout) :: this
+    character(kind=c_char), intent(in) :: id128(128)
+    integer, intent(in) :: nranks, rank
+    call nka_hip_check(nka_hip_comm_init_rank(this%handle, id128, int(nranks, c_int32_t), &
+                                              int(rank, c_int32_t)), 'nka%use_rccl')
+  end subroutine
+
+  integer function vec_len(this)                              ! F08:238-241
+    class(nka), intent(in) :: this
+    vec_len = int(nka_hip_vec_len(this%handle))
+  end function
+
+  integer function num_vec(this)                              ! F08:221-231
+    class(nka), intent(in) :: this
+    num_vec = nka_hip_num_vec(this%handle)
+    if (num_vec < 0) call nka_hip_check(int(num_vec, c_int), 'nka%num_vec')
+  end function
+
+  integer function max_vec(this)                              ! F08:233-236
+    class(nka), intent(in) :: this
+    max_vec = nka_hip_max_vec(this%handle)
+  end function
+
+  real(r8) function vec_tol(this)                             ! F08:243-246
+    class(nka), intent(in) :: this
+    vec_tol = nka_hip_vec_tol(this%handle)
+  end function
+
+  !! call a%accel_update(f), host array (reference signature, F08:249-253)
+  subroutine accel_update(this, f)
+    class(nka), intent(inout) :: this
+    real(r8), intent(inout), contiguous :: f(:)
+    if (size(f) /= vec_len(this)) error stop 'nka%accel_update: size(f) /= vec_len()'   ! F08:258
+    call nka_hip_check(nka_hip_accel_update_host(this%handle, f), 'nka%accel_update')
+  end subroutine
+
+  !! The same on device memory: f_dev points to vec_len() doubles on the GPU.
+  subroutine accel_update_dev(this, f_dev)
+    class(nka), intent(inout) :: this
+    type(c_ptr), intent(in) :: f_dev
+    call nka_hip_check(nka_hip_accel_update(this%handle, f_dev), 'nka%accel_update_dev')
+  end subroutine
+
+  subroutine restart(this)                                    ! F08:422-436
+    class(nka), intent(inout) :: this
+    call nka_hip_check(nka_hip_restart(this%handle), 'nka%restart')
+  end subroutine
+
+  subroutine relax(this)                                      ! F08:439-457
+    class(nka), intent(inout) :: this
+    call nka_hip_check(nka_hip_relax(this%handle), 'nka%relax')
+  end subroutine
+
+  logical function defined(this)                              ! F08:460-524
+    class(nka), intent(in) :: this
+    defined = .false.
+    if (c_associated(this%handle)) defined = (nka_hip_defined(this%handle) == 1)
+  end function
+
+  subroutine set_timing(this, capacity)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: capacity
+    call nka_hip_check(nka_hip_set_timing(this%handle, int(capacity, c_int32_t)), 'nka%set_timing')
+  end subroutine
+
+  subroutine get_timing(this, back, ms)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: back
+    real, intent(out) :: ms(4)
+    real(c_float) :: t(4)
+    call nka_hip_check(nka_hip_get_timing(this%handle, int(back, c_int32_t), t), 'nka%get_timing')
+    ms = t
+  end subroutine
+
+end module nka_type

@@ -1,0 +1,210 @@
+!! nka_hip_c -- iso_c_binding interfaces to the C ABI of libnka_hip.so
+!! (include/nka_hip.h).  The thin shim the Fortran host code calls the HIP
+!! kernels through; no arithmetic happens on this side.
+
+module nka_hip_c
+
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  integer(c_int), parameter :: NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2
+
+  interface
+    integer(c_int) function nka_hip_create(handle, vlen_local, mvec, vtol, flavor, device, stream) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+      type(c_ptr), intent(out) :: handle
+      integer(c_int64_t), value :: vlen_local
+      integer(c_int32_t), value :: mvec, flavor, device
+      real(c_double), value :: vtol
+      type(c_ptr), value :: stream
+    end function
+    integer(c_int) function nka_hip_destroy(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_accel_update(handle, f_dev) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle, f_dev
+    end function
+    integer(c_int) function nka_hip_accel_update_host(handle, f_host) bind(C)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(inout) :: f_host(*)
+    end function
+    integer(c_int) function nka_hip_restart(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_relax(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_set_vec_tol(handle, vtol) bind(C)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), value :: vtol
+    end function
+    integer(c_int) function nka_hip_num_vec(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_max_vec(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int64_t) function nka_hip_vec_len(handle) bind(C)
+      import :: c_int64_t, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    real(c_double) function nka_hip_vec_tol(handle) bind(C)
+      import :: c_double, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_defined(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_set_allreduce(handle, fn, ctx) bind(C)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: handle, ctx
+      type(c_funptr), value :: fn
+    end function
+    integer(c_int) function nka_hip_comm_unique_id(id128) bind(C)
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: id128(128)
+    end function
+    integer(c_int) function nka_hip_comm_init_rank(handle, id128, nranks, rank) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: id128(128)
+      integer(c_int32_t), value :: nranks, rank
+    end function
+    integer(c_int) function nka_hip_set_timing(handle, capacity) bind(C)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: capacity
+    end function
+    integer(c_int) function nka_hip_get_timing(handle, back, ms) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_float
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: back
+      real(c_float), intent(out) :: ms(4)
+    end function
+    type(c_ptr) function nka_hip_last_error() bind(C)
+      import :: c_ptr
+    end function
+
+    !! vector primitives (the deferred procedures of the abstract vector class)
+    integer(c_int) function nka_hip_vec_workspace_create(ws, device, stream) bind(C)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), intent(out) :: ws
+      integer(c_int32_t), value :: device
+      type(c_ptr), value :: stream
+    end function
+    integer(c_int) function nka_hip_vec_workspace_destroy(ws) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ws
+    end function
+    integer(c_int) function nka_hip_vec_alloc(ws, n, dev) bind(C)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ws
+      integer(c_int64_t), value :: n
+      type(c_ptr), intent(out) :: dev
+    end function
+    integer(c_int) function nka_hip_vec_free(ws, dev) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ws, dev
+    end function
+    integer(c_int) function nka_hip_vec_copy(ws, n, dst, src) bind(C)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: ws, dst, src
+      integer(c_int64_t), value :: n
+    end function
+    integer(c_int) function nka_hip_vec_setval(ws, n, x, val) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: val
+    end function
+    integer(c_int) function nka_hip_vec_scale(ws, n, x, a) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a
+    end function
+    integer(c_int) function nka_hip_vec_update1(ws, n, z, a, x) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a
+    end function
+    integer(c_int) function nka_hip_vec_update2(ws, n, z, a, x, b) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a, b
+    end function
+    integer(c_int) function nka_hip_vec_update3(ws, n, z, a, x, b, y) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x, y
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a, b
+    end function
+    integer(c_int) function nka_hip_vec_update4(ws, n, z, a, x, b, y, c) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x, y
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a, b, c
+    end function
+    integer(c_int) function nka_hip_vec_dot(ws, n, x, y, res) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x, y
+      integer(c_int64_t), value :: n
+      real(c_double), intent(out) :: res
+    end function
+    integer(c_int) function nka_hip_vec_norm2(ws, n, x, res) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x
+      integer(c_int64_t), value :: n
+      real(c_double), intent(out) :: res
+    end function
+    integer(c_int) function nka_hip_vec_h2d(ws, n, dst_dev, src_host) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, dst_dev
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: src_host(*)
+    end function
+    integer(c_int) function nka_hip_vec_d2h(ws, n, dst_host, src_dev) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, src_dev
+      integer(c_int64_t), value :: n
+      real(c_double), intent(out) :: dst_host(*)
+    end function
+  end interface
+
+contains
+
+  !! The reference has no status codes: a failed precondition stops the program
+  !! (f90_assert / error stop).  A failing C-ABI call does the same here, with
+  !! the library's message.
+  subroutine nka_hip_check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: i
+    if (rc == 0) return
+    write(*,'(3a,i0)') 'nka_hip: ', what, ' failed with status ', rc
+    p = nka_hip_last_error()
+    if (c_associated(p)) then
+      call c_f_pointer(p, msg, [512])
+      do i = 1, 512
+        if (msg(i) == c_null_char) exit
+      end do
+      write(*,'(512a)') msg(1:i-1)
+    end if
+    error stop 1
+  end subroutine
+
+end module nka_hip_c

@@ -1,0 +1,308 @@
+!! nka_type (abstract-vector flavour) -- NKA on user-defined vector objects.
+!!
+!! Drop-in for module nka_type of src-F08-vector/nka_type.F90:148-171: same type
+!! name and type-bound procedures
+!!   init(vec, mvec)  set_vec_tol(vtol)  accel_update(f)  restart()  relax()
+!!   num_vec()  max_vec()  vec_tol()  defined()
+!! The algorithm can only touch the vectors through the hooks of class(vector),
+!! so -- as in the reference -- the list bookkeeping and the (mvec+1)^2 Gram /
+!! Cholesky matrix live on the host and every O(n) statement is a hook call:
+!!   update(-1,f) ; norm2 ; scale(1/s) x2 ; dot x L        (F08V:237-262)
+!!   copy ; dot x k ; update(-c,w,c,v) x k ; copy          (F08V:336-382)
+!! With a device-resident concrete vector (hip_block_vector_type) each hook is a
+!! HIP kernel.  The hook sequence, and therefore every rounding of the stored
+!! vectors, is the reference's; the scalar step restates F08V:269-368 (see
+!! factor_with_drops / solve_normal_equations).
+
+module nka_type
+
+  use, intrinsic :: iso_fortran_env, only: r8 => real64
+  use vector_class
+  implicit none
+  private
+
+  type, public :: nka
+    private
+    logical :: subspace = .false., pending = .false.
+    integer :: mvec = 0
+    real(r8) :: vtol = 0.01_r8                    ! default drop tolerance (F08V:152)
+    class(vector), allocatable :: v(:), w(:)      ! mvec+1 slots each
+    real(r8), allocatable :: h(:,:)               ! raw Gram entries / Cholesky factor
+    integer :: first = 0, last = 0, free = 0      ! list heads; 0 terminates a list
+    integer, allocatable :: next(:), prev(:)
+  contains
+    procedure :: init
+    procedure :: set_vec_tol
+    procedure :: num_vec
+    procedure :: max_vec
+    procedure :: vec_tol
+    procedure :: accel_update
+    procedure :: relax
+    procedure :: restart
+    procedure :: defined
+  end type nka
+
+contains
+
+  !! call a%init(vec, mvec): slots are clones of vec (F08V:175-188)
+  subroutine init(this, vec, mvec)
+    class(nka), intent(out) :: this
+    class(vector), intent(in) :: vec
+    integer, intent(in) :: mvec
+    if (mvec <= 0) error stop 'nka%init: mvec must be positive'
+    this%mvec = mvec
+    call vec%clone(this%v, mvec+1)
+    call vec%clone(this%w, mvec+1)
+    allocate(this%h(mvec+1,mvec+1), this%next(mvec+1), this%prev(mvec+1))
+    this%h = 0.0_r8
+    this%prev = 0
+    call this%restart
+  end subroutine
+
+  subroutine set_vec_tol(this, vtol)              ! F08V:190-195
+    class(nka), intent(inout) :: this
+    real(r8), intent(in) :: vtol
+    if (.not.(vtol > 0.0_r8)) error stop 'nka%set_vec_tol: vtol must be positive'
+    this%vtol = vtol
+  end subroutine
+
+  integer function num_vec(this)                  ! F08V:197-207
+    class(nka), intent(in) :: this
+    integer :: k
+    num_vec = 0
+    k = this%first
+    do while (k /= 0)
+      num_vec = num_vec + 1
+      k = this%next(k)
+    end do
+    if (this%pending) num_vec = num_vec - 1
+  end function
+
+  integer function max_vec(this)
+    class(nka), intent(in) :: this
+    max_vec = this%mvec
+  end function
+
+  real(r8) function vec_tol(this)
+    class(nka), intent(in) :: this
+    vec_tol = this%vtol
+  end function
+
+  subroutine restart(this)                        ! F08V:400-414
+    class(nka), intent(inout) :: this
+    integer :: k
+    this%subspace = .false.
+    this%pending = .false.
+    this%first = 0
+    this%last = 0
+    this%free = 1
+    do k = 1, this%mvec
+      this%next(k) = k + 1
+    end do
+    this%next(this%mvec+1) = 0
+  end subroutine
+
+  subroutine relax(this)                          ! F08V:417-435
+    class(nka), intent(inout) :: this
+    integer :: slot
+    if (.not. this%pending) return
+    slot = this%first
+    this%first = this%next(slot)
+    if (this%first == 0) then
+      this%last = 0
+    else
+      this%prev(this%first) = 0
+    end if
+    call push_free(this, slot)
+    this%pending = .false.
+  end subroutine
+
+  subroutine push_free(this, slot)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: slot
+    this%next(slot) = this%free
+    this%free = slot
+  end subroutine
+
+  !! Row-by-row Cholesky factorisation of the Gram matrix in list order with the
+  !! capacity and dependence drops (F08V:269-321).  For list entries j newer than
+  !! k, h(j,k) is the raw inner product and h(k,j) the factor entry.
+  subroutine factor_with_drops(this)
+    class(nka), intent(inout) :: this
+    integer :: i, j, k, nvec, before, after
+    real(r8) :: pivot, entry
+    this%h(this%first,this%first) = 1.0_r8
+    nvec = 1
+    k = this%next(this%first)
+    do while (k /= 0)
+      nvec = nvec + 1
+      if (nvec > this%mvec) then                  ! capacity: k is the last entry
+        this%last = this%prev(k)
+        this%next(this%last) = 0
+        call push_free(this, k)
+        exit
+      end if
+      pivot = 1.0_r8
+      j = this%first
+      do while (j /= k)
+        entry = this%h(j,k)
+        i = this%first
+        do while (i /= j)
+          entry = entry - this%h(k,i) * this%h(j,i)
+          i = this%next(i)
+        end do
+        entry = entry / this%h(j,j)
+        pivot = pivot - entry**2
+        this%h(k,j) = entry
+        j = this%next(j)
+      end do
+      if (pivot > this%vtol**2) then
+        this%h(k,k) = sqrt(pivot)
+        k = this%next(k)
+      else                                        ! dependent on the newer vectors: unlink k
+        before = this%prev(k)
+        after = this%next(k)
+        this%next(before) = after
+        if (after == 0) then
+          this%last = before
+        else
+          this%prev(after) = before
+        end if
+        call push_free(this, k)
+        nvec = nvec - 1
+        k = after
+      end if
+    end do
+    this%subspace = .true.
+    this%pending = .false.
+  end subroutine
+
+  !! c holds <f,w_j> by slot on entry, the least-squares coefficients on return
+  !! (forward then backward substitution, F08V:344-368).
+  subroutine solve_normal_equations(this, c)
+    class(nka), intent(in) :: this
+    real(r8), intent(inout) :: c(:)
+    integer :: i, j
+    real(r8) :: t
+    j = this%first
+    do while (j /= 0)
+      t = c(j)
+      i = this%first
+      do while (i /= j)
+        t = t - this%h(j,i) * c(i)
+        i = this%next(i)
+      end do
+      c(j) = t / this%h(j,j)
+      j = this%next(j)
+    end do
+    j = this%last
+    do while (j /= 0)
+      t = c(j)
+      i = this%last
+      do while (i /= j)
+        t = t - this%h(i,j) * c(i)
+        i = this%prev(i)
+      end do
+      c(j) = t / this%h(j,j)
+      j = this%prev(j)
+    end do
+  end subroutine
+
+  !! call a%accel_update(f)                                   F08V:219-397
+  subroutine accel_update(this, f)
+    class(nka), intent(inout) :: this
+    class(vector), intent(inout) :: f
+    real(r8) :: s, c(this%mvec+1)
+    integer :: k, slot
+
+    if (this%pending) then
+      call this%w(this%first)%update(-1.0_r8, f)             ! w1 <- w1 - f
+      s = this%w(this%first)%norm2()
+      if (s == 0.0_r8) call this%relax                       ! nothing to learn from a zero difference
+    end if
+
+    if (this%pending) then
+      call this%v(this%first)%scale(1.0_r8/s)
+      call this%w(this%first)%scale(1.0_r8/s)
+      k = this%next(this%first)
+      do while (k /= 0)
+        this%h(this%first,k) = this%w(this%first)%dot(this%w(k))
+        k = this%next(k)
+      end do
+      call factor_with_drops(this)
+    end if
+
+    slot = this%free
+    this%free = this%next(slot)
+    call this%w(slot)%copy(f)                                ! keep the raw f for the next call
+
+    if (this%subspace) then
+      k = this%first
+      do while (k /= 0)
+        c(k) = f%dot(this%w(k))
+        k = this%next(k)
+      end do
+      call solve_normal_equations(this, c)
+      k = this%first
+      do while (k /= 0)
+        call f%update(-c(k), this%w(k), c(k), this%v(k))     ! f <- f - c w + c v
+        k = this%next(k)
+      end do
+    end if
+
+    call this%v(slot)%copy(f)                                ! keep the returned update
+    this%prev(slot) = 0
+    this%next(slot) = this%first
+    if (this%first == 0) then
+      this%last = slot
+    else
+      this%prev(this%first) = slot
+    end if
+    this%first = slot
+    this%pending = .true.
+  end subroutine accel_update
+
+  !! Structural invariants of the two lists (F08V:438-501).
+  logical function defined(this)
+    class(nka), intent(in) :: this
+    logical, allocatable :: seen(:)
+    integer :: n, k, steps
+    defined = .false.
+    if (this%mvec < 1) return
+    if (.not.allocated(this%v) .or. .not.allocated(this%w) .or. .not.allocated(this%h)) return
+    if (.not.allocated(this%next) .or. .not.allocated(this%prev)) return
+    n = this%mvec + 1
+    if (size(this%v) /= n .or. size(this%w) /= n) return
+    if (any(shape(this%h) /= [n,n]) .or. size(this%next) /= n .or. size(this%prev) /= n) return
+    if (.not.(this%vtol > 0.0_r8)) return
+    if (any(this%next < 0) .or. any(this%next > n)) return
+    if (this%first < 0 .or. this%first > n .or. this%free < 0 .or. this%free > n) return
+    allocate(seen(n))
+    seen = .false.
+    if (this%first == 0) then
+      if (this%last /= 0) return
+    else
+      if (this%prev(this%first) /= 0) return
+      k = this%first
+      steps = 0
+      do
+        if (seen(k)) return
+        seen(k) = .true.
+        steps = steps + 1
+        if (this%next(k) == 0) exit
+        if (this%prev(this%next(k)) /= k) return
+        k = this%next(k)
+        if (steps > n) return
+      end do
+      if (this%last /= k) return
+    end if
+    k = this%free
+    do while (k /= 0)
+      if (seen(k)) return
+      seen(k) = .true.
+      k = this%next(k)
+    end do
+    defined = all(seen)
+  end function
+
+end module nka_type

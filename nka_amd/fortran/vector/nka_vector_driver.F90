@@ -1,0 +1,140 @@
+!! nka_vector_driver -- exercises the abstract-vector flavour on the GPU.
+!!
+!!   nka_vector_driver check NFIELD NPER MVEC NCALLS OUTFILE
+!!       drives NKA (vector flavour) on a hip_block_vector with the integer-LCG
+!!       inputs of SURVEY.md 8(c) (x <- (1103515245 x + 12345) mod 2^31, value
+!!       x/2^30 - 1; every 5th call a vector from a 3-dimensional pool so that
+!!       dependence drops occur) and writes, per call, num_vec and the returned
+!!       vector to OUTFILE (stream, native real64) for tests/test_fortran_gpu.py
+!!       to compare with the oracle's F08-vector flavour.
+!!   nka_vector_driver bench NFIELD NPER MVEC STEPS
+!!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
+!!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
+
+program nka_vector_driver
+
+  use, intrinsic :: iso_fortran_env, only: r8 => real64, i8 => int64
+  use, intrinsic :: iso_c_binding
+  use vector_class
+  use hip_block_vector_type
+  use nka_type
+  implicit none
+
+  character(256) :: mode, arg, outfile
+  integer :: nfield, mvec, ncalls
+  integer(i8) :: nper
+  integer(i8) :: lcg_state = 1
+
+  call get_command_argument(1, mode)
+  call get_command_argument(2, arg); read(arg,*) nfield
+  call get_command_argument(3, arg); read(arg,*) nper
+  call get_command_argument(4, arg); read(arg,*) mvec
+  call get_command_argument(5, arg); read(arg,*) ncalls
+  select case (trim(mode))
+  case ('check')
+    call get_command_argument(6, outfile)
+    call run_check
+  case ('bench')
+    call run_bench
+  case default
+    error stop 'usage: nka_vector_driver check|bench NFIELD NPER MVEC NCALLS [OUTFILE]'
+  end select
+
+contains
+
+  real(r8) function lcg()
+    lcg_state = mod(1103515245_i8*lcg_state + 12345_i8, 2147483648_i8)
+    lcg = real(lcg_state, r8) / 1073741824.0_r8 - 1.0_r8
+  end function
+
+  subroutine run_check
+    type(hip_block_vector) :: f
+    type(nka) :: accel
+    type(c_ptr) :: ws
+    real(r8), allocatable :: host(:), pool(:,:), coef(:)
+    integer :: t, k, lun
+    integer(i8) :: n, i
+    n = nfield * nper
+    ws = hip_block_vector_workspace(0)
+    call f%init(nfield, nper, ws)
+    call accel%init(f, mvec)
+    allocate(host(n), pool(n,3), coef(3))
+    do k = 1, 3
+      do i = 1, n
+        pool(i,k) = lcg()
+      end do
+    end do
+    open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    do t = 1, ncalls
+      if (mod(t, 5) == 0) then
+        do k = 1, 3
+          coef(k) = lcg()
+        end do
+        host = coef(1)*pool(:,1) + coef(2)*pool(:,2) + coef(3)*pool(:,3)
+      else
+        do i = 1, n
+          host(i) = lcg()
+        end do
+      end if
+      write(lun) host                             ! the input, so the checker needs no second LCG
+      do k = 1, nfield
+        call f%set_field(k, host((k-1)*nper+1:k*nper))
+      end do
+      call accel%accel_update(f)
+      do k = 1, nfield
+        call f%get_field(k, host((k-1)*nper+1:k*nper))
+      end do
+      write(lun) real(accel%num_vec(), r8)
+      write(lun) host
+    end do
+    close(lun)
+    if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
+    write(*,'(a,i0,a,i0)') 'check: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
+  end subroutine
+
+  subroutine run_bench
+    type(hip_block_vector) :: f
+    type(hip_block_vector), allocatable :: inputs(:)
+    type(nka) :: accel
+    type(c_ptr) :: ws
+    real(r8), allocatable :: host(:)
+    integer :: t, k, warm, ninp
+    integer(i8) :: n, c0, c1, rate
+    real(r8) :: secs, per, dummy
+    n = nfield * nper
+    warm = mvec + 3
+    ninp = warm + ncalls
+    ws = hip_block_vector_workspace(0)
+    call f%init(nfield, nper, ws)
+    call accel%init(f, mvec)
+    !! independent inputs, resident on the device before the timed region
+    allocate(inputs(ninp), host(nper))
+    do t = 1, ninp
+      call inputs(t)%init(nfield, nper, ws)
+      do k = 1, nfield
+        call random_number(host)
+        host = 2.0_r8*host - 1.0_r8
+        call inputs(t)%set_field(k, host)
+      end do
+    end do
+    do t = 1, warm
+      call f%copy(inputs(t))
+      call accel%accel_update(f)
+    end do
+    if (accel%num_vec() /= mvec) error stop 'bench: subspace not full after warm-up'
+    dummy = f%norm2()                               ! drains the stream
+    call system_clock(c0, rate)
+    do t = warm+1, ninp
+      call accel%accel_update(inputs(t))
+    end do
+    dummy = inputs(ninp)%norm2()
+    call system_clock(c1)
+    secs = real(c1 - c0, r8) / real(rate, r8)
+    per = secs / ncalls
+    write(*,'(a,i0,a,i0,a,i0)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec
+    write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
+    write(*,'(a,f10.1,a,f10.1)') 'as-written GB/s (8n(12+8m)) ', 8.0_r8*n*(12+8*mvec)/per/1e9_r8, &
+                                 '   algorithmic GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
+  end subroutine
+
+end program nka_vector_driver

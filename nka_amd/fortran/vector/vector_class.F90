@@ -1,0 +1,215 @@
+!! vector_class -- the abstract vector interface of the abstract-vector flavour.
+!!
+!! Plugin interface kept intact from the reference (src-F08-vector/
+!! vector_class.F90:90-228): a user type extends `vector` and supplies the eleven
+!! deferred procedures
+!!   clone1, clone2, setval, scale, norm2, copy_, update1_ .. update4_, dot_
+!! and the accelerator only ever calls the public generics
+!!   clone, copy, setval, scale, update (1-4 coefficient forms), dot, norm2.
+!! The non-deferred wrappers check that the operands have the same dynamic type
+!! (error stop otherwise, :157,167,180,194,210,226) and short-circuit zero
+!! coefficients exactly like the reference (:176,189,203-206,219-222).
+!!
+!! Additions (SURVEY.md 8 f1), NOT deferred, so existing user types keep
+!! compiling: dot_many and update_many have default bodies that loop over the
+!! deferred hooks; a device vector may override them with fused kernels.
+
+module vector_class
+
+  use, intrinsic :: iso_fortran_env, only: r8 => real64
+  implicit none
+  private
+
+  type, abstract, public :: vector
+  contains
+    generic :: clone => clone1, clone2
+    procedure(clone1_if), deferred :: clone1
+    procedure(clone2_if), deferred :: clone2
+    procedure :: copy
+    procedure(setval_if), deferred :: setval
+    procedure(scale_if), deferred :: scale
+    generic :: update => update1, update2, update3, update4
+    procedure, private :: update1, update2, update3, update4
+    procedure :: dot
+    procedure(norm2_if), deferred :: norm2
+    !! the hooks behind the wrappers (called only with same-type operands)
+    procedure(copy_if), deferred :: copy_
+    procedure(update1_if), deferred :: update1_
+    procedure(update2_if), deferred :: update2_
+    procedure(update3_if), deferred :: update3_
+    procedure(update4_if), deferred :: update4_
+    procedure(dot_if), deferred :: dot_
+    !! optional batched forms (overridable, default = loops over the hooks)
+    procedure :: dot_many
+    procedure :: update_many
+  end type
+
+  abstract interface
+    subroutine clone1_if(this, clone)
+      import :: vector
+      class(vector), intent(in) :: this
+      class(vector), allocatable, intent(out) :: clone
+    end subroutine
+    subroutine clone2_if(this, clone, n)
+      import :: vector
+      class(vector), intent(in) :: this
+      class(vector), allocatable, intent(out) :: clone(:)
+      integer, intent(in) :: n
+    end subroutine
+    subroutine setval_if(this, val)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: val
+    end subroutine
+    subroutine scale_if(this, a)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: a
+    end subroutine
+    function norm2_if(this) result(val)
+      import :: vector, r8
+      class(vector), intent(in) :: this
+      real(r8) :: val
+    end function
+    subroutine copy_if(dest, src)
+      import :: vector
+      class(vector), intent(inout) :: dest
+      class(vector), intent(in) :: src
+    end subroutine
+    subroutine update1_if(this, a, x)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: a
+      class(vector), intent(in) :: x
+    end subroutine
+    subroutine update2_if(this, a, x, b)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: a, b
+      class(vector), intent(in) :: x
+    end subroutine
+    subroutine update3_if(this, a, x, b, y)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: a, b
+      class(vector), intent(in) :: x, y
+    end subroutine
+    subroutine update4_if(this, a, x, b, y, c)
+      import :: vector, r8
+      class(vector), intent(inout) :: this
+      real(r8), intent(in) :: a, b, c
+      class(vector), intent(in) :: x, y
+    end subroutine
+    function dot_if(x, y) result(val)
+      import :: vector, r8
+      class(vector), intent(in) :: x, y
+      real(r8) :: val
+    end function
+  end interface
+
+contains
+
+  subroutine need_same_type(a, b, who)
+    class(vector), intent(in) :: a, b
+    character(*), intent(in) :: who
+    if (.not. same_type_as(a, b)) then
+      write(*,'(2a)') 'incompatible arguments to VECTOR%', who
+      error stop 1
+    end if
+  end subroutine
+
+  !! dest <- src
+  recursive subroutine copy(dest, src)
+    class(vector), intent(inout) :: dest
+    class(vector), intent(in) :: src
+    call need_same_type(dest, src, 'COPY')
+    call dest%copy_(src)
+  end subroutine
+
+  recursive function dot(x, y) result(val)
+    class(vector), intent(in) :: x, y
+    real(r8) :: val
+    call need_same_type(x, y, 'DOT')
+    val = x%dot_(y)
+  end function
+
+  !! this <- a*x + this
+  recursive subroutine update1(this, a, x)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    if (a == 0.0_r8) return
+    call need_same_type(this, x, 'UPDATE')
+    call this%update1_(a, x)
+  end subroutine
+
+  !! this <- a*x + b*this
+  recursive subroutine update2(this, a, x, b)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a, b
+    class(vector), intent(in) :: x
+    if (a == 0.0_r8) then
+      call this%scale(b)
+      return
+    end if
+    call need_same_type(this, x, 'UPDATE')
+    call this%update2_(a, x, b)
+  end subroutine
+
+  !! this <- a*x + b*y + this
+  recursive subroutine update3(this, a, x, b, y)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a, b
+    class(vector), intent(in) :: x, y
+    if (a == 0.0_r8) then
+      call update1(this, b, y)
+    else if (b == 0.0_r8) then
+      call update1(this, a, x)
+    else
+      call need_same_type(this, x, 'UPDATE')
+      call need_same_type(this, y, 'UPDATE')
+      call this%update3_(a, x, b, y)
+    end if
+  end subroutine
+
+  !! this <- a*x + b*y + c*this
+  recursive subroutine update4(this, a, x, b, y, c)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a, b, c
+    class(vector), intent(in) :: x, y
+    if (a == 0.0_r8) then
+      call update2(this, b, y, c)
+    else if (b == 0.0_r8) then
+      call update2(this, a, x, c)
+    else
+      call need_same_type(this, x, 'UPDATE')
+      call need_same_type(this, y, 'UPDATE')
+      call this%update4_(a, x, b, y, c)
+    end if
+  end subroutine
+
+  !! vals(j) = <this, ys(idx(j))>, j = 1..size(idx).  Default: one dot per entry.
+  subroutine dot_many(this, ys, idx, vals)
+    class(vector), intent(in) :: this
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals(:)
+    integer :: j
+    do j = 1, size(idx)
+      vals(j) = this%dot(ys(idx(j)))
+    end do
+  end subroutine
+
+  !! this <- this + sum_j ( a(j)*xs(idx(j)) + b(j)*ys(idx(j)) ), applied in order j = 1..size(idx).
+  subroutine update_many(this, a, xs, b, ys, idx)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:), b(:)
+    class(vector), intent(in) :: xs(:), ys(:)
+    integer, intent(in) :: idx(:)
+    integer :: j
+    do j = 1, size(idx)
+      call this%update(a(j), xs(idx(j)), b(j), ys(idx(j)))
+    end do
+  end subroutine
+
+end module vector_class
