@@ -120,10 +120,20 @@ def main():
 
     flavor = {"f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR, "c": nka_amd.FLAVOR_C}[args.flavor]
     acc = nka_amd.nka().init(n_local, m, flavor=flavor)
-    if world > 1:
-        if args.allreduce == "rccl":
-            nd.attach_rccl(acc, rank, world)
-        else:
+    hook = "none"
+    if world > 1 or os.environ.get("NKA_BENCH_FORCE_HOOK") == "1":
+        if not dist.is_initialized():          # single-process rehearsal of the N > 1 plumbing
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        hook = args.allreduce
+        if hook == "rccl":
+            try:
+                nd.attach_rccl(acc, rank, world)
+            except Exception as exc:   # collective failure: every rank lands here together
+                print(f"[bench] RCCL communicator failed ({exc!r}); using the torch.distributed hook", file=sys.stderr)
+                hook = "torch"
+        if hook == "torch":
             nd.attach_torch_allreduce(acc)
 
     # ---- inputs: resident in HBM before the timed region ----------------------
@@ -210,6 +220,18 @@ def main():
                              "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None}
         kernels["k_solve"] = {"mean_ms": mean[1]}
         achieved = b_alg / upd_s / 1e9 if upd_s > 0 else 0.0
+        # HBM bytes per update from the rocprofv3 PMC passes of THIS workload (tools/rocprof_bench.sh +
+        # tools/pmc_summary.py, committed under profiles/); null if no matching measurement is present
+        traffic, traffic_src = None, None
+        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{args.flavor}.json")), reverse=True):
+            try:
+                with open(cand) as fh:
+                    pm = json.load(fh)
+                if pm.get("n") == n_local and pm.get("mvec") == m and pm.get("hbm_bytes_per_update"):
+                    traffic, traffic_src = pm["hbm_bytes_per_update"], os.path.relpath(cand, ROOT)
+                    break
+            except Exception:
+                pass
         out = {
             "metric": "NKA accel_update throughput (updates/s) at n=%.0e, m=%d, fp64" % (n_global, m),
             "value": K / elapsed, "unit": "updates/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -221,11 +243,11 @@ def main():
                        "flavor": {"c": "src-C rounding f += c*(v-w), compact storage",
                                   "f08": "src-F08 rounding (f - c*w) + c*v",
                                   "f08vec": "src-F08-vector rounding"}[args.flavor],
-                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={args.allreduce if world > 1 else 'none'}",
+                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook}",
                        "steady_state": bool(steady and nv_end == m),
                        "inputs_resident": not refill_in_timed_region},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "what": "whole accel_update on one GPU: algorithmic bytes 8*n_local*(11+L+2k) / mean "
                                  "device time first-kernel-start..last-kernel-end (HIP events, kernel stream)",
                          "algorithmic_bytes_per_update": b_alg, "mean_update_ms": mean[3],
@@ -244,7 +266,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

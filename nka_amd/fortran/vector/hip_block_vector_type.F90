@@ -3,12 +3,13 @@
 !! grid_vector, src-F08-vector/grid_vector_type.F90:44-197).
 !!
 !! A block vector of NFIELD fields of NPER doubles each (BASELINE config 5: 4
-!! fields x 1e7), every field a separate array in HBM.  Each deferred procedure
-!! of class(vector) is one HIP kernel per field through the C ABI
-!! (nka_hip_vec_*, nka_amd/csrc/vec_ops.hip); the elementwise results are rounded
-!! like the Fortran expressions of grid_vector (a*x + b*y + z evaluated left to
-!! right, no fused multiply-add); dot products are deterministic two-stage
-!! reductions, summed over the fields in order.
+!! fields x 1e7).  The fields are consecutive views of ONE allocation in HBM, so
+!! each deferred procedure of class(vector) is a single HIP kernel over all
+!! fields through the C ABI (nka_hip_vec_*, nka_amd/csrc/vec_ops.hip), not one
+!! launch (and, for dot/norm2, one host round trip) per field.  The elementwise
+!! results are rounded like the Fortran expressions of grid_vector (a*x + b*y + z
+!! evaluated left to right, no fused multiply-add); dot products are
+!! deterministic two-stage reductions.
 
 module hip_block_vector_type
 
@@ -22,7 +23,8 @@ module hip_block_vector_type
   type, extends(vector), public :: hip_block_vector
     integer :: nfield = 0
     integer(c_int64_t) :: nper = 0
-    type(c_ptr), allocatable :: field(:)        ! device pointers, one per field
+    integer(c_int64_t) :: ntot = 0              ! nfield*nper
+    type(c_ptr) :: base = c_null_ptr            ! device pointer to ntot doubles; field k starts at (k-1)*nper
     type(c_ptr) :: ws = c_null_ptr              ! shared workspace (stream, reduction scratch); not owned
   contains
     procedure :: clone1
@@ -59,37 +61,40 @@ contains
     integer, intent(in) :: nfield
     integer(c_int64_t), intent(in) :: nper
     type(c_ptr), intent(in) :: ws
-    integer :: k
     call this%release
     this%nfield = nfield
     this%nper = nper
+    this%ntot = nfield * nper
     this%ws = ws
-    allocate(this%field(nfield))
-    do k = 1, nfield
-      call nka_hip_check(nka_hip_vec_alloc(ws, nper, this%field(k)), 'vec_alloc')
-    end do
+    call nka_hip_check(nka_hip_vec_alloc(ws, this%ntot, this%base), 'vec_alloc')
   end subroutine
 
   !! Device memory is released explicitly (clones made by the accelerator live
   !! as long as the accelerator object).
   subroutine release(this)
     class(hip_block_vector), intent(inout) :: this
-    integer :: k
-    if (allocated(this%field)) then
-      do k = 1, size(this%field)
-        if (c_associated(this%field(k))) call nka_hip_check(nka_hip_vec_free(this%ws, this%field(k)), 'vec_free')
-      end do
-      deallocate(this%field)
-    end if
+    if (c_associated(this%base)) call nka_hip_check(nka_hip_vec_free(this%ws, this%base), 'vec_free')
+    this%base = c_null_ptr
     this%nfield = 0
+    this%ntot = 0
   end subroutine
+
+  !! device address of field k
+  type(c_ptr) function field_ptr(this, k)
+    class(hip_block_vector), intent(in) :: this
+    integer, intent(in) :: k
+    integer(c_intptr_t) :: addr
+    if (k < 1 .or. k > this%nfield) error stop 'hip_block_vector: field index out of range'
+    addr = transfer(this%base, addr) + int(k-1, c_intptr_t) * int(this%nper, c_intptr_t) * 8_c_intptr_t
+    field_ptr = transfer(addr, field_ptr)
+  end function
 
   subroutine set_field(this, k, array)
     class(hip_block_vector), intent(inout) :: this
     integer, intent(in) :: k
     real(r8), intent(in), contiguous :: array(:)
     if (size(array, kind=c_int64_t) /= this%nper) error stop 'hip_block_vector%set_field: wrong size'
-    call nka_hip_check(nka_hip_vec_h2d(this%ws, this%nper, this%field(k), array), 'vec_h2d')
+    call nka_hip_check(nka_hip_vec_h2d(this%ws, this%nper, field_ptr(this, k), array), 'vec_h2d')
   end subroutine
 
   subroutine get_field(this, k, array)
@@ -97,7 +102,7 @@ contains
     integer, intent(in) :: k
     real(r8), intent(out), contiguous :: array(:)
     if (size(array, kind=c_int64_t) /= this%nper) error stop 'hip_block_vector%get_field: wrong size'
-    call nka_hip_check(nka_hip_vec_d2h(this%ws, this%nper, array, this%field(k)), 'vec_d2h')
+    call nka_hip_check(nka_hip_vec_d2h(this%ws, this%nper, array, field_ptr(this, k)), 'vec_d2h')
   end subroutine
 
   !! clone: same structure, NEW device storage, values undefined (vector_class.F90:93-101)
@@ -128,43 +133,31 @@ contains
   subroutine copy_(dest, src)
     class(hip_block_vector), intent(inout) :: dest
     class(vector), intent(in) :: src
-    integer :: k
     select type (src)
     class is (hip_block_vector)
-      do k = 1, dest%nfield
-        call nka_hip_check(nka_hip_vec_copy(dest%ws, dest%nper, dest%field(k), src%field(k)), 'vec_copy')
-      end do
+      call nka_hip_check(nka_hip_vec_copy(dest%ws, dest%ntot, dest%base, src%base), 'vec_copy')
     end select
   end subroutine
 
   subroutine setval(this, val)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: val
-    integer :: k
-    do k = 1, this%nfield
-      call nka_hip_check(nka_hip_vec_setval(this%ws, this%nper, this%field(k), val), 'vec_setval')
-    end do
+    call nka_hip_check(nka_hip_vec_setval(this%ws, this%ntot, this%base, val), 'vec_setval')
   end subroutine
 
   subroutine scale(this, a)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a
-    integer :: k
-    do k = 1, this%nfield
-      call nka_hip_check(nka_hip_vec_scale(this%ws, this%nper, this%field(k), a), 'vec_scale')
-    end do
+    call nka_hip_check(nka_hip_vec_scale(this%ws, this%ntot, this%base, a), 'vec_scale')
   end subroutine
 
   subroutine update1_(this, a, x)               ! this <- a*x + this
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a
     class(vector), intent(in) :: x
-    integer :: k
     select type (x)
     class is (hip_block_vector)
-      do k = 1, this%nfield
-        call nka_hip_check(nka_hip_vec_update1(this%ws, this%nper, this%field(k), a, x%field(k)), 'vec_update1')
-      end do
+      call nka_hip_check(nka_hip_vec_update1(this%ws, this%ntot, this%base, a, x%base), 'vec_update1')
     end select
   end subroutine
 
@@ -172,12 +165,9 @@ contains
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b
     class(vector), intent(in) :: x
-    integer :: k
     select type (x)
     class is (hip_block_vector)
-      do k = 1, this%nfield
-        call nka_hip_check(nka_hip_vec_update2(this%ws, this%nper, this%field(k), a, x%field(k), b), 'vec_update2')
-      end do
+      call nka_hip_check(nka_hip_vec_update2(this%ws, this%ntot, this%base, a, x%base, b), 'vec_update2')
     end select
   end subroutine
 
@@ -185,15 +175,11 @@ contains
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b
     class(vector), intent(in) :: x, y
-    integer :: k
     select type (x)
     class is (hip_block_vector)
       select type (y)
       class is (hip_block_vector)
-        do k = 1, this%nfield
-          call nka_hip_check(nka_hip_vec_update3(this%ws, this%nper, this%field(k), a, x%field(k), b, y%field(k)), &
-                             'vec_update3')
-        end do
+        call nka_hip_check(nka_hip_vec_update3(this%ws, this%ntot, this%base, a, x%base, b, y%base), 'vec_update3')
       end select
     end select
   end subroutine
@@ -202,15 +188,11 @@ contains
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b, c
     class(vector), intent(in) :: x, y
-    integer :: k
     select type (x)
     class is (hip_block_vector)
       select type (y)
       class is (hip_block_vector)
-        do k = 1, this%nfield
-          call nka_hip_check(nka_hip_vec_update4(this%ws, this%nper, this%field(k), a, x%field(k), b, y%field(k), c), &
-                             'vec_update4')
-        end do
+        call nka_hip_check(nka_hip_vec_update4(this%ws, this%ntot, this%base, a, x%base, b, y%base, c), 'vec_update4')
       end select
     end select
   end subroutine
@@ -218,28 +200,18 @@ contains
   function dot_(x, y) result(val)
     class(hip_block_vector), intent(in) :: x
     class(vector), intent(in) :: y
-    real(r8) :: val, part
-    integer :: k
+    real(r8) :: val
     val = 0.0_r8
     select type (y)
     class is (hip_block_vector)
-      do k = 1, x%nfield
-        call nka_hip_check(nka_hip_vec_dot(x%ws, x%nper, x%field(k), y%field(k), part), 'vec_dot')
-        val = val + part
-      end do
+      call nka_hip_check(nka_hip_vec_dot(x%ws, x%ntot, x%base, y%base, val), 'vec_dot')
     end select
   end function
 
   function norm2_(this) result(val)
     class(hip_block_vector), intent(in) :: this
-    real(r8) :: val, part
-    integer :: k
-    val = 0.0_r8
-    do k = 1, this%nfield
-      call nka_hip_check(nka_hip_vec_dot(this%ws, this%nper, this%field(k), this%field(k), part), 'vec_dot')
-      val = val + part
-    end do
-    val = sqrt(val)
+    real(r8) :: val
+    call nka_hip_check(nka_hip_vec_norm2(this%ws, this%ntot, this%base, val), 'vec_norm2')
   end function
 
 end module hip_block_vector_type

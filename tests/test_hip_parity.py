@@ -353,3 +353,29 @@ def test_rccl_hook_single_rank_and_python_hook(torch_cuda, oracle):
             outs.append(ft.cpu().numpy())
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert set(calls) == {2 + 2 * m}          # ONE exchange per update: the norm and both Gram rows
+
+
+@pytest.mark.parametrize("hook", ["rccl", "torch"])
+def test_bench_multi_gpu_plumbing_rehearsal_single_rank(torch_cuda, hook):
+    """bench.py with the N > 1 plumbing forced on at world size 1 (process group,
+    id broadcast, RCCL communicator or torch all-reduce hook on the library's
+    device buffer), launched the way the driver launches it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(S.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NKA_BENCH_FORCE_HOOK="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--n", "2e6",
+           "--mvec", "6", "--steps", "5", "--no-cpu-baseline", "--allreduce", hook]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["config"]["steady_state"]
+    assert hook in d["config"]["parallelism"]
+    assert d["value"] > 0
