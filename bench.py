@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- NKA accel_update throughput on MI355X (the BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 100000000] [--mvec 20]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--vlen 100000000] [--mvec 20]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is ONE nka accel_update on one synthetic correction vector: the hot
@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=None, help="default mvec+4 (fills the subspace)")
-    ap.add_argument("--n", type=float, default=1e8, help="GLOBAL vector length")
+    # (--n clashes with torchrun's own option abbreviations when given after the script name)
+    ap.add_argument("--vlen", "--n", dest="n", type=float, default=1e8, help="GLOBAL vector length")
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")

@@ -370,7 +370,7 @@ def test_bench_multi_gpu_plumbing_rehearsal_single_rank(torch_cuda, hook):
         port = sk.getsockname()[1]
     env = dict(os.environ, NKA_BENCH_FORCE_HOOK="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--n", "2e6",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--vlen", "2e6",
            "--mvec", "6", "--steps", "5", "--no-cpu-baseline", "--allreduce", hook]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
