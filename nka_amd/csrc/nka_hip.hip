@@ -322,10 +322,21 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = record(a, 1)) return rc;
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
-  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve)
-    hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(kSolveThreads), solve_wave_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
-  else
+  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
+    const size_t sm = solve_wave_smem_bytes(a->mvec);
+    const int ns = solve_pairs_per_lane(a->mvec);
+#define SOLVE(NS) hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, rcp ? 1 : 0)
+    if (ns <= 1) SOLVE(1);
+    else if (ns <= 2) SOLVE(2);
+    else if (ns <= 4) SOLVE(4);
+    else if (ns <= 6) SOLVE(6);
+    else if (ns <= 9) SOLVE(9);
+    else if (ns <= 13) SOLVE(13);
+    else SOLVE(19);
+#undef SOLVE
+  } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
+  }
   HIP_TRY(hipGetLastError());
   if (int rc = record(a, 2)) return rc;
 

@@ -652,69 +652,93 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
 // free-list pushes in list order, new slot, prepend) stays on lane 0.
 // Requires mvec+1 <= kSolveWaveMax; larger subspaces use k_solve.
 constexpr int kSolveWaveMax = 48;
+// pairs (p,q), p > q, of the (mvec+2)-row triangle (list rows + the rhs row) dealt
+// round-robin to the 64 lanes
+__host__ __device__ inline int solve_pairs_per_lane(int mvec) {
+  return ((mvec + 2) * (mvec + 1) / 2 + kSolveThreads - 1) / kSolveThreads;
+}
 
 __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   const int nl = mvec + 1;
   size_t b = (lst_smem_bytes(mvec) + 15) / 16 * 16;
-  b += (size_t)(nl * (nl + 1) + 3 * nl) * sizeof(double);
-  b += (size_t)(2 * nl + 8) * sizeof(int32_t);
+  b += (size_t)((nl + 1) * (nl + 1) + 3 * nl + (2 + 2 * mvec)) * sizeof(double);
+  b += (size_t)(3 * nl) * sizeof(int32_t);
   return b;
 }
 
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve_wave(Ctl ctl, int rcp) {
+// All 64 lanes run the O(m) list bookkeeping REDUNDANTLY on private copies of
+// the scalars (first/last/free/flags) -- LDS reads are uniform-address
+// broadcasts, LDS writes store the same value from every lane -- so the state
+// stays consistent across the wavefront without any broadcast, and nothing on
+// the critical path waits on global memory (red[] and the plan are staged into
+// LDS by one coalesced load each).
+// NS = pairs per lane = ceil((mvec+2)(mvec+1)/2 / 64), a template parameter so
+// the per-column update loop is exactly as long as this mvec needs: a lone
+// wavefront issues ~1 instruction per 4-5 cycles, so instruction COUNT, not
+// latency, sets the run time here (NS = 19 for every mvec took 50 us at m = 20).
+template <int NS>
+__global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int rcp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem);
   const int lane = threadIdx.x;
-  const int NL = ctl.m1(), LDA = NL + 1;
+  const int NL = ctl.m1(), LDA = NL + 1, M = ctl.mvec;
+  // A has NL+1 rows: row nl (one past the list) carries the right-hand side
+  // <f,w_j> through the factorisation, which IS the forward substitution
+  // F08:369-379 (same recurrence, same order) -- it then costs nothing extra.
   double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
-  double *dd = A + NL * LDA;   // running pivots 1 - sum l^2
-  double *Ld = dd + NL;        // accepted pivots sqrt(hkk)
-  double *bb = Ld + NL;        // right-hand side / solution by list position
-  int32_t *ord = reinterpret_cast<int32_t *>(bb + NL);  // list position -> slot
+  double *dd = A + (NL + 1) * LDA;   // running pivots 1 - sum l^2
+  double *Ld = dd + NL;              // accepted pivots sqrt(hkk)
+  double *bb = Ld + NL;              // right-hand side / solution by list position
+  double *redL = bb + NL;            // LDS copy of red[2+2M]
+  int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));  // list position -> slot
   int32_t *alive = ord + NL;
-  int32_t *shi = alive + NL;   // [0] nl, [1] normed, [2] entry_first, [3] nk, [4] subspace
-  const double *red = ctl.red();
-  const int32_t *ps = ctl.plan_slots();
+  int32_t *psL = alive + NL;         // LDS copy of the dot plan (slots PA read)
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const double vtol2 = L.vtol * L.vtol;
-
-  // ---- phase 0 (lane 0): norm, s == 0 -> relax, raw Gram row, linearise the list
-  if (lane == 0) {
-    const int entry_first = L.first;
-    int normed = 0;
-    double s = 0.0;
-    if (L.pending) {
-      s = sqrt(red[0]);                       // F08:267
-      ctl.dc[DC_S] = s;
-      if (s == 0.0) {                         // F08:275
-        lst_relax(L);
-        ctl.ic[IC_NRELAX] += 1;
-      }
-    }
-    if (L.pending) {
-      normed = 1;
-      const double rs = 1.0 / s;
-      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = rcp ? rs * red[2 + p] : red[2 + p] / s;
-      L.c[entry_first] = rcp ? rs * red[1] : red[1] / s;   // <f,w1'> = <f,d>/s
-    }
-    for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
-    int nl = 0;
-    for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;
-    shi[0] = nl;
-    shi[1] = normed;
-    shi[2] = entry_first;
-  }
+  for (int i = lane; i < 2 + 2 * M; i += kSolveThreads) redL[i] = ctl.red()[i];
+  for (int i = lane; i < nolder; i += kSolveThreads) psL[i] = ctl.plan_slots()[i];
   __syncthreads();
-  const int nl = shi[0];
-  const int normed = shi[1];
+
+  // ---- phase 0: norm, s == 0 -> relax, Gram row of w1' = d/s, right-hand side
+  const int entry_first = L.first;
+  int normed = 0;
+  double s = 0.0;
+  if (L.pending) {
+    s = sqrt(redL[0]);                        // F08:267
+    if (s == 0.0) lst_relax(L);               // F08:275
+  }
+  if (L.pending) normed = 1;
+  {
+    const double rs = 1.0 / s;
+    for (int p = lane; p < nolder; p += kSolveThreads) {
+      if (normed) L.H(L.first, psL[p]) = rcp ? rs * redL[2 + p] : redL[2 + p] / s;   // F08:286-290
+      L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
+    }
+    if (normed && lane == 0) L.c[entry_first] = rcp ? rs * redL[1] : redL[1] / s;    // <f,w1'> = <f,d>/s
+  }
+  int nl = 0;
+  for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;
+  __syncthreads();
   int capdrop = -1;
+  bool forward_done = false;
 
   if (normed) {
-    // ---- phase 1: right-looking Cholesky with drops (F08:295-347)
-    for (int idx = lane; idx < nl * nl; idx += kSolveThreads) {
-      const int p = idx / nl, q = idx - p * nl;
-      if (p > q) A[p * LDA + q] = L.H(ord[q], ord[p]);   // raw <w_q, w_p>, q newer than p
+    // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
+    //      plus the right-hand side as row nl.
+    // this lane's share of the strictly-lower pairs (p,q), p in 1..nl, q < p
+    int pp[NS], qq[NS];
+    const int npairs = (nl + 1) * nl / 2;
+#pragma unroll
+    for (int t = 0; t < NS; t++) {
+      const int idx = lane + kSolveThreads * t;
+      int p = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
+      while (p * (p - 1) / 2 > idx) p--;
+      while ((p + 1) * p / 2 <= idx) p++;
+      pp[t] = idx < npairs ? p : 0;
+      qq[t] = idx < npairs ? idx - p * (p - 1) / 2 : 0;
+      if (idx < npairs) A[p * LDA + qq[t]] = (p < nl) ? L.H(ord[qq[t]], ord[p])   // raw <w_q,w_p>, q newer
+                                                       : L.c[ord[qq[t]]];           // rhs <f,w_q>
     }
     for (int p = lane; p < nl; p += kSolveThreads) {
       dd[p] = 1.0;
@@ -736,90 +760,86 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
         if (keep) Lii = sqrt(hkk);
       }
       if (!keep) {
-        if (lane == 0) alive[i] = 0;
+        alive[i] = 0;
         if (capdrop >= 0) break;
         continue;
       }
       kept++;
-      if (lane == 0) Ld[i] = Lii;
-      for (int p = i + 1 + lane; p < nl; p += kSolveThreads) {
-        const double l = A[p * LDA + i] / Lii;   // F08:320
+      Ld[i] = Lii;
+      for (int p = i + 1 + lane; p <= nl; p += kSolveThreads) {
+        const double l = A[p * LDA + i] / Lii;   // F08:320 (row nl: F08:377)
         A[p * LDA + i] = l;
-        dd[p] = dd[p] - l * l;                   // F08:321
+        if (p < nl) dd[p] = dd[p] - l * l;       // F08:321
       }
       __syncthreads();
-      const int r = nl - i - 1;
-      for (int idx = lane; idx < r * r; idx += kSolveThreads) {
-        const int pp = idx / r, qq = idx - pp * r;
-        if (pp > qq) {
-          const int p = i + 1 + pp, q = i + 1 + qq;
-          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];   // F08:317
-        }
+#pragma unroll
+      for (int t = 0; t < NS; t++) {
+        const int p = pp[t], q = qq[t];
+        if (q > i && p > q)                      // trailing entry: F08:317 (row nl: F08:374)
+          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];
       }
       __syncthreads();
     }
     __syncthreads();
-    // ---- phase 2: scatter the factor back by slot; drops in list order on lane 0
-    for (int idx = lane; idx < nl * nl; idx += kSolveThreads) {
-      const int p = idx / nl, q = idx - p * nl;
-      if (alive[p] && alive[q]) {
-        if (p > q) L.H(ord[p], ord[q]) = A[p * LDA + q];
-        else if (p == q) L.H(ord[p], ord[p]) = Ld[p];
+    // ---- phase 2: scatter the factor back by slot, compact the forward-
+    //      substituted right-hand side, replay the drops in list order
+#pragma unroll
+    for (int t = 0; t < NS; t++) {
+      const int p = pp[t], q = qq[t];
+      if (p > q && p < nl && alive[p] && alive[q]) L.H(ord[p], ord[q]) = A[p * LDA + q];
+    }
+    for (int p = lane; p < nl; p += kSolveThreads)
+      if (alive[p]) L.H(ord[p], ord[p]) = Ld[p];
+    {
+      int nk = 0;
+      for (int p = 0; p < nl; p++)
+        if (alive[p]) bb[nk++] = A[nl * LDA + p];
+    }
+    forward_done = true;
+    for (int p = 1; p < nl; p++) {
+      if (alive[p]) continue;
+      const int k = ord[p];
+      if (p == capdrop) {                      // F08:303-307
+        L.next[L.last] = L.free_;
+        L.free_ = k;
+        L.last = L.prev[k];
+        L.next[L.last] = 0;
+      } else {                                 // F08:331-340
+        const int pv = L.prev[k], nx = L.next[k];
+        L.next[pv] = nx;
+        if (nx == 0) L.last = pv; else L.prev[nx] = pv;
+        L.next[k] = L.free_;
+        L.free_ = k;
       }
     }
-    __syncthreads();
-    if (lane == 0) {
-      for (int p = 1; p < nl; p++) {
-        if (alive[p]) continue;
-        const int k = ord[p];
-        if (p == capdrop) {                    // F08:303-307
-          L.next[L.last] = L.free_;
-          L.free_ = k;
-          L.last = L.prev[k];
-          L.next[L.last] = 0;
-        } else {                               // F08:331-340
-          const int pv = L.prev[k], nx = L.next[k];
-          L.next[pv] = nx;
-          if (nx == 0) L.last = pv; else L.prev[nx] = pv;
-          L.next[k] = L.free_;
-          L.free_ = k;
-        }
-      }
-      L.subspace = 1;
-      L.pending = 0;
-    }
+    L.subspace = 1;
+    L.pending = 0;
     __syncthreads();
   }
 
-  // ---- phase 3: new slot, then both substitutions on the current list
-  if (lane == 0) {
-    const int slot = L.free_;                  // F08:357-358
-    L.free_ = L.next[slot];
-    ctl.ic[IC_NEW] = slot;
-    int nk = 0;
-    if (L.subspace)
-      for (int k = L.first; k != 0; k = L.next[k]) {
-        ord[nk] = k;
-        bb[nk] = L.c[k];
-        nk++;
-      }
-    shi[3] = nk;
-    shi[4] = slot;
-  }
+  // ---- phase 3: new slot, then the substitutions on the current list
+  const int slot = L.free_;                    // F08:357-358
+  L.free_ = L.next[slot];
+  int nk = 0;
+  if (L.subspace)
+    for (int k = L.first; k != 0; k = L.next[k]) ord[nk++] = k;
   __syncthreads();
-  const int nk = shi[3];
   if (nk > 0) {
+    if (!forward_done)
+      for (int p = lane; p < nk; p += kSolveThreads) bb[p] = L.c[ord[p]];
     for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
       const int p = idx / nk, q = idx - p * nk;
       if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
     }
     __syncthreads();
-    for (int i = 0; i < nk; i++) {             // forward, F08:369-379
-      const double ci = bb[i] / A[i * LDA + i];
-      __syncthreads();
-      if (lane == 0) bb[i] = ci;
-      for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
-      __syncthreads();
+    if (!forward_done) {
+      for (int i = 0; i < nk; i++) {           // forward, F08:369-379
+        const double ci = bb[i] / A[i * LDA + i];
+        __syncthreads();
+        if (lane == 0) bb[i] = ci;
+        for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
+        __syncthreads();
+      }
     }
     for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
       const double ci = bb[i] / A[i * LDA + i];
@@ -835,10 +855,13 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     }
   }
   __syncthreads();
+  lst_prepend(L, slot);                        // F08:406-417 (every lane, same values)
   if (lane == 0) {
+    ctl.dc[DC_S] = s;
+    if (entry_first != 0 && !normed && ctl.ic[IC_PENDING]) ctl.ic[IC_NRELAX] += 1;
+    ctl.ic[IC_NEW] = slot;
     ctl.ic[IC_NCOMB] = nk;
     ctl.ic[IC_NORMED] = normed;
-    lst_prepend(L, shi[4]);                    // F08:406-417
   }
   lst_store(L, ctl);
 }
