@@ -172,6 +172,16 @@ int nka_hip_vec_update4(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, con
                         double b, const double *y, double c);                                   /* a*x + b*y + c*z */
 int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result); /* dot_ */
 int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *host_result);    /* norm2   */
+/* Batched forms (optional overrides of vector%dot_many / vector%update_many,
+ * nka_amd/fortran/vector/vector_class.F90): ys / xs are HOST arrays of `count`
+ * device pointers.  dot_many: vals[j] = <x, ys[j]> with x read once per 16
+ * vectors.  update_many: z <- (a[j]*xs[j] + b[j]*ys[j]) + z for j = 0..count-1
+ * in order -- the rounding of `count` successive update3_ calls -- with z read
+ * and written once per 16 pairs. */
+int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys,
+                         int32_t count, double *host_vals);
+int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                            const double *const *xs, const double *b, const double *const *ys, int32_t count);
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
 int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 

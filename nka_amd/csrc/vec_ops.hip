@@ -31,6 +31,8 @@ struct nka_hip_vec_ws {
   double *partials = nullptr;  // kMaxGrid
   double *result = nullptr;    // 1 double, device
   double *host_result = nullptr;  // pinned
+  double *results = nullptr;      // kManyMax doubles, device
+  double *host_results = nullptr; // pinned
 };
 
 namespace {
@@ -101,6 +103,78 @@ __global__ __launch_bounds__(kBlock) void k_dot(int64_t n, const double *__restr
   block_reduce_store<1>(acc, partials, G);
 }
 
+// ---- batched hooks: one pass for many dots / many axpys -----------
+constexpr int kManyMax = 16;   // vectors per launch; longer lists run several launches
+struct ManyArgs {
+  const double *x[kManyMax];
+  const double *y[kManyMax];
+  double a[kManyMax], b[kManyMax];
+  int count;
+};
+
+// partials[j*G + block] = partial <x0, x_j>: x0 read ONCE while the others stream past.
+template <int NV, int VEC>
+__global__ __launch_bounds__(kBlock) void k_dot_many(int64_t n, const double *__restrict__ x0, ManyArgs m,
+                                                     double *__restrict__ partials) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) acc[j] = 0.0;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const V xv = ld<VEC>(x0 + e);
+    V yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) yv[j] = ld<VEC>((j < m.count ? m.x[j] : x0) + e);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+#pragma unroll
+      for (int q = 0; q < VEC; q++) acc[j] = fma(ex(xv, q), ex(yv[j], q), acc[j]);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock)
+#pragma unroll
+      for (int j = 0; j < NV; j++) acc[j] = fma(x0[i], (j < m.count ? m.x[j] : x0)[i], acc[j]);
+  block_reduce_store<NV>(acc, partials, G);
+}
+
+// z <- (a_j*x_j + b_j*y_j) + z for j = 0..count-1 IN ORDER (the rounding of
+// count successive update3_ calls, grid_vector_type.F90:151), z read and written once.
+template <int NV, int VEC>
+__global__ __launch_bounds__(kBlock) void k_update_many(int64_t n, double *z, ManyArgs m) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V zv = ld<VEC>(z + e);
+    V xv[NV], yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      xv[j] = ld<VEC>((j < m.count ? m.x[j] : z) + e);
+      yv[j] = ld<VEC>((j < m.count ? m.y[j] : z) + e);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (j < m.count)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) setc(zv, q, (m.a[j] * ex(xv[j], q) + m.b[j] * ex(yv[j], q)) + ex(zv, q));
+    st(z + e, zv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      double zi = z[i];
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+        if (j < m.count) zi = (m.a[j] * m.x[j][i] + m.b[j] * m.y[j][i]) + zi;
+      z[i] = zi;
+    }
+}
+
 int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec) {
   int64_t g = (int64_t)ws->num_cu * 8;
   g = std::min<int64_t>(g, std::max<int64_t>(n / (kBlock * vec), 1));
@@ -143,7 +217,9 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   HIP_TRYV(hipGetDeviceProperties(&prop, device));
   ws->num_cu = prop.multiProcessorCount;
   ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
-  HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid));
+  HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * kManyMax));
+  HIP_TRYV(hipMalloc((void **)&ws->results, sizeof(double) * kManyMax));
+  HIP_TRYV(hipHostMalloc((void **)&ws->host_results, sizeof(double) * kManyMax, hipHostMallocDefault));
   HIP_TRYV(hipMalloc((void **)&ws->result, sizeof(double)));
   HIP_TRYV(hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault));
   *out = ws;
@@ -157,6 +233,8 @@ int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   hipFree(ws->partials);
   hipFree(ws->result);
   hipHostFree(ws->host_result);
+  hipFree(ws->results);
+  hipHostFree(ws->host_results);
   delete ws;
   return 0;
 }
@@ -228,6 +306,65 @@ int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *h
   double d = 0.0;
   if (int rc = nka_hip_vec_dot(ws, n, x, x, &d)) return rc;
   *host_result = std::sqrt(d);  // grid_vector_type.F90:185-197
+  return 0;
+}
+
+// vals[j] = <x, ys[j]>, j < count: x is read once per group of kManyMax vectors.
+int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys, int32_t count,
+                         double *host_vals) {
+  if (!ws || n < 0 || count < 0 || (count > 0 && (!ys || !host_vals))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  for (int j = 0; j < count; j++) host_vals[j] = 0.0;
+  if (n == 0 || count == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  for (int base = 0; base < count; base += kManyMax) {
+    ManyArgs m{};
+    m.count = std::min(kManyMax, count - base);
+    bool v2 = al16(x);
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = ys[base + j];
+      v2 = v2 && al16(m.x[j]);
+    }
+    const int g = grid_for(ws, n, v2 ? 2 : 1);
+    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
+#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_dot_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, m, ws->partials)
+    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
+    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
+#undef LAUNCH
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, m.count, m.count, ws->results);
+    HIP_TRYV(hipGetLastError());
+    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * m.count, hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
+  }
+  return 0;
+}
+
+// z <- (a[j]*xs[j] + b[j]*ys[j]) + z for j = 0..count-1 in order; z is read and
+// written once per group of kManyMax pairs.
+int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                            const double *b, const double *const *ys, int32_t count) {
+  if (!ws || n < 0 || count < 0 || (count > 0 && (!a || !b || !xs || !ys))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if (n == 0 || count == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  for (int base = 0; base < count; base += kManyMax) {
+    ManyArgs m{};
+    m.count = std::min(kManyMax, count - base);
+    bool v2 = al16(z);
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = xs[base + j];
+      m.y[j] = ys[base + j];
+      m.a[j] = a[base + j];
+      m.b[j] = b[base + j];
+      v2 = v2 && al16(m.x[j]) && al16(m.y[j]);
+    }
+    const int g = grid_for(ws, n, v2 ? 2 : 1);
+    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
+#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_update_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
+    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
+#undef LAUNCH
+    HIP_TRYV(hipGetLastError());
+  }
   return 0;
 }
 

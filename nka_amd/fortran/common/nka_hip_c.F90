@@ -169,6 +169,22 @@ module nka_hip_c
       integer(c_int64_t), value :: n
       real(c_double), intent(out) :: res
     end function
+    integer(c_int) function nka_hip_vec_dot_many(ws, n, x, ys, count, vals) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x
+      integer(c_int64_t), value :: n
+      type(c_ptr), intent(in) :: ys(*)            ! host array of device pointers
+      integer(c_int32_t), value :: count
+      real(c_double), intent(out) :: vals(*)
+    end function
+    integer(c_int) function nka_hip_vec_update_many(ws, n, z, a, xs, b, ys, count) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*), b(*)
+      type(c_ptr), intent(in) :: xs(*), ys(*)     ! host arrays of device pointers
+      integer(c_int32_t), value :: count
+    end function
     integer(c_int) function nka_hip_vec_h2d(ws, n, dst_dev, src_host) bind(C)
       import :: c_int, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, dst_dev

@@ -38,6 +38,9 @@ module hip_block_vector_type
     procedure :: update4_
     procedure :: dot_
     procedure :: norm2 => norm2_
+    !! fused overrides of the optional batched hooks (one kernel for many dots / axpys)
+    procedure :: dot_many => dot_many_fused
+    procedure :: update_many => update_many_fused
     !! specific to this type
     procedure :: init
     procedure :: release
@@ -213,5 +216,54 @@ contains
     real(r8) :: val
     call nka_hip_check(nka_hip_vec_norm2(this%ws, this%ntot, this%base, val), 'vec_norm2')
   end function
+
+  !! vals(j) = <this, ys(idx(j))>: `this` is read once while the ys stream past.
+  subroutine dot_many_fused(this, ys, idx, vals)
+    class(hip_block_vector), intent(in) :: this
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals(:)
+    type(c_ptr) :: ptrs(size(idx))
+    integer :: j
+    if (size(idx) == 0) return
+    select type (ys)
+    class is (hip_block_vector)
+      do j = 1, size(idx)
+        ptrs(j) = ys(idx(j))%base
+      end do
+    class default
+      error stop 'incompatible arguments to VECTOR%DOT_MANY'
+    end select
+    call nka_hip_check(nka_hip_vec_dot_many(this%ws, this%ntot, this%base, ptrs, size(idx, kind=c_int32_t), vals), &
+                       'vec_dot_many')
+  end subroutine
+
+  !! this <- (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) + this, j in order: the rounding of
+  !! successive update3_ calls, with `this` read and written once.
+  subroutine update_many_fused(this, a, xs, b, ys, idx)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:), b(:)
+    class(vector), intent(in) :: xs(:), ys(:)
+    integer, intent(in) :: idx(:)
+    type(c_ptr) :: xp(size(idx)), yp(size(idx))
+    integer :: j
+    if (size(idx) == 0) return
+    select type (xs)
+    class is (hip_block_vector)
+      select type (ys)
+      class is (hip_block_vector)
+        do j = 1, size(idx)
+          xp(j) = xs(idx(j))%base
+          yp(j) = ys(idx(j))%base
+        end do
+      class default
+        error stop 'incompatible arguments to VECTOR%UPDATE_MANY'
+      end select
+    class default
+      error stop 'incompatible arguments to VECTOR%UPDATE_MANY'
+    end select
+    call nka_hip_check(nka_hip_vec_update_many(this%ws, this%ntot, this%base, a, xp, b, yp, &
+                                               size(idx, kind=c_int32_t)), 'vec_update_many')
+  end subroutine
 
 end module hip_block_vector_type

@@ -9,6 +9,10 @@
 !! Cholesky matrix live on the host and every O(n) statement is a hook call:
 !!   update(-1,f) ; norm2 ; scale(1/s) x2 ; dot x L        (F08V:237-262)
 !!   copy ; dot x k ; update(-c,w,c,v) x k ; copy          (F08V:336-382)
+!! The L dots, the k dots and the k updates are issued through the optional
+!! batched hooks dot_many / update_many of vector_class, whose default bodies
+!! are exactly those loops -- a user type that does not override them sees the
+!! reference's hook sequence.
 !! With a device-resident concrete vector (hip_block_vector_type) each hook is a
 !! HIP kernel.  The hook sequence, and therefore every rounding of the stored
 !! vectors, is the reference's; the scalar step restates F08V:269-368 (see
@@ -212,8 +216,8 @@ contains
   subroutine accel_update(this, f)
     class(nka), intent(inout) :: this
     class(vector), intent(inout) :: f
-    real(r8) :: s, c(this%mvec+1)
-    integer :: k, slot
+    real(r8) :: s, c(this%mvec+1), vals(this%mvec+1)
+    integer :: k, slot, idx(this%mvec+1), nidx, j
 
     if (this%pending) then
       call this%w(this%first)%update(-1.0_r8, f)             ! w1 <- w1 - f
@@ -224,10 +228,19 @@ contains
     if (this%pending) then
       call this%v(this%first)%scale(1.0_r8/s)
       call this%w(this%first)%scale(1.0_r8/s)
+      !! Gram row <w1,w_k> for every older entry (F08V:260-264), as ONE batched
+      !! hook call: a plain user type gets the default loop of dot() calls in list
+      !! order, a device vector one fused pass.
+      nidx = 0
       k = this%next(this%first)
       do while (k /= 0)
-        this%h(this%first,k) = this%w(this%first)%dot(this%w(k))
+        nidx = nidx + 1
+        idx(nidx) = k
         k = this%next(k)
+      end do
+      call this%w(this%first)%dot_many(this%w, idx(1:nidx), vals(1:nidx))
+      do j = 1, nidx
+        this%h(this%first,idx(j)) = vals(j)
       end do
       call factor_with_drops(this)
     end if
@@ -237,17 +250,23 @@ contains
     call this%w(slot)%copy(f)                                ! keep the raw f for the next call
 
     if (this%subspace) then
+      nidx = 0
       k = this%first
       do while (k /= 0)
-        c(k) = f%dot(this%w(k))
+        nidx = nidx + 1
+        idx(nidx) = k
         k = this%next(k)
+      end do
+      call f%dot_many(this%w, idx(1:nidx), vals(1:nidx))     ! <f,w_j>, F08V:347
+      do j = 1, nidx
+        c(idx(j)) = vals(j)
       end do
       call solve_normal_equations(this, c)
-      k = this%first
-      do while (k /= 0)
-        call f%update(-c(k), this%w(k), c(k), this%v(k))     ! f <- f - c w + c v
-        k = this%next(k)
+      do j = 1, nidx
+        vals(j) = c(idx(j))
       end do
+      !! f <- f - c w + c v for every k in list order (F08V:374), one batched call
+      call f%update_many(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx))
     end if
 
     call this%v(slot)%copy(f)                                ! keep the returned update

@@ -1,0 +1,108 @@
+"""Device implementations of the abstract-vector hooks (nka_amd/csrc/vec_ops.hip)
+through the C ABI: elementwise results BIT-EXACT against the Fortran expressions
+of the reference's grid_vector (src-F08-vector/grid_vector_type.F90:104-165,
+evaluated with numpy: IEEE, left to right, no FMA); reductions within tolerance;
+the batched hooks equal the loops they replace."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ws():
+    import torch
+    import nka_amd
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    L = nka_amd.load()
+    h = C.c_void_p()
+    assert L.nka_hip_vec_workspace_create(C.byref(h), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    yield L, h, torch
+    L.nka_hip_vec_workspace_destroy(h)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n", [1, 2, 511, 512, 513, 100003])
+def test_elementwise_hooks_bit_exact(ws, n):
+    L, h, torch = ws
+    rng = np.random.default_rng(n)
+    x, y, z0 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    a, b, c = 0.7312, -1.25e-3, 3.5
+    xd, yd = _dev(torch, x), _dev(torch, y)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_scale(h, n, P(zd), a) == 0
+    assert np.array_equal(zd.cpu().numpy(), a * z0)
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_update1(h, n, P(zd), a, P(xd)) == 0
+    assert np.array_equal(zd.cpu().numpy(), a * x + z0)
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_update2(h, n, P(zd), a, P(xd), b) == 0
+    assert np.array_equal(zd.cpu().numpy(), a * x + b * z0)
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_update3(h, n, P(zd), a, P(xd), b, P(yd)) == 0
+    assert np.array_equal(zd.cpu().numpy(), (a * x + b * y) + z0)
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_update4(h, n, P(zd), a, P(xd), b, P(yd), c) == 0
+    assert np.array_equal(zd.cpu().numpy(), (a * x + b * y) + c * z0)
+    zd = _dev(torch, z0)
+    assert L.nka_hip_vec_setval(h, n, P(zd), 2.5) == 0
+    assert np.array_equal(zd.cpu().numpy(), np.full(n, 2.5))
+    assert L.nka_hip_vec_copy(h, n, P(zd), P(xd)) == 0
+    assert np.array_equal(zd.cpu().numpy(), x)
+
+    r = C.c_double()
+    assert L.nka_hip_vec_dot(h, n, P(xd), P(yd), C.byref(r)) == 0
+    assert r.value == pytest.approx(float(x @ y), abs=1e-13 * np.linalg.norm(x) * np.linalg.norm(y))
+    assert L.nka_hip_vec_norm2(h, n, P(xd), C.byref(r)) == 0
+    assert r.value == pytest.approx(float(np.linalg.norm(x)), rel=1e-14)
+
+
+@pytest.mark.parametrize("n,count", [(1000, 1), (4099, 5), (100003, 20), (777, 37)])
+def test_batched_hooks_equal_the_loops_they_replace(ws, n, count):
+    L, h, torch = ws
+    rng = np.random.default_rng(n + count)
+    X = rng.standard_normal((count, n))
+    Y = rng.standard_normal((count, n))
+    z0 = rng.standard_normal(n)
+    a, b = rng.standard_normal(count), rng.standard_normal(count)
+    Xd = [_dev(torch, X[j]) for j in range(count)]
+    Yd = [_dev(torch, Y[j]) for j in range(count)]
+    xs = (C.c_void_p * count)(*[t.data_ptr() for t in Xd])
+    ys = (C.c_void_p * count)(*[t.data_ptr() for t in Yd])
+    zd = _dev(torch, z0)
+    dp = C.POINTER(C.c_double)
+
+    # update_many == count successive update3_ calls, bit for bit
+    assert L.nka_hip_vec_update_many(h, n, C.c_void_p(zd.data_ptr()), a.ctypes.data_as(dp), xs,
+                                     b.ctypes.data_as(dp), ys, count) == 0
+    ref = z0.copy()
+    for j in range(count):
+        ref = (a[j] * X[j] + b[j] * Y[j]) + ref
+    assert np.array_equal(zd.cpu().numpy(), ref)
+
+    # dot_many == count dot_ calls within the reduction tolerance
+    vals = np.zeros(count)
+    wd = _dev(torch, z0)
+    assert L.nka_hip_vec_dot_many(h, n, C.c_void_p(wd.data_ptr()), xs, count, vals.ctypes.data_as(dp)) == 0
+    for j in range(count):
+        assert vals[j] == pytest.approx(float(z0 @ X[j]), abs=1e-13 * np.linalg.norm(z0) * np.linalg.norm(X[j]))
+
+
+def test_unaligned_operands_take_the_scalar_path(ws):
+    L, h, torch = ws
+    n = 3001
+    base = torch.arange(2 * n + 2, dtype=torch.float64, device="cuda") * 0.001
+    x = base[1:n + 1]                      # 8-byte aligned only
+    z = base[n + 1:2 * n + 1].clone()
+    z0 = z.cpu().numpy().copy()
+    assert x.data_ptr() % 16 == 8
+    assert L.nka_hip_vec_update1(h, n, C.c_void_p(z.data_ptr()), 2.0, C.c_void_p(x.data_ptr())) == 0
+    assert np.array_equal(z.cpu().numpy(), 2.0 * x.cpu().numpy() + z0)
