@@ -60,7 +60,8 @@ SIGNATURES = {
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "libnka_hip.so")
+    # NKA_HIP_LIB: load another build of the same ABI (kernel tuning experiments)
+    return os.environ.get("NKA_HIP_LIB") or os.path.join(HERE, "libnka_hip.so")
 
 
 def build(force: bool = False) -> str:

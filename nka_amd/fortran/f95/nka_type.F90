@@ -1,0 +1,124 @@
+!! nka_type (Fortran 95 procedural flavour) -- SURVEY.md 8 row f3.
+!!
+!! The reference's original procedural API (src-F95/nka_type.F90:205-207):
+!!   nka_init(this,vlen,mvec)  nka_delete(this)  nka_set_vec_tol(this,vtol)
+!!   nka_accel_update(this,f)  nka_relax(this)   nka_restart(this)
+!!   nka_num_vec  nka_max_vec  nka_vec_len  nka_vec_tol  nka_real_kind  nka_defined
+!! as thin wrappers over the C ABI of libnka_hip.so (module nka_hip_c).  The type
+!! is a handle; every vector and the scalar step live on the GPU.
+!!
+!! The reference's optional per-call dummy procedure DP (src-F95/nka_type.F90:
+!! 284-291) is a host dot product and cannot see device memory; the device
+!! equivalent is installed once with nka_set_allreduce (see the array flavour).
+!! nka_accel_update_dev takes device memory (type(c_ptr)).
+
+module nka_type
+
+  use, intrinsic :: iso_c_binding
+  use nka_hip_c
+  implicit none
+  private
+
+  integer, parameter :: r8 = selected_real_kind(15)
+
+  type, public :: nka
+    private
+    type(c_ptr) :: handle = c_null_ptr
+  end type nka
+
+  public :: nka_init, nka_delete, nka_set_vec_tol, nka_defined
+  public :: nka_vec_len, nka_num_vec, nka_max_vec, nka_vec_tol, nka_real_kind
+  public :: nka_accel_update, nka_accel_update_dev, nka_relax, nka_restart, nka_set_allreduce
+
+contains
+
+  subroutine nka_init(this, vlen, mvec)                       ! src-F95 :211-225
+    type(nka), intent(inout) :: this
+    integer, intent(in) :: vlen, mvec
+    call nka_delete(this)
+    call nka_hip_check(nka_hip_create(this%handle, int(vlen, c_int64_t), int(mvec, c_int32_t), 0.01_c_double, &
+                                      NKA_HIP_FLAVOR_F08, 0_c_int32_t, c_null_ptr), 'nka_init')
+  end subroutine
+
+  subroutine nka_delete(this)                                 ! :266-275
+    type(nka), intent(inout) :: this
+    integer(c_int) :: rc
+    if (c_associated(this%handle)) rc = nka_hip_destroy(this%handle)
+    this%handle = c_null_ptr
+  end subroutine
+
+  subroutine nka_set_vec_tol(this, vtol)                      ! :227-232
+    type(nka), intent(inout) :: this
+    real(r8), intent(in) :: vtol
+    call nka_hip_check(nka_hip_set_vec_tol(this%handle, vtol), 'nka_set_vec_tol')
+  end subroutine
+
+  subroutine nka_set_allreduce(this, fn, ctx)
+    type(nka), intent(inout) :: this
+    type(c_funptr), intent(in) :: fn
+    type(c_ptr), intent(in) :: ctx
+    call nka_hip_check(nka_hip_set_allreduce(this%handle, fn, ctx), 'nka_set_allreduce')
+  end subroutine
+
+  subroutine nka_accel_update(this, f)                        ! :278-473 (host array)
+    type(nka), intent(inout) :: this
+    real(r8), intent(inout) :: f(:)
+    real(r8), allocatable :: tmp(:)
+    if (size(f) /= nka_vec_len(this)) stop 'nka_accel_update: size(f) /= nka_vec_len(this)'
+    if (is_contiguous(f)) then
+      call nka_hip_check(nka_hip_accel_update_host(this%handle, f), 'nka_accel_update')
+    else
+      tmp = f
+      call nka_hip_check(nka_hip_accel_update_host(this%handle, tmp), 'nka_accel_update')
+      f = tmp
+    end if
+  end subroutine
+
+  subroutine nka_accel_update_dev(this, f_dev)
+    type(nka), intent(inout) :: this
+    type(c_ptr), intent(in) :: f_dev
+    call nka_hip_check(nka_hip_accel_update(this%handle, f_dev), 'nka_accel_update_dev')
+  end subroutine
+
+  subroutine nka_relax(this)                                  ! :494-512
+    type(nka), intent(inout) :: this
+    call nka_hip_check(nka_hip_relax(this%handle), 'nka_relax')
+  end subroutine
+
+  subroutine nka_restart(this)                                ! :476-491
+    type(nka), intent(inout) :: this
+    call nka_hip_check(nka_hip_restart(this%handle), 'nka_restart')
+  end subroutine
+
+  integer function nka_num_vec(this)
+    type(nka), intent(in) :: this
+    nka_num_vec = nka_hip_num_vec(this%handle)
+  end function
+
+  integer function nka_max_vec(this)
+    type(nka), intent(in) :: this
+    nka_max_vec = nka_hip_max_vec(this%handle)
+  end function
+
+  integer function nka_vec_len(this)
+    type(nka), intent(in) :: this
+    nka_vec_len = int(nka_hip_vec_len(this%handle))
+  end function
+
+  real(r8) function nka_vec_tol(this)
+    type(nka), intent(in) :: this
+    nka_vec_tol = nka_hip_vec_tol(this%handle)
+  end function
+
+  integer function nka_real_kind(this)                        ! :261-264
+    type(nka), intent(in) :: this
+    nka_real_kind = r8
+  end function
+
+  logical function nka_defined(this)
+    type(nka), intent(in) :: this
+    nka_defined = .false.
+    if (c_associated(this%handle)) nka_defined = (nka_hip_defined(this%handle) == 1)
+  end function
+
+end module nka_type

@@ -75,3 +75,36 @@ def test_abstract_vector_bench_mode_runs(fortran_build):
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "updates/s" in p.stdout
+
+
+def _lcg_scenario_oracle(oracle, flavor, vtol=0.05):
+    n, m = 501, 4
+    X = oracle.lcg_vectors(12, n, seed=1)
+    acc = oracle.OracleNKA(n, m, flavor)
+    acc.set_vec_tol(vtol)
+    rows = []
+    for t in range(1, 13):
+        f = X[t - 1].copy()
+        acc.accel_update(f)
+        if t == 6:
+            acc.relax()
+        if t == 9:
+            acc.restart()
+        rows.append((t, acc.num_vec(), float(np.sum(f)), float(np.sqrt(np.sum(f * f)))))
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,flavor_name", [("nka_f95_driver", "F08"), ("nka_c_driver", "C_FLAVOR")])
+def test_f95_wrappers_and_c_compat_header_on_gpu(fortran_build, oracle, exe, flavor_name):
+    """Rows f2/f3: the reference's C API names (include/nka_c_compat.h) and its F95
+    procedural API (nka_amd/fortran/f95) over the same HIP library."""
+    p = subprocess.run([os.path.join(fortran_build, exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    want = _lcg_scenario_oracle(oracle, getattr(oracle, flavor_name))
+    got = [ln.split() for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert (int(g[0]), int(g[1])) == (w[0], w[1])
+        assert float(g[2]) == pytest.approx(w[2], abs=1e-11)
+        assert float(g[3]) == pytest.approx(w[3], rel=1e-12)
