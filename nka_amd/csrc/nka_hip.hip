@@ -6,7 +6,7 @@
 //   PA k_dots -> k_finalize_dots -> [all-reduce 2+2*mvec] -> k_solve -> PB k_combine
 // on one HIP stream and returns; nothing is read back.  The host only tracks what
 // it can know without looking: whether a pair is pending, and an upper bound on
-// the list length (used to pick the unroll width of P2/P3).
+// the list length (used to pick the unroll width of PA/PB).
 #include "../../include/nka_hip.h"
 #include "nka_kernels.hpp"
 

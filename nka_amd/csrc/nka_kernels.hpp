@@ -59,7 +59,7 @@ enum {
   IC_FREE = 4,
   IC_NEW = 5,          // slot that receives (f_in, f_out) in the current update
   IC_NCOMB = 6,        // number of (slot, coefficient) pairs in the combine plan
-  IC_PLAN_PENDING = 7, // plan for P1/P2 of the NEXT update: `pending` at its entry
+  IC_PLAN_PENDING = 7, // plan for PA of the NEXT update: `pending` at its entry
   IC_PLAN_FIRST = 8,   //   slot holding the pending pair
   IC_PLAN_NOLDER = 9,  //   number of list entries to dot against
   IC_NRELAX = 10,      // count of s == 0 events (diagnostic)
@@ -562,7 +562,7 @@ __device__ inline void lst_store(Lst &L, const Ctl &ctl) {
     ctl.ic[IC_FIRST] = L.first;
     ctl.ic[IC_LAST] = L.last;
     ctl.ic[IC_FREE] = L.free_;
-    // plan for the next update's P1/P2
+    // plan for the next update's PA
     ctl.ic[IC_PLAN_PENDING] = L.pending;
     ctl.ic[IC_PLAN_FIRST] = L.first;
     int n = 0;

@@ -3,9 +3,9 @@
 The reference's parallel contract (src-F08/nka_type.F90:58-64): every rank calls
 the same sequence collectively on ITS slice of the vectors and supplies a global
 dot product.  Here the slice is contiguous, the per-rank partial dot products
-stay on the GPU, and the only exchange is the SUM of those partials: 1 double
-after P1 and 1+2*mvec doubles (both Gram rows merged) after P2, by RCCL over xGMI
-on the accelerator's own stream.  H, c and the lists are replicated; they stay
+stay on the GPU, and the only exchange is the SUM of those partials: ONE
+all-reduce of 2+2*mvec doubles per update (the norm and both Gram rows, after the
+pure-read pass PA), by RCCL over xGMI on the accelerator's own stream.  H, c and the lists are replicated; they stay
 bitwise identical because every rank receives the same all-reduced bits.
 """
 from __future__ import annotations

@@ -237,7 +237,7 @@ def test_medium_case_against_f08_reference_fixture(torch_cuda):
 @pytest.mark.parametrize("n,m", [(0, 2), (1, 1), (7, 8), (1000, 1), (777, 40), (2048, 33), (5000, 64)])
 def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m):
     """Empty and tiny vectors, mvec = 1, and mvec beyond one unrolled pass (the
-    P2/P3 kernels then run several passes of 32)."""
+    PA/PB kernels then run several passes of 32)."""
     rng = np.random.default_rng(n * 131 + m)
     acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
     ncall = min(m + 4, 45)

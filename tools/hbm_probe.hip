@@ -68,8 +68,52 @@ __global__ __launch_bounds__(256) void k_stream(const double *base, double *wbas
   if (S > 0 && acc == 12345.678) out[0] = acc;  // keep the loads alive
 }
 
+// Burst variant: each block reads B tiles of S streams, THEN writes B tiles of W streams.
+template <int S, int W, int B, int NTS>
+__global__ __launch_bounds__(256) void k_burst(const double *base, double *wbase, size_t stride, size_t n, double *out) {
+  const size_t ngroup = n / 512 / B;
+  double acc = 0.0;
+  for (size_t g = blockIdx.x; g < ngroup; g += gridDim.x) {
+    double2 sum = {0.0, 0.0};
+    for (int q = 0; q < B; q++) {
+      double2 v[S];
+#pragma unroll
+      for (int s = 0; s < S; s++) v[s] = ld2<true>(base + s * stride + (g * B + q) * 512 + threadIdx.x * 2);
+#pragma unroll
+      for (int s = 0; s < S; s++) { sum.x += v[s].x; sum.y += v[s].y; }
+    }
+    acc += sum.x + sum.y;
+    for (int q = 0; q < B; q++)
+#pragma unroll
+      for (int w = 0; w < W; w++) st2<NTS>(wbase + w * stride + (g * B + q) * 512 + threadIdx.x * 2, sum);
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int S, int W, int B, int NTS>
+void runb(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 3;
+  hipLaunchKernelGGL((k_burst<S, W, B, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_burst<S, W, B, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+}
+
 template <int S, int W, int T, bool NTL, int NTS, int MAP>
 void run(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -91,25 +135,24 @@ void run(const char *name, const double *base, double *wbase, size_t stride, siz
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? (size_t)atof(argv[1]) : 100000000;
   const size_t stride = ((n + 31) / 32) * 32 + (argc > 2 ? atoi(argv[2]) / 8 : 0);
-  const int NS = 42;
+  const int NS = 42, NW = 6;   // slots allocated for reads / writes; every variant is checked against these
   double *rd, *wr, *out;
   CK(hipMalloc(&rd, stride * 8 * NS));
-  CK(hipMalloc(&wr, stride * 8 * 3));
+  CK(hipMalloc(&wr, stride * 8 * NW));
   CK(hipMalloc(&out, 64));
   CK(hipMemset(rd, 0, stride * 8 * NS));
-  CK(hipMemset(wr, 0, stride * 8 * 3));
+  CK(hipMemset(wr, 0, stride * 8 * NW));
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int cu = prop.multiProcessorCount;
   printf("device %s, %d CUs, n=%zu, slot stride %zu B\n", prop.gcnArchName, cu, n, stride * 8);
 #define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
-  for (int g : {cu * 2, cu * 4, cu * 8}) {
-    R(8, 0, 1, true, 0, 0, g);  R(8, 1, 1, true, 0, 0, g);  R(8, 1, 1, true, 4, 0, g); R(8, 1, 1, false, 0, 0, g);
-    R(8, 2, 1, true, 4, 0, g);
-    R(4, 1, 1, true, 4, 0, g);  R(4, 1, 2, true, 4, 0, g);
-    R(16, 0, 1, true, 0, 0, g); R(16, 1, 1, true, 0, 0, g); R(16, 1, 1, true, 4, 0, g);
-    R(16, 3, 1, true, 4, 0, g);
-    R(12, 0, 1, true, 0, 0, g); R(12, 3, 1, true, 4, 0, g); R(12, 3, 1, true, 0, 0, g);
+#define RB(S, W, B, NTS, G) runb<S, W, B, NTS>("burst S=" #S " W=" #W " B=" #B " st=" #NTS, rd, wr, stride, n, out, G)
+  for (int g : {cu * 1, cu * 2, cu * 4}) {
+    R(22, 5, 1, true, 1, 0, g);
+    RB(22, 5, 1, 1, g); RB(22, 5, 4, 1, g); RB(22, 5, 16, 1, g); RB(22, 5, 64, 1, g); RB(22, 5, 256, 1, g);
+    RB(22, 5, 64, 0, g);
+    R(22, 0, 1, true, 0, 0, g);
   }
   return 0;
 }
