@@ -143,7 +143,7 @@ int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32
 int nka_hip_set_timing(nka_hip_t a, int32_t capacity);
 int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 
-/* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = keep). */
+/* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */
 int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
 const char *nka_hip_last_error(void);

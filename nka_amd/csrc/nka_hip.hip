@@ -72,7 +72,7 @@ struct nka_hip_state {
   int list_ub = 0;            // upper bound on the list length
   // launch geometry
   int num_cu = 256;
-  int bpc[2] = {2, 2};        // blocks per CU of PA, PB (caps; the grid also respects occupancy)
+  int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   // distribution hook
@@ -98,9 +98,15 @@ int occupancy_of(K kernel) {
   return nb;
 }
 
-int grid_for(const nka_hip_state *a, int which, int vec, int occ) {
+// `nloads` = 16-byte loads each thread keeps in flight per tile.  Measured on
+// MI355X (n = 1.25e7 and 1e8, m = 20): ONE block per CU is fastest once a block
+// has >= 22 loads per thread in flight (88 KiB per CU); more blocks per CU only
+// add write/read interleaving in the mixed pass (PB 0.46 -> 0.52 ms at 4 per CU).
+// Narrow instantiations get proportionally more blocks to keep ~88 KiB in flight.
+int grid_for(const nka_hip_state *a, int which, int vec, int occ, int nloads) {
   const int64_t ntile = a->n / (kBlock * vec);
-  int64_t g = (int64_t)a->num_cu * std::min(occ, a->bpc[which]);
+  const int want = a->bpc[which] > 0 ? a->bpc[which] : std::max(1, (22 + nloads - 1) / nloads);
+  int64_t g = (int64_t)a->num_cu * std::min(occ, want);
   g = std::min<int64_t>(g, std::max<int64_t>(ntile, 1));
   g = std::min<int64_t>(g, kMaxGrid);
   return (int)std::max<int64_t>(g, 1);
@@ -117,7 +123,7 @@ int rccl_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
 template <int MAXL, int VEC>
 int launch_dots_1(const nka_hip_state *a, const double *f, int pass) {
   static const int occ = occupancy_of(k_dots<MAXL, VEC>);
-  const int g = grid_for(a, 0, VEC, occ);
+  const int g = grid_for(a, 0, VEC, occ, MAXL + 2);
   hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
                      a->partials, g, pass);
@@ -137,7 +143,7 @@ int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
 template <int MAXK, int VEC, int COMB>
 int launch_combine_1(const nka_hip_state *a, double *f, int pass, int last) {
   static const int occ = occupancy_of(k_combine<MAXK, VEC, COMB>);
-  const int g = grid_for(a, 1, VEC, occ);
+  const int g = grid_for(a, 1, VEC, occ, (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1));
   hipLaunchKernelGGL((k_combine<MAXK, VEC, COMB>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, pass, last);
   return g;
 }
@@ -570,7 +576,7 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   const int32_t v[2] = {pa, pb};
   for (int i = 0; i < 2; i++) {
     if (v[i] < 0 || v[i] * a->num_cu > kMaxGrid) return fail(NKA_HIP_EINVAL, "blocks per CU out of range");
-    if (v[i] > 0) a->bpc[i] = v[i];
+    a->bpc[i] = v[i];   // 0 = automatic
   }
   return 0;
 }
