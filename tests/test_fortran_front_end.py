@@ -70,6 +70,14 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
 
 
 @pytest.mark.gpu
+def test_fortran_array_bench_runs(fortran_build):
+    p = subprocess.run([os.path.join(fortran_build, "nka_bench"), "2000000", "6", "5", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "updates/s" in p.stdout
+
+
+@pytest.mark.gpu
 def test_abstract_vector_bench_mode_runs(fortran_build):
     p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "bench", "4", "100000", "5", "5"],
                        capture_output=True, text=True, timeout=300)
@@ -108,3 +116,39 @@ def test_f95_wrappers_and_c_compat_header_on_gpu(fortran_build, oracle, exe, fla
         assert (int(g[0]), int(g[1])) == (w[0], w[1])
         assert float(g[2]) == pytest.approx(w[2], abs=1e-11)
         assert float(g[3]) == pytest.approx(w[3], rel=1e-12)
+
+
+# ---------------------------------------------------------------------------
+# Drop-in: the reference's OWN callers compiled unchanged against our modules
+# (oracle/Makefile target `dropin`; built only where /root/reference exists, the
+# executables travel to the GPU box with oracle/_ref/).
+# ---------------------------------------------------------------------------
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+CASES = [([], "f08"), (["--nka-vec", "5"], "f08 --nka-vec 5"), (["--sweeps", "4", "--nka-vec", "5"], "f08 --sweeps 4 --nka-vec 5")]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin_example_f08vec")), reason="drop-in build absent")
+@pytest.mark.parametrize("args,key", CASES)
+def test_reference_vector_caller_and_user_vector_type_against_our_modules(tmp_path, args, key):
+    """Reference src-F08-vector/{grid_vector_type,nka_example}.F90 -- a user type
+    that extends `vector`, and its caller -- linked with OUR vector_class and
+    vector-flavour nka_type: the plugin interface is intact and the three
+    reference_output tables come out digit for digit.  (The user's hooks are CPU
+    code, so this runs anywhere.)"""
+    p = subprocess.run([os.path.join(REFDIR, "dropin_example_f08vec")] + args, cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.splitlines() == _tables()[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin_example_f08")), reason="drop-in build absent")
+@pytest.mark.parametrize("args,key", CASES[1:])
+def test_reference_array_caller_against_our_module_on_gpu(tmp_path, args, key):
+    """Reference src-F08/nka_example.F90, unchanged, with OUR module nka_type in
+    place of the reference's: every accel_update runs on the MI355X and the
+    printed tables equal the compiled reference's."""
+    p = subprocess.run([os.path.join(REFDIR, "dropin_example_f08")] + args, cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.splitlines() == _tables()[key]
