@@ -227,7 +227,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   alloc((void **)&a->vs.w, slot_bytes);
   alloc((void **)&a->ctl.ic, sizeof(int32_t) * a->ctl.ic_count());
   alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
-  alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 1));
+  alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 2));  // NACC columns of k_dots
   if (rc) {
     nka_hip_destroy(a);
     return rc;

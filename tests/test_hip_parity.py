@@ -379,3 +379,34 @@ def test_bench_multi_gpu_plumbing_rehearsal_single_rank(torch_cuda, hook):
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["config"]["steady_state"]
     assert hook in d["config"]["parallelism"]
     assert d["value"] > 0
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_input_takes_the_same_decisions_as_the_oracle(torch_cuda, oracle, bad):
+    """A NaN / Inf in f: the reference has no guard (s == 0 is false for NaN,
+    hkk > vtol**2 is false for NaN -> the entry is dropped); the device takes the
+    same branches, and restart() recovers a clean object."""
+    n, m = 257, 3
+    rng = np.random.default_rng(17)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    for t in range(7):
+        x = rng.standard_normal(n)
+        if t == 3:
+            x[5] = bad
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        out = ft.cpu().numpy()
+        assert acc.num_vec() == ora.num_vec(), t
+        assert acc.state().list_order() == ora.state().list_order(), t
+        assert np.array_equal(np.isnan(out), np.isnan(f)), t
+    acc.restart(); ora.restart()
+    for t in range(4):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert acc.num_vec() == ora.num_vec()
+        assert S.rel_err(ft.cpu().numpy(), f, x) <= TOL_SMALL
