@@ -45,6 +45,30 @@ int fail(int code, const std::string &msg) {
 namespace nka_detail {
 // shared with vec_ops.hip: one thread-local error string per library
 int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
+// A kernel reading past a caller's buffer faults the GPU (and can take the node
+// with it), so every device pointer that crosses the ABI is checked on the host
+// against the allocation it lies in before any launch: it must be device
+// memory and hold at least n doubles from p on.  NKA_HIP_CHECK_POINTERS=0
+// switches the check off.
+int check_device_span(const void *p, int64_t n, const char *what) {
+  static const bool on = [] {
+    const char *e = getenv("NKA_HIP_CHECK_POINTERS");
+    return !(e && e[0] == '0');
+  }();
+  if (!on || n <= 0) return 0;
+  if (!p) return fail(NKA_HIP_EINVAL, std::string(what) + ": NULL device pointer");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(NKA_HIP_EINVAL, std::string(what) + ": not a device allocation");
+  }
+  const char *lo = static_cast<const char *>(p), *end = static_cast<const char *>(base) + size;
+  if (lo < static_cast<const char *>(base) || lo + (size_t)n * sizeof(double) > end)
+    return fail(NKA_HIP_EINVAL, std::string(what) + ": device buffer shorter than the vector length");
+  return 0;
+}
 }  // namespace nka_detail
 
 namespace {
@@ -304,6 +328,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
+  if (int rc = nka_detail::check_device_span(f, a->n, "accel_update: f")) return rc;   // F08:258 size(f) == vlen
   hipStream_t s = a->stream;
   const bool aligned = (reinterpret_cast<uintptr_t>(f) % 16) == 0;
   const int vec = aligned ? 2 : 1;

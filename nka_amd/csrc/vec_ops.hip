@@ -22,6 +22,7 @@ using namespace nka;
 extern "C" const char *nka_hip_last_error(void);
 namespace nka_detail {
 int set_error(int code, const std::string &msg);
+int check_device_span(const void *p, int64_t n, const char *what);
 }
 
 struct nka_hip_vec_ws {
@@ -190,6 +191,9 @@ int run_elementwise(nka_hip_vec_ws *ws, int64_t n, double *z, const double *x, c
   if (n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "negative length");
   if (n == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(z, n, "vector hook: z")) return rc;
+  if (OP >= 2) if (int rc = nka_detail::check_device_span(x, n, "vector hook: x")) return rc;
+  if (OP >= 4) if (int rc = nka_detail::check_device_span(y, n, "vector hook: y")) return rc;
   const bool v2 = al16(z) && (OP < 2 || al16(x)) && (OP < 4 || al16(y));
   const int g = grid_for(ws, n, v2 ? 2 : 1);
   if (v2)
@@ -258,6 +262,8 @@ int nka_hip_vec_copy(nka_hip_vec_ws_t ws, int64_t n, double *dst, const double *
   if (!ws || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   if (n == 0 || dst == src) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(dst, n, "vec_copy: dst")) return rc;
+  if (int rc = nka_detail::check_device_span(src, n, "vec_copy: src")) return rc;
   HIP_TRYV(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ws->stream));
   return 0;
 }
@@ -288,6 +294,8 @@ int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const doubl
   *host_result = 0.0;
   if (n == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(x, n, "vec_dot: x")) return rc;
+  if (int rc = nka_detail::check_device_span(y, n, "vec_dot: y")) return rc;
   const bool v2 = al16(x) && al16(y);
   const int g = grid_for(ws, n, v2 ? 2 : 1);
   if (v2)
@@ -316,6 +324,9 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
   for (int j = 0; j < count; j++) host_vals[j] = 0.0;
   if (n == 0 || count == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(x, n, "vec_dot_many: x")) return rc;
+  for (int j = 0; j < count; j++)
+    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_many: ys[j]")) return rc;
   for (int base = 0; base < count; base += kManyMax) {
     ManyArgs m{};
     m.count = std::min(kManyMax, count - base);
@@ -346,6 +357,11 @@ int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const dou
   if (!ws || n < 0 || count < 0 || (count > 0 && (!a || !b || !xs || !ys))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   if (n == 0 || count == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(z, n, "vec_update_many: z")) return rc;
+  for (int j = 0; j < count; j++) {
+    if (int rc = nka_detail::check_device_span(xs[j], n, "vec_update_many: xs[j]")) return rc;
+    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_update_many: ys[j]")) return rc;
+  }
   for (int base = 0; base < count; base += kManyMax) {
     ManyArgs m{};
     m.count = std::min(kManyMax, count - base);

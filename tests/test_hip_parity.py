@@ -312,6 +312,16 @@ def test_api_surface_defaults_and_errors(torch_cuda):
     assert a.num_vec() == 0 and a.state().first == 0 and a.defined()
     with pytest.raises(nka_amd.NKAError):
         a.accel_update(torch_cuda.zeros(11, dtype=torch_cuda.float64, device="cuda"))   # size(f) == vlen (F08:258)
+    # the C ABI itself refuses a buffer that is too short or not device memory (no kernel is launched)
+    import ctypes as C
+    L = nka_amd.load()
+    short = torch_cuda.zeros(4, dtype=torch_cuda.float64, device="cuda")
+    big = nka_amd.nka().init(1 << 22, 2)
+    assert L.nka_hip_accel_update(big._handle(), C.c_void_p(short.data_ptr())) == -1
+    assert b"shorter" in L.nka_hip_last_error()
+    host = np.zeros(1 << 22)
+    assert L.nka_hip_accel_update(big._handle(), C.c_void_p(host.ctypes.data)) == -1
+    assert big.num_vec() == 0 and big.defined()
     a.init(10, 3)                                     # re-init resets vtol (intent(out), F08:186)
     assert a.vec_tol() == 0.01
 
