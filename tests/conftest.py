@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are git-ignored; a fresh checkout builds them once
+    (hipcc cross-compiles gfx950 without a GPU; ~15 s)."""
+    import nka_amd
+    if not os.path.exists(nka_amd.lib_path()):
+        nka_amd.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement (checker).  Built on demand with gcc."""
