@@ -234,12 +234,13 @@ def test_medium_case_against_f08_reference_fixture(torch_cuda):
         assert abs(float(out @ probe) - g["out_probe"][t]) <= TOL_SMALL * fin_norm * np.linalg.norm(probe)
 
 
+@pytest.mark.parametrize("flavor", [0, 1, 2])
 @pytest.mark.parametrize("n,m", [(0, 2), (1, 1), (7, 8), (1000, 1), (777, 40), (2048, 33), (5000, 64)])
-def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m):
+def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m, flavor):
     """Empty and tiny vectors, mvec = 1, and mvec beyond one unrolled pass (the
     PA/PB kernels then run several passes of 32)."""
     rng = np.random.default_rng(n * 131 + m)
-    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    acc, ora = make_acc(n, m, flavor), oracle.OracleNKA(n, m, flavor)
     ncall = min(m + 4, 45)
     basis = rng.standard_normal((3, n))
     for t in range(ncall):
