@@ -180,6 +180,11 @@ int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *h
  * and written once per 16 pairs. */
 int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys,
                          int32_t count, double *host_vals);
+/* Both rows of the Gram update in one pass: vals0[j] = <x0, ys[j]>,
+ * vals1[j] = <x1, ys[j]>, *cross = <x0, x1> (override of vector%dot_pair_many). */
+int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
+                              const double *const *ys, int32_t count, double *host_vals0,
+                              double *host_vals1, double *host_cross);
 int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                             const double *const *xs, const double *b, const double *const *ys, int32_t count);
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "nka_hip_vec_dot": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _dp]),
     "nka_hip_vec_norm2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp]),
     "nka_hip_vec_dot_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, _dp]),
+    "nka_hip_vec_dot_pair_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                            C.c_int32, _dp, _dp, _dp]),
     "nka_hip_vec_update_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                           C.POINTER(C.c_void_p), C.c_int32]),
     "nka_hip_vec_h2d": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

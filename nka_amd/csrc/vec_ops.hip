@@ -142,6 +142,48 @@ __global__ __launch_bounds__(kBlock) void k_dot_many(int64_t n, const double *__
   block_reduce_store<NV>(acc, partials, G);
 }
 
+// Two rows at once: partials[j] = <x0, x_j>, partials[NV+j] = <x1, x_j>, and
+// partials[2NV] = <x0, x1>; x0, x1 and every x_j are read ONCE.
+template <int NV, int VEC>
+__global__ __launch_bounds__(kBlock) void k_dot_pair_many(int64_t n, const double *__restrict__ x0,
+                                                          const double *__restrict__ x1, ManyArgs m,
+                                                          double *__restrict__ partials) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  double acc[2 * NV + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * NV + 1; j++) acc[j] = 0.0;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const V av = ld<VEC>(x0 + e), bv = ld<VEC>(x1 + e);
+    V yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) yv[j] = ld<VEC>((j < m.count ? m.x[j] : x0) + e);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      acc[2 * NV] = fma(ex(av, q), ex(bv, q), acc[2 * NV]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        acc[j] = fma(ex(av, q), ex(yv[j], q), acc[j]);
+        acc[NV + j] = fma(ex(bv, q), ex(yv[j], q), acc[NV + j]);
+      }
+    }
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      acc[2 * NV] = fma(x0[i], x1[i], acc[2 * NV]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const double y = (j < m.count ? m.x[j] : x0)[i];
+        acc[j] = fma(x0[i], y, acc[j]);
+        acc[NV + j] = fma(x1[i], y, acc[NV + j]);
+      }
+    }
+  block_reduce_store<2 * NV + 1>(acc, partials, G);
+}
+
 // z <- (a_j*x_j + b_j*y_j) + z for j = 0..count-1 IN ORDER (the rounding of
 // count successive update3_ calls, grid_vector_type.F90:151), z read and written once.
 template <int NV, int VEC>
@@ -221,9 +263,9 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   HIP_TRYV(hipGetDeviceProperties(&prop, device));
   ws->num_cu = prop.multiProcessorCount;
   ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
-  HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * kManyMax));
-  HIP_TRYV(hipMalloc((void **)&ws->results, sizeof(double) * kManyMax));
-  HIP_TRYV(hipHostMalloc((void **)&ws->host_results, sizeof(double) * kManyMax, hipHostMallocDefault));
+  HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1)));
+  HIP_TRYV(hipMalloc((void **)&ws->results, sizeof(double) * (2 * kManyMax + 1)));
+  HIP_TRYV(hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault));
   HIP_TRYV(hipMalloc((void **)&ws->result, sizeof(double)));
   HIP_TRYV(hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault));
   *out = ws;
@@ -347,6 +389,50 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
   }
+  return 0;
+}
+
+// vals0[j] = <x0, ys[j]>, vals1[j] = <x1, ys[j]>, *cross = <x0, x1>: both rows of
+// the Gram update in ONE pass over the stored vectors.
+int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
+                              const double *const *ys, int32_t count, double *host_vals0, double *host_vals1,
+                              double *host_cross) {
+  if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals0 || !host_vals1)))
+    return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  *host_cross = 0.0;
+  for (int j = 0; j < count; j++) host_vals0[j] = host_vals1[j] = 0.0;
+  if (n == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(x0, n, "vec_dot_pair_many: x0")) return rc;
+  if (int rc = nka_detail::check_device_span(x1, n, "vec_dot_pair_many: x1")) return rc;
+  for (int j = 0; j < count; j++)
+    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_pair_many: ys[j]")) return rc;
+  int base = 0;
+  do {  // at least one launch so that <x0,x1> is computed even when count == 0
+    ManyArgs m{};
+    m.count = std::min(kManyMax, count - base);
+    bool v2 = al16(x0) && al16(x1);
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = ys[base + j];
+      v2 = v2 && al16(m.x[j]);
+    }
+    const int g = grid_for(ws, n, v2 ? 2 : 1);
+    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
+#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_dot_pair_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, x0, x1, m, ws->partials)
+    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
+    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
+#undef LAUNCH
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->results);
+    HIP_TRYV(hipGetLastError());
+    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * (2 * nv + 1), hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    for (int j = 0; j < m.count; j++) {
+      host_vals0[base + j] = ws->host_results[j];
+      host_vals1[base + j] = ws->host_results[nv + j];
+    }
+    if (base == 0) *host_cross = ws->host_results[2 * nv];
+    base += kManyMax;
+  } while (base < count);
   return 0;
 }
 

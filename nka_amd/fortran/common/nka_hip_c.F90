@@ -177,6 +177,14 @@ module nka_hip_c
       integer(c_int32_t), value :: count
       real(c_double), intent(out) :: vals(*)
     end function
+    integer(c_int) function nka_hip_vec_dot_pair_many(ws, n, x0, x1, ys, count, vals0, vals1, cross) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, x0, x1
+      integer(c_int64_t), value :: n
+      type(c_ptr), intent(in) :: ys(*)
+      integer(c_int32_t), value :: count
+      real(c_double), intent(out) :: vals0(*), vals1(*), cross
+    end function
     integer(c_int) function nka_hip_vec_update_many(ws, n, z, a, xs, b, ys, count) bind(C)
       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, z

@@ -40,6 +40,7 @@ module hip_block_vector_type
     procedure :: norm2 => norm2_
     !! fused overrides of the optional batched hooks (one kernel for many dots / axpys)
     procedure :: dot_many => dot_many_fused
+    procedure :: dot_pair_many => dot_pair_many_fused
     procedure :: update_many => update_many_fused
     !! specific to this type
     procedure :: init
@@ -236,6 +237,31 @@ contains
     end select
     call nka_hip_check(nka_hip_vec_dot_many(this%ws, this%ntot, this%base, ptrs, size(idx, kind=c_int32_t), vals), &
                        'vec_dot_many')
+  end subroutine
+
+  subroutine dot_pair_many_fused(this, other, ys, idx, vals_this, vals_other, cross)
+    class(hip_block_vector), intent(in) :: this
+    class(vector), intent(in) :: other
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_other(:), cross
+    type(c_ptr) :: ptrs(max(size(idx),1))
+    integer :: j
+    select type (other)
+    class is (hip_block_vector)
+      select type (ys)
+      class is (hip_block_vector)
+        do j = 1, size(idx)
+          ptrs(j) = ys(idx(j))%base
+        end do
+        call nka_hip_check(nka_hip_vec_dot_pair_many(this%ws, this%ntot, this%base, other%base, ptrs, &
+                           size(idx, kind=c_int32_t), vals_this, vals_other, cross), 'vec_dot_pair_many')
+      class default
+        error stop 'incompatible arguments to VECTOR%DOT_PAIR_MANY'
+      end select
+    class default
+      error stop 'incompatible arguments to VECTOR%DOT_PAIR_MANY'
+    end select
   end subroutine
 
   !! this <- (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) + this, j in order: the rounding of

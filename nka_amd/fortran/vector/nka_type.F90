@@ -9,10 +9,10 @@
 !! Cholesky matrix live on the host and every O(n) statement is a hook call:
 !!   update(-1,f) ; norm2 ; scale(1/s) x2 ; dot x L        (F08V:237-262)
 !!   copy ; dot x k ; update(-c,w,c,v) x k ; copy          (F08V:336-382)
-!! The L dots, the k dots and the k updates are issued through the optional
-!! batched hooks dot_many / update_many of vector_class, whose default bodies
-!! are exactly those loops -- a user type that does not override them sees the
-!! reference's hook sequence.
+!! The L + k + 1 dots and the k updates are issued through the optional batched
+!! hooks dot_pair_many / dot_many / update_many of vector_class, whose default
+!! bodies are exactly those loops of dot() / update() calls -- a user type that
+!! does not override them sees only the reference's deferred hooks.
 !! With a device-resident concrete vector (hip_block_vector_type) each hook is a
 !! HIP kernel.  The hook sequence, and therefore every rounding of the stored
 !! vectors, is the reference's; the scalar step restates F08V:269-368 (see
@@ -216,9 +216,11 @@ contains
   subroutine accel_update(this, f)
     class(nka), intent(inout) :: this
     class(vector), intent(inout) :: f
-    real(r8) :: s, c(this%mvec+1), vals(this%mvec+1)
+    real(r8) :: s, c(this%mvec+1), vals(this%mvec+1), bvals(this%mvec+1), cross
     integer :: k, slot, idx(this%mvec+1), nidx, j
+    logical :: have_rows
 
+    have_rows = .false.
     if (this%pending) then
       call this%w(this%first)%update(-1.0_r8, f)             ! w1 <- w1 - f
       s = this%w(this%first)%norm2()
@@ -228,9 +230,11 @@ contains
     if (this%pending) then
       call this%v(this%first)%scale(1.0_r8/s)
       call this%w(this%first)%scale(1.0_r8/s)
-      !! Gram row <w1,w_k> for every older entry (F08V:260-264), as ONE batched
-      !! hook call: a plain user type gets the default loop of dot() calls in list
-      !! order, a device vector one fused pass.
+      !! Both inner-product rows of this update in ONE batched hook call: the Gram
+      !! row <w1,w_k> (F08V:260-264) and the projection row <f,w_k> (F08V:347) for
+      !! every older entry, plus <f,w1>.  f is not modified in between, so the
+      !! values equal the reference's; rows of entries the factorisation then drops
+      !! are simply not used.  A plain user type gets the default loops of dot().
       nidx = 0
       k = this%next(this%first)
       do while (k /= 0)
@@ -238,10 +242,13 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
-      call this%w(this%first)%dot_many(this%w, idx(1:nidx), vals(1:nidx))
+      call this%w(this%first)%dot_pair_many(f, this%w, idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
+      c(this%first) = cross
       do j = 1, nidx
         this%h(this%first,idx(j)) = vals(j)
+        c(idx(j)) = bvals(j)
       end do
+      have_rows = .true.
       call factor_with_drops(this)
     end if
 
@@ -257,10 +264,12 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
-      call f%dot_many(this%w, idx(1:nidx), vals(1:nidx))     ! <f,w_j>, F08V:347
-      do j = 1, nidx
-        c(idx(j)) = vals(j)
-      end do
+      if (.not. have_rows) then                              ! after relax(): no new pair this call
+        call f%dot_many(this%w, idx(1:nidx), vals(1:nidx))   ! <f,w_j>, F08V:347
+        do j = 1, nidx
+          c(idx(j)) = vals(j)
+        end do
+      end if
       call solve_normal_equations(this, c)
       do j = 1, nidx
         vals(j) = c(idx(j))

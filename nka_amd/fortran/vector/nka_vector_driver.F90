@@ -134,8 +134,8 @@ contains
     write(*,'(a,i0,a,i0,a,i0)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
     !! bytes the hooks move per update: hook by hook 8n(12+8m); with the batched
-    !! dot_many/update_many of hip_block_vector 8n(16+4m); contract figure 8n(11+3m)
-    write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, batched hooks (8n(16+4m)) ', 8.0_r8*n*(16+4*mvec)/per/1e9_r8, &
+    !! hooks of hip_block_vector 8n(16+3m); contract figure 8n(11+3m)
+    write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, batched hooks (8n(16+3m)) ', 8.0_r8*n*(16+3*mvec)/per/1e9_r8, &
                                  '   algorithmic GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
     write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by algorithmic bytes ', &
                         8.0_r8*n*(11+3*mvec)/per/8.0e12_r8

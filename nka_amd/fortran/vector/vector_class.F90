@@ -13,6 +13,8 @@
 !! Additions (SURVEY.md 8 f1), NOT deferred, so existing user types keep
 !! compiling: dot_many and update_many have default bodies that loop over the
 !! deferred hooks; a device vector may override them with fused kernels.
+!! dot_pair_many computes BOTH inner-product rows an update needs (the new
+!! difference against the stored w's, and f against them) in one pass.
 
 module vector_class
 
@@ -41,6 +43,7 @@ module vector_class
     procedure(dot_if), deferred :: dot_
     !! optional batched forms (overridable, default = loops over the hooks)
     procedure :: dot_many
+    procedure :: dot_pair_many
     procedure :: update_many
   end type
 
@@ -198,6 +201,19 @@ contains
     do j = 1, size(idx)
       vals(j) = this%dot(ys(idx(j)))
     end do
+  end subroutine
+
+  !! Two rows against the same vectors: vals_this(j) = <this, ys(idx(j))>,
+  !! vals_other(j) = <other, ys(idx(j))>, cross = <other, this>.  Default: the
+  !! individual dot() calls.
+  subroutine dot_pair_many(this, other, ys, idx, vals_this, vals_other, cross)
+    class(vector), intent(in) :: this, other
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_other(:), cross
+    call this%dot_many(ys, idx, vals_this)
+    cross = other%dot(this)
+    call other%dot_many(ys, idx, vals_other)
   end subroutine
 
   !! this <- this + sum_j ( a(j)*xs(idx(j)) + b(j)*ys(idx(j)) ), applied in order j = 1..size(idx).

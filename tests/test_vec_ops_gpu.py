@@ -95,6 +95,16 @@ def test_batched_hooks_equal_the_loops_they_replace(ws, n, count):
     for j in range(count):
         assert vals[j] == pytest.approx(float(z0 @ X[j]), abs=1e-13 * np.linalg.norm(z0) * np.linalg.norm(X[j]))
 
+    # dot_pair_many: both rows and the cross term in one pass
+    v0, v1, cross = np.zeros(count), np.zeros(count), C.c_double()
+    ud = _dev(torch, Y[0])
+    assert L.nka_hip_vec_dot_pair_many(h, n, C.c_void_p(wd.data_ptr()), C.c_void_p(ud.data_ptr()), xs, count,
+                                       v0.ctypes.data_as(dp), v1.ctypes.data_as(dp), C.byref(cross)) == 0
+    assert cross.value == pytest.approx(float(z0 @ Y[0]), abs=1e-13 * np.linalg.norm(z0) * np.linalg.norm(Y[0]))
+    for j in range(count):
+        assert v0[j] == pytest.approx(float(z0 @ X[j]), abs=1e-13 * np.linalg.norm(z0) * np.linalg.norm(X[j]))
+        assert v1[j] == pytest.approx(float(Y[0] @ X[j]), abs=1e-13 * np.linalg.norm(Y[0]) * np.linalg.norm(X[j]))
+
 
 def test_unaligned_operands_take_the_scalar_path(ws):
     L, h, torch = ws
