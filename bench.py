@@ -272,6 +272,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(out), flush=True)
 
+    # tear down in a fixed order on every rank: the library's RCCL communicator first,
+    # then torch's process group
+    del pool, pool_store
+    acc.delete()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
