@@ -20,6 +20,9 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  launch actually moves (PB is the dominant kernel)
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
                  oracle port timed on this box's host on a bounded sample.
+  also_f08_rounding : the same workload and protocol measured a second time in
+                 the same run with the src-F08 rounding (the headline `value` is
+                 the src-C rounding with compact storage).
 """
 from __future__ import annotations
 
@@ -124,23 +127,30 @@ def main():
     prime = max(0, (m + 2) - W)
     W_all = prime + W
 
-    flavor = {"f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR, "c": nka_amd.FLAVOR_C}[args.flavor]
-    acc = nka_amd.nka().init(n_local, m, flavor=flavor)
-    hook = "none"
-    if world > 1 or os.environ.get("NKA_BENCH_FORCE_HOOK") == "1":
-        if not dist.is_initialized():          # single-process rehearsal of the N > 1 plumbing
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        hook = args.allreduce
-        if hook == "rccl":
-            try:
-                nd.attach_rccl(acc, rank, world)
-            except Exception as exc:   # collective failure: every rank lands here together
-                print(f"[bench] RCCL communicator failed ({exc!r}); using the torch.distributed hook", file=sys.stderr)
-                hook = "torch"
-        if hook == "torch":
-            nd.attach_torch_allreduce(acc)
+    FLAVORS = {"f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR, "c": nka_amd.FLAVOR_C}
+    hook_box = ["none"]
+
+    def make_acc(flavor_name):
+        acc = nka_amd.nka().init(n_local, m, flavor=FLAVORS[flavor_name])
+        if world > 1 or os.environ.get("NKA_BENCH_FORCE_HOOK") == "1":
+            if not dist.is_initialized():          # single-process rehearsal of the N > 1 plumbing
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29511")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            hook = args.allreduce if hook_box[0] == "none" else hook_box[0]
+            if hook == "rccl":
+                try:
+                    nd.attach_rccl(acc, rank, world)
+                except Exception as exc:   # collective failure: every rank lands here together
+                    print(f"[bench] RCCL communicator failed ({exc!r}); using the torch.distributed hook",
+                          file=sys.stderr)
+                    hook = "torch"
+            if hook == "torch":
+                nd.attach_torch_allreduce(acc)
+            hook_box[0] = hook
+        return acc
+
+    acc = make_acc(args.flavor)
 
     # ---- inputs: resident in HBM before the timed region ----------------------
     free_b, _ = torch.cuda.mem_get_info(dev)
@@ -149,13 +159,10 @@ def main():
     n_pad = n_local + (n_local % 2)            # keep every row 16-byte aligned
     pool_store = torch.empty((P, max(n_pad, 2)), dtype=torch.float64, device=dev)
     pool = [pool_store[j, :n_local] for j in range(P)]
+    refill_in_timed_region = (W_all + K) > P
 
     def fill(j, t):
         synth.fill_torch(pool[j], SEED, t, lo, n_global)
-
-    for t in range(min(P, W_all + K)):
-        fill(t, t)
-    refill_in_timed_region = (W_all + K) > P
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -163,13 +170,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # ---- warm-up (fills the subspace: num_vec == mvec from call mvec+1 on) ----
-    for t in range(W_all):
-        if t >= P:
-            fill(t % P, t)
-        acc.accel_update(pool[t % P])
-    sync_all()
-    nv = acc.num_vec()
+    def measure(acc):
+        """W_all untimed calls (priming + warm-up), then EXACTLY K timed updates
+        bracketed by barrier + synchronize; returns wall time (max over ranks),
+        mean per-phase device times (HIP events on the kernel stream), num_vec."""
+        for t in range(min(P, W_all + K)):     # inputs (re)generated outside the timed region
+            fill(t, t)
+        for t in range(W_all):
+            if t >= P:
+                fill(t % P, t)
+            acc.accel_update(pool[t % P])
+        sync_all()
+        nv0 = acc.num_vec()
+        acc.set_timing(min(K, 4096))
+        sync_all()
+        t0 = time.perf_counter()
+        for s in range(K):
+            t = W_all + s
+            if t >= P:
+                fill(t % P, t)       # only when HBM cannot hold W+K inputs (reported below)
+            acc.accel_update(pool[t % P])
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        nrec = min(K, 4096)
+        ph = [acc.timing_ms(b) for b in range(nrec)]
+        mean = [sum(p[i] for p in ph) / nrec for i in range(4)]
+        return elapsed, mean, nv0, acc.num_vec()
+
+    elapsed, mean, nv, nv_end = measure(acc)
     steady = (nv == m)
 
     # device-copy ceiling measured in the same run
@@ -190,27 +222,19 @@ def main():
     else:
         copy_gbps = None
 
-    # ---- timed region: EXACTLY K updates ------------------------------------
-    acc.set_timing(min(K, 4096))
-    sync_all()
-    t0 = time.perf_counter()
-    for s in range(K):
-        t = W_all + s
-        if t >= P:
-            fill(t % P, t)           # only when HBM cannot hold W+K inputs (reported below)
-        acc.accel_update(pool[t % P])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # per-phase device times of the timed updates (HIP events on the kernel stream)
-    nrec = min(K, 4096)
-    ph = [acc.timing_ms(b) for b in range(nrec)]
-    mean = [sum(p[i] for p in ph) / nrec for i in range(4)]
-    nv_end = acc.num_vec()
+    # Secondary figure in the same run: the src-F08 rounding (two stored vectors
+    # per pair, bit-faithful to F08:397), same workload, same protocol.
+    also = None
+    if args.flavor == "c" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+        acc.delete()
+        acc = make_acc("f08")
+        e2, mean2, nv2, nv2_end = measure(acc)
+        also = {"flavor": "src-F08 rounding (f - c*w) + c*v, two stored vectors per pair",
+                "value": K / e2, "unit": "updates/s", "ms_per_step": 1e3 * e2 / K,
+                "steady_state": bool(nv2 == m and nv2_end == m),
+                "roofline_frac": 8.0 * n_local * (11 + 3 * m) / (mean2[3] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_of_bytes_moved": 8.0 * n_local * (8 + 3 * m) / (mean2[3] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "kernels_mean_ms": {"PA_k_dots": mean2[0], "k_solve": mean2[1], "PB_k_combine": mean2[2]}}
 
     if rank == 0:
         L = k = m
@@ -249,7 +273,7 @@ def main():
                        "flavor": {"c": "src-C rounding f += c*(v-w), compact storage",
                                   "f08": "src-F08 rounding (f - c*w) + c*v",
                                   "f08vec": "src-F08-vector rounding"}[args.flavor],
-                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook}",
+                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}",
                        "steady_state": bool(steady and nv_end == m), "prime_steps": prime,
                        "inputs_resident": not refill_in_timed_region},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -263,6 +287,8 @@ def main():
                          "copy_ceiling_GBps": copy_gbps},
             "aggregate_algorithmic_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
         }
+        if also is not None:
+            out["also_f08_rounding"] = also
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(m, int(args.cpu_n))
