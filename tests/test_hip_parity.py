@@ -421,3 +421,36 @@ def test_non_finite_input_takes_the_same_decisions_as_the_oracle(torch_cuda, ora
         acc.accel_update(ft)
         assert acc.num_vec() == ora.num_vec()
         assert S.rel_err(ft.cpu().numpy(), f, x) <= TOL_SMALL
+
+
+@pytest.mark.skipif(not __import__("oracle.oracle_py", fromlist=["x"]).have_ref(),
+                    reason="compiled reference (oracle/_ref) did not travel to this box")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_against_the_live_compiled_reference(torch_cuda, oracle, seed):
+    """The reference's own src-F08 module (compiled from /root/reference into
+    oracle/_ref and shipped with the repo) and the HIP path, side by side, on
+    fresh random streams with dependent vectors, relax and restart mixed in."""
+    n, m = 20011, 8
+    rng = np.random.default_rng(seed)
+    ref = oracle.RefF08(n, m)
+    acc = make_acc(n, m, 0)
+    basis = rng.standard_normal((4, n))
+    worst = 0.0
+    for t in range(40):
+        x = rng.standard_normal(4) @ basis if t % 6 == 4 else rng.standard_normal(n)
+        if t == 11:
+            x = prev.copy()                      # repeated input -> s == 0 -> relax inside the update
+        prev = x
+        f = x.copy()
+        ref.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert acc.num_vec() == ref.num_vec(), (seed, t)
+        err = S.rel_err(ft.cpu().numpy(), f, x)
+        assert err <= cond_tol(acc.state()), (seed, t, err)
+        worst = max(worst, err)
+        if t == 20:
+            ref.relax(); acc.relax()
+        if t == 30:
+            ref.restart(); acc.restart()
+    assert ref.defined() and acc.defined()
