@@ -1,0 +1,81 @@
+"""Worker of tests/test_hip_parity.py::test_sharded_hip_path_two_ranks_one_gpu.
+
+Two ranks share cuda:0 (the boxes available to the tests have one GPU).  Each
+rank runs the PRODUCT path -- libnka_hip.so through nka_amd.nka -- on its
+contiguous slice; the distribution hook (nka_hip_set_allreduce, the device-side
+set_dot_prod) sums the partial inner products of the two ranks through
+torch.distributed/gloo, staging the 2+2*mvec doubles through the host.  RCCL
+refuses two ranks on one device, so the built-in RCCL hook is exercised
+single-rank elsewhere; everything else of the N > 1 path is what runs here."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import nka_amd  # noqa: E402
+from nka_amd import dist as nd  # noqa: E402
+from nka_amd import synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+
+class _Alias:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    n, m, calls = 200003, 6, 16
+    lo, hi = nd.slice_bounds(n, world, rank)
+    counts = []
+
+    def hook(ptr, count, stream):
+        dev = torch.as_tensor(_Alias(ptr, count), device="cuda")
+        host = dev.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        dev.copy_(host)
+        counts.append(count)
+
+    for flavor in (nka_amd.FLAVOR_F08, nka_amd.FLAVOR_C):
+        acc = nka_amd.nka().init(hi - lo, m, flavor=flavor)
+        acc.set_dot_prod(hook)
+        full = O.OracleNKA(n, m, flavor)
+        basis = np.stack([synth.fill_numpy(3, 50 + j, 0, n, n) for j in range(3)])
+        for t in range(calls):
+            x = (synth.fill_numpy(5, t, 0, 3, 3) @ basis) if t % 5 == 3 else synth.fill_numpy(12345, t, 0, n, n)
+            f_full = x.copy()
+            full.accel_update(f_full)
+            ft = torch.from_numpy(x[lo:hi].copy()).cuda()
+            acc.accel_update(ft)
+            out = ft.cpu().numpy()
+            assert acc.num_vec() == full.num_vec(), (rank, flavor, t)
+            st = acc.state()
+            assert st.list_order() == full.state().list_order(), (rank, flavor, t)
+            # replicated scalars: bitwise identical on both ranks
+            c = torch.from_numpy(st.c.copy())
+            cmax, cmin = c.clone(), c.clone()
+            dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+            assert torch.equal(cmax, cmin), (rank, flavor, t)
+            piv = min([abs(st.h[k - 1, k - 1]) for k in st.list_order()[1:]] + [1.0])
+            err = np.linalg.norm(out - f_full[lo:hi]) / np.linalg.norm(x)
+            assert err <= 1e-12 / piv**2, (rank, flavor, t, err)
+            if t == 9:
+                acc.relax(); full.relax()
+        assert acc.defined()
+        acc.delete()
+    assert set(counts) == {2 + 2 * m}
+    print(f"rank {rank}/{world} slice [{lo},{hi}) OK", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

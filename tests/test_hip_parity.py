@@ -454,3 +454,23 @@ def test_against_the_live_compiled_reference(torch_cuda, oracle, seed):
         if t == 30:
             ref.restart(); acc.restart()
     assert ref.defined() and acc.defined()
+
+
+def test_sharded_hip_path_two_ranks_one_gpu(torch_cuda):
+    """Row (e) on real hardware: two ranks (sharing the one GPU of the test box)
+    run the HIP path on contiguous slices with the all-reduce hook; decisions,
+    replicated scalars and the returned slices are checked against the
+    unsharded oracle (tests/_sharded_gpu_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(S.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_sharded_gpu_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-5000:]
+    assert p.stdout.count(" OK") == 2
