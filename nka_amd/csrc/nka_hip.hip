@@ -214,14 +214,14 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   if (device < 0 || device >= ndev) return fail(NKA_HIP_EINVAL, "nka_hip_create: no such HIP device");
   HIP_TRY(hipSetDevice(device));
 
-  auto *a = new nka_hip_state();
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  auto *a = new nka_hip_state();   // from here on every failure path goes through nka_hip_destroy(a)
   a->device = device;
   a->n = vlen_local;
   a->mvec = mvec;
   a->vtol = vtol;
   a->flavor = flavor;
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
   a->num_cu = prop.multiProcessorCount;
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
