@@ -244,10 +244,17 @@ def main():
         words = {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + 5}
         b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # SURVEY.md 8(d), per update, per GPU
         upd_s = mean[3] * 1e-3
+        # Attribution of the contract's algorithmic words 11+L+2k (P1 2, P2 5+L, P3 4+2k)
+        # to the two launches of this schedule: PA does P1 and the reading/dot part of P2
+        # (2 + 2+L); PB does P3 plus P2's normalisation traffic (v1 read, w1'/v1' writes: 4+2k + 3).
+        alg_words = {"PA_k_dots": 4 + L, "PB_k_combine": 7 + 2 * k}
         kernels = {}
         for (name, w), ms in zip(words.items(), (mean[0], mean[2])):
             kernels[name] = {"bytes_moved": 8.0 * n_local * w, "mean_ms": ms,
-                             "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None}
+                             "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                             "algorithmic_bytes": 8.0 * n_local * alg_words[name],
+                             "algorithmic_GBps": (8.0 * n_local * alg_words[name] / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                             "frac": (8.0 * n_local * alg_words[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms > 0 else None}
         kernels["k_solve"] = {"mean_ms": mean[1]}
         achieved = b_alg / upd_s / 1e9 if upd_s > 0 else 0.0
         # HBM bytes per update from the rocprofv3 PMC passes of THIS workload (tools/rocprof_bench.sh +
