@@ -90,6 +90,62 @@ __global__ __launch_bounds__(256) void k_burst(const double *base, double *wbase
   if (acc == 12345.678) out[0] = acc;
 }
 
+// Software-pipelined variant: the stores of tile t are issued AFTER the loads of
+// tile t+1, so no load ever waits (vmcnt is in issue order) behind a store's ack.
+template <int S, int W, int NTS>
+__global__ __launch_bounds__(256) void k_pipe(const double *base, double *wbase, size_t stride, size_t n, double *out) {
+  const size_t ntile = n / 512;
+  double acc = 0.0;
+  size_t t = blockIdx.x;
+  if (t >= ntile) return;
+  double2 v[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) v[s] = ld2<true>(base + s * stride + t * 512 + threadIdx.x * 2);
+  double2 sum = {0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < S; s++) { sum.x += v[s].x; sum.y += v[s].y; }
+  for (;;) {
+    const size_t tn = t + gridDim.x;
+    const bool more = tn < ntile;
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < S; s++) v[s] = ld2<true>(base + s * stride + tn * 512 + threadIdx.x * 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < W; w++) st2<NTS>(wbase + w * stride + t * 512 + threadIdx.x * 2, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    acc += sum.x + sum.y;
+    if (!more) break;
+    sum.x = 0.0; sum.y = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; s++) { sum.x += v[s].x; sum.y += v[s].y; }
+    t = tn;
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int S, int W, int NTS>
+void runp(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 3;
+  hipLaunchKernelGGL((k_pipe<S, W, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_pipe<S, W, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+}
+
 template <int S, int W, int B, int NTS>
 void runb(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
   static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
@@ -148,10 +204,11 @@ int main(int argc, char **argv) {
   printf("device %s, %d CUs, n=%zu, slot stride %zu B\n", prop.gcnArchName, cu, n, stride * 8);
 #define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
 #define RB(S, W, B, NTS, G) runb<S, W, B, NTS>("burst S=" #S " W=" #W " B=" #B " st=" #NTS, rd, wr, stride, n, out, G)
-  for (int g : {cu * 1, cu * 2, cu * 4}) {
-    R(22, 5, 1, true, 1, 0, g);
-    RB(22, 5, 1, 1, g); RB(22, 5, 4, 1, g); RB(22, 5, 16, 1, g); RB(22, 5, 64, 1, g); RB(22, 5, 256, 1, g);
-    RB(22, 5, 64, 0, g);
+#define RP(S, W, NTS, G) runp<S, W, NTS>("pipelined S=" #S " W=" #W " st=" #NTS, rd, wr, stride, n, out, G)
+  for (int rep = 0; rep < 2; rep++)
+  for (int g : {cu * 1, cu * 2}) {
+    R(22, 5, 1, true, 1, 0, g);  RP(22, 5, 1, g); RP(22, 5, 0, g);
+    R(41, 5, 1, true, 1, 0, g);  RP(41, 5, 1, g);
     R(22, 0, 1, true, 0, 0, g);
   }
   return 0;
