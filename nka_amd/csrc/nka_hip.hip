@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -185,6 +187,35 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
 
 int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
 
+// Optional ROCTx ranges around the phases of an update (NKA_HIP_ROCTX=1), for
+// rocprofv3 --marker-trace timelines.  The library is looked up at run time so
+// that libnka_hip.so has no hard dependency on the profiler SDK.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = getenv("NKA_HIP_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+      }
+    }
+    push = nullptr;
+    pop = nullptr;
+  }
+};
+const Roctx &roctx() {
+  static const Roctx r;
+  return r;
+}
+struct RoctxRange {
+  explicit RoctxRange(const char *name) { if (roctx().push) roctx().push(name); }
+  ~RoctxRange() { if (roctx().pop) roctx().pop(); }
+};
+
 constexpr int kTimingEvents = 4;
 
 int record(nka_hip_state *a, int i) {
@@ -339,6 +370,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   // ---- PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371) ----
   // Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
   if (a->pending || older_ub > 0) {
+    RoctxRange range("nka:PA dots + all-reduce");
     const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
     const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
     for (int p = 0; p < npass; p++) {
@@ -353,6 +385,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = record(a, 1)) return rc;
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
+  RoctxRange range_tail("nka:solve + PB combine");
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int ns = solve_pairs_per_lane(a->mvec);
