@@ -101,6 +101,8 @@ struct nka_hip_state {
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
+  bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
+                              // reference built without -DNDEBUG (F08:257); synchronises
   // distribution hook
   nka_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_ctx = nullptr;
@@ -256,6 +258,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->num_cu = prop.multiProcessorCount;
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
+  a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
@@ -360,6 +363,8 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
   if (int rc = nka_detail::check_device_span(f, a->n, "accel_update: f")) return rc;   // F08:258 size(f) == vlen
+  if (a->debug && nka_hip_defined(a) != 1)                                                // F08:257 ASSERT(defined(this))
+    return fail(NKA_HIP_ESTATE, "accel_update: the device state fails the defined() invariants");
   hipStream_t s = a->stream;
   const bool aligned = (reinterpret_cast<uintptr_t>(f) % 16) == 0;
   const int vec = aligned ? 2 : 1;

@@ -474,3 +474,19 @@ def test_sharded_hip_path_two_ranks_one_gpu(torch_cuda):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-5000:]
     assert p.stdout.count(" OK") == 2
+
+
+def test_debug_mode_checks_invariants_every_update(torch_cuda, oracle, monkeypatch):
+    """NKA_HIP_DEBUG=1 is the counterpart of the reference's non-NDEBUG build
+    (ASSERT(defined(this)) on entry of accel_update, F08:257)."""
+    monkeypatch.setenv("NKA_HIP_DEBUG", "1")
+    n, m = 1000, 3
+    rng = np.random.default_rng(4)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    for t in range(8):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert S.rel_err(ft.cpu().numpy(), f, x) <= TOL_SMALL
