@@ -65,6 +65,10 @@ enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C =
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
 
+/* Rebind the handle to another hipStream_t (NULL = default stream).  Work already
+ * enqueued on the old stream is ordered before anything enqueued on the new one. */
+int nka_hip_set_stream(nka_hip_t a, void *stream);
+
 /* Replaces nka_delete (C .h:5, .c:261-282) / automatic deallocation (F08). */
 int nka_hip_destroy(nka_hip_t a);
 

@@ -308,6 +308,21 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   return 0;
 }
 
+int nka_hip_set_stream(nka_hip_t a, void *stream) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  hipStream_t ns = (hipStream_t)stream;
+  if (ns == a->stream) return 0;
+  HIP_TRY(hipSetDevice(a->device));
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e1 = hipEventRecord(ev, a->stream);
+  hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(ns, ev, 0) : e1;
+  hipEventDestroy(ev);
+  if (e2 != hipSuccess) return fail(NKA_HIP_EHIP, std::string("set_stream: ") + hipGetErrorString(e2));
+  a->stream = ns;
+  return 0;
+}
+
 int nka_hip_destroy(nka_hip_t a) {
   if (!a) return 0;
   hipSetDevice(a->device);

@@ -72,12 +72,14 @@ class nka:  # noqa: N801  (the reference's type name)
             raise NKAError("no HIP device visible: nka_amd has no CPU path")
         if device is None:
             device = torch.cuda.current_device()
+        explicit_stream = stream
         if stream is None:
             stream = torch.cuda.current_stream(device).cuda_stream
         h = C.c_void_p()
         _check(self._L.nka_hip_create(C.byref(h), int(vlen), int(mvec), 0.01, int(flavor), int(device),
                                       C.c_void_p(stream)), "nka_hip_create")
         self._h, self._device, self._vlen, self._mvec = h, device, int(vlen), int(mvec)
+        self._stream, self._follow_torch_stream = int(stream), explicit_stream is None
         return self
 
     def delete(self):
@@ -152,8 +154,17 @@ class nka:  # noqa: N801  (the reference's type name)
             raise NKAError("accel_update: need a contiguous float64 CUDA tensor of vec_len() elements")
         if f.device.index != self._device:
             raise NKAError("accel_update: tensor lives on another device than the accelerator")
+        if self._follow_torch_stream:      # stay on torch's CURRENT stream (e.g. inside `with torch.cuda.stream(s)`)
+            cur = int(torch.cuda.current_stream(self._device).cuda_stream)
+            if cur != self._stream:
+                self.set_stream(cur)
         _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update")
         return f
+
+    def set_stream(self, stream: int):
+        """Rebind to another hipStream_t; earlier work stays ordered before later work."""
+        _check(self._L.nka_hip_set_stream(self._handle(), C.c_void_p(int(stream))), "set_stream")
+        self._stream = int(stream)
 
     # -- call a%restart() / a%relax()                 F08:422-457
     def restart(self):

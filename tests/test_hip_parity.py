@@ -490,3 +490,28 @@ def test_debug_mode_checks_invariants_every_update(torch_cuda, oracle, monkeypat
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
         assert S.rel_err(ft.cpu().numpy(), f, x) <= TOL_SMALL
+
+
+def test_follows_the_current_torch_stream(torch_cuda, oracle):
+    """Updates issued under `with torch.cuda.stream(side)` run on that stream and
+    stay ordered with the updates issued before and after on the default stream."""
+    torch = torch_cuda
+    n, m = 50021, 4
+    rng = np.random.default_rng(8)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    side = torch.cuda.Stream()
+    for t in range(10):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        if t % 3 == 1:
+            with torch.cuda.stream(side):
+                ft = torch.from_numpy(x.copy()).cuda()
+                acc.accel_update(ft)
+                out = ft.cpu().numpy()
+        else:
+            ft = torch.from_numpy(x.copy()).cuda()
+            acc.accel_update(ft)
+            out = ft.cpu().numpy()
+        assert acc.num_vec() == ora.num_vec()
+        assert S.rel_err(out, f, x) <= TOL_SMALL, t
