@@ -65,6 +65,15 @@ enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C =
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
 
+/* hipGraph capture.  nka_hip_accel_update only enqueues kernels (no allocation,
+ * no synchronisation), so a caller may capture it into a graph and replay it.
+ * A replay re-issues the kernel instances chosen at capture time; they stay
+ * valid as long as the unroll widths chosen then cover the list, which is
+ * guaranteed once nka_hip_capture_safe() returns 1: a pair is pending and the
+ * host-side bound on the list length has reached mvec+1 (from the mvec+1-th
+ * update after init/restart on).  restart()/relax() end that state. */
+int nka_hip_capture_safe(nka_hip_t a);
+
 /* Rebind the handle to another hipStream_t (NULL = default stream).  Work already
  * enqueued on the old stream is ordered before anything enqueued on the new one. */
 int nka_hip_set_stream(nka_hip_t a, void *stream);

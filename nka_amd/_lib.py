@@ -16,6 +16,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_
 SIGNATURES = {
     "nka_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p]),
     "nka_hip_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_capture_safe": (C.c_int, [C.c_void_p]),
     "nka_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update_host": (C.c_int, [C.c_void_p, C.c_void_p]),

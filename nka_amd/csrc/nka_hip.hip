@@ -308,6 +308,11 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   return 0;
 }
 
+int nka_hip_capture_safe(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  return (a->pending && a->list_ub >= a->mvec + 1) ? 1 : 0;
+}
+
 int nka_hip_set_stream(nka_hip_t a, void *stream) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   hipStream_t ns = (hipStream_t)stream;

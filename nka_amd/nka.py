@@ -161,6 +161,11 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update")
         return f
 
+    def capture_safe(self) -> bool:
+        """True once an accel_update captured into a hipGraph stays valid on replay
+        (steady state: see nka_hip_capture_safe in include/nka_hip.h)."""
+        return self._L.nka_hip_capture_safe(self._handle()) == 1
+
     def set_stream(self, stream: int):
         """Rebind to another hipStream_t; earlier work stays ordered before later work."""
         _check(self._L.nka_hip_set_stream(self._handle(), C.c_void_p(int(stream))), "set_stream")

@@ -515,3 +515,45 @@ def test_follows_the_current_torch_stream(torch_cuda, oracle):
             out = ft.cpu().numpy()
         assert acc.num_vec() == ora.num_vec()
         assert S.rel_err(out, f, x) <= TOL_SMALL, t
+
+
+def test_steady_state_update_is_hipgraph_capturable(torch_cuda):
+    """accel_update only enqueues kernels; once capture_safe() is true, ONE update
+    captured into a hipGraph and replayed with fresh inputs reproduces the eager
+    results bit for bit (launch-bound small-n loops can be replayed as graphs)."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 200003, 6
+    rng = np.random.default_rng(0)
+    X = [rng.standard_normal(n) for _ in range(m + 12)]
+    ref = nka_amd.nka().init(n, m)
+    want = []
+    for x in X:
+        t = torch.from_numpy(x.copy()).cuda()
+        ref.accel_update(t)
+        want.append(t.cpu().numpy())
+    acc = nka_amd.nka().init(n, m)
+    side = torch.cuda.Stream()
+    static = torch.empty(n, dtype=torch.float64, device="cuda")
+    got = []
+    with torch.cuda.stream(side):
+        for i, x in enumerate(X[:m + 3]):
+            assert acc.capture_safe() == (i >= m + 1)
+            static.copy_(torch.from_numpy(x))
+            acc.accel_update(static)
+            got.append(static.cpu().numpy())
+    torch.cuda.synchronize()
+    assert acc.capture_safe()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        acc.accel_update(static)
+    for x in X[m + 3:]:
+        static.copy_(torch.from_numpy(x))
+        g.replay()
+        torch.cuda.synchronize()
+        got.append(static.cpu().numpy())
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    assert acc.num_vec() == ref.num_vec() == m
+    acc.relax()
+    assert not acc.capture_safe()
