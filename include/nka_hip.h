@@ -200,6 +200,9 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
                               double *host_vals1, double *host_cross);
 int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                             const double *const *xs, const double *b, const double *const *ys, int32_t count);
+/* z <- a[j]*xs[j] + z for j = 0..count-1 in order (override of vector%axpy_many). */
+int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                          const double *const *xs, int32_t count);
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
 int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 

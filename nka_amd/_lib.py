@@ -58,6 +58,7 @@ SIGNATURES = {
                                             C.c_int32, _dp, _dp, _dp]),
     "nka_hip_vec_update_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                           C.POINTER(C.c_void_p), C.c_int32]),
+    "nka_hip_vec_axpy_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32]),
     "nka_hip_vec_h2d": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nka_hip_vec_d2h": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -218,6 +218,37 @@ __global__ __launch_bounds__(kBlock) void k_update_many(int64_t n, double *z, Ma
     }
 }
 
+// z <- a_j*x_j + z for j = 0..count-1 IN ORDER (the rounding of count successive
+// update1_ calls, grid_vector_type.F90:127), z read and written once.
+template <int NV, int VEC>
+__global__ __launch_bounds__(kBlock) void k_axpy_many(int64_t n, double *z, ManyArgs m) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V zv = ld<VEC>(z + e);
+    V xv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) xv[j] = ld<VEC>((j < m.count ? m.x[j] : z) + e);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (j < m.count)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) setc(zv, q, m.a[j] * ex(xv[j], q) + ex(zv, q));
+    st(z + e, zv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      double zi = z[i];
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+        if (j < m.count) zi = m.a[j] * m.x[j][i] + zi;
+      z[i] = zi;
+    }
+}
+
 int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec) {
   int64_t g = (int64_t)ws->num_cu * 8;
   g = std::min<int64_t>(g, std::max<int64_t>(n / (kBlock * vec), 1));
@@ -462,6 +493,36 @@ int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const dou
     const int g = grid_for(ws, n, v2 ? 2 : 1);
     const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
 #define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_update_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
+    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
+#undef LAUNCH
+    HIP_TRYV(hipGetLastError());
+  }
+  return 0;
+}
+
+// z <- a[j]*xs[j] + z for j = 0..count-1 in order; z read and written once per
+// group of kManyMax vectors.
+int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                          int32_t count) {
+  if (!ws || n < 0 || count < 0 || (count > 0 && (!a || !xs))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if (n == 0 || count == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(z, n, "vec_axpy_many: z")) return rc;
+  for (int j = 0; j < count; j++)
+    if (int rc = nka_detail::check_device_span(xs[j], n, "vec_axpy_many: xs[j]")) return rc;
+  for (int base = 0; base < count; base += kManyMax) {
+    ManyArgs m{};
+    m.count = std::min(kManyMax, count - base);
+    bool v2 = al16(z);
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = xs[base + j];
+      m.a[j] = a[base + j];
+      v2 = v2 && al16(m.x[j]);
+    }
+    const int g = grid_for(ws, n, v2 ? 2 : 1);
+    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
+#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_axpy_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
     if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
     else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
 #undef LAUNCH

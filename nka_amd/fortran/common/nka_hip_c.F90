@@ -193,6 +193,14 @@ module nka_hip_c
       type(c_ptr), intent(in) :: xs(*), ys(*)     ! host arrays of device pointers
       integer(c_int32_t), value :: count
     end function
+    integer(c_int) function nka_hip_vec_axpy_many(ws, n, z, a, xs, count) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*)
+      type(c_ptr), intent(in) :: xs(*)
+      integer(c_int32_t), value :: count
+    end function
     integer(c_int) function nka_hip_vec_h2d(ws, n, dst_dev, src_host) bind(C)
       import :: c_int, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, dst_dev

@@ -42,6 +42,7 @@ module hip_block_vector_type
     procedure :: dot_many => dot_many_fused
     procedure :: dot_pair_many => dot_pair_many_fused
     procedure :: update_many => update_many_fused
+    procedure :: axpy_many => axpy_many_fused
     !! specific to this type
     procedure :: init
     procedure :: release
@@ -290,6 +291,27 @@ contains
     end select
     call nka_hip_check(nka_hip_vec_update_many(this%ws, this%ntot, this%base, a, xp, b, yp, &
                                                size(idx, kind=c_int32_t)), 'vec_update_many')
+  end subroutine
+
+  !! this <- a(j)*xs(idx(j)) + this, j in order (the rounding of successive update1_ calls)
+  subroutine axpy_many_fused(this, a, xs, idx)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:)
+    class(vector), intent(in) :: xs(:)
+    integer, intent(in) :: idx(:)
+    type(c_ptr) :: xp(size(idx))
+    integer :: j
+    if (size(idx) == 0) return
+    select type (xs)
+    class is (hip_block_vector)
+      do j = 1, size(idx)
+        xp(j) = xs(idx(j))%base
+      end do
+    class default
+      error stop 'incompatible arguments to VECTOR%AXPY_MANY'
+    end select
+    call nka_hip_check(nka_hip_vec_axpy_many(this%ws, this%ntot, this%base, a, xp, size(idx, kind=c_int32_t)), &
+                       'vec_axpy_many')
   end subroutine
 
 end module hip_block_vector_type

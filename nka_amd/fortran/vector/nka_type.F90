@@ -28,6 +28,7 @@ module nka_type
   type, public :: nka
     private
     logical :: subspace = .false., pending = .false.
+    logical :: compact = .false.                  ! optional: keep v - w in the v slots (see init)
     integer :: mvec = 0
     real(r8) :: vtol = 0.01_r8                    ! default drop tolerance (F08V:152)
     class(vector), allocatable :: v(:), w(:)      ! mvec+1 slots each
@@ -48,13 +49,19 @@ module nka_type
 
 contains
 
-  !! call a%init(vec, mvec): slots are clones of vec (F08V:175-188)
-  subroutine init(this, vec, mvec)
+  !! call a%init(vec, mvec): slots are clones of vec (F08V:175-188).
+  !! compact (optional, default .false.): once a pair is normalised, keep the
+  !! difference v - w in the v slot and combine with  f <- f + c*(v - w)  -- the
+  !! rounding of the C reference (src-C/...c:423) instead of update3_(-c,w,c,v) --
+  !! so the combine streams one vector per pair instead of two.
+  subroutine init(this, vec, mvec, compact)
     class(nka), intent(out) :: this
     class(vector), intent(in) :: vec
     integer, intent(in) :: mvec
+    logical, intent(in), optional :: compact
     if (mvec <= 0) error stop 'nka%init: mvec must be positive'
     this%mvec = mvec
+    if (present(compact)) this%compact = compact
     call vec%clone(this%v, mvec+1)
     call vec%clone(this%w, mvec+1)
     allocate(this%h(mvec+1,mvec+1), this%next(mvec+1), this%prev(mvec+1))
@@ -230,6 +237,7 @@ contains
     if (this%pending) then
       call this%v(this%first)%scale(1.0_r8/s)
       call this%w(this%first)%scale(1.0_r8/s)
+      if (this%compact) call this%v(this%first)%update(-1.0_r8, this%w(this%first))   ! v1 <- v1 - w1
       !! Both inner-product rows of this update in ONE batched hook call: the Gram
       !! row <w1,w_k> (F08V:260-264) and the projection row <f,w_k> (F08V:347) for
       !! every older entry, plus <f,w1>.  f is not modified in between, so the
@@ -275,7 +283,11 @@ contains
         vals(j) = c(idx(j))
       end do
       !! f <- f - c w + c v for every k in list order (F08V:374), one batched call
-      call f%update_many(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx))
+      if (this%compact) then
+        call f%axpy_many(vals(1:nidx), this%v, idx(1:nidx))    ! v slots hold v - w: f <- f + c*(v - w)
+      else
+        call f%update_many(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx))
+      end if
     end if
 
     call this%v(slot)%copy(f)                                ! keep the returned update

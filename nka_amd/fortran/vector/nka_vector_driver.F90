@@ -1,13 +1,13 @@
 !! nka_vector_driver -- exercises the abstract-vector flavour on the GPU.
 !!
-!!   nka_vector_driver check NFIELD NPER MVEC NCALLS OUTFILE
+!!   nka_vector_driver check NFIELD NPER MVEC NCALLS OUTFILE [COMPACT 0|1]
 !!       drives NKA (vector flavour) on a hip_block_vector with the integer-LCG
 !!       inputs of SURVEY.md 8(c) (x <- (1103515245 x + 12345) mod 2^31, value
 !!       x/2^30 - 1; every 5th call a vector from a 3-dimensional pool so that
 !!       dependence drops occur) and writes, per call, num_vec and the returned
 !!       vector to OUTFILE (stream, native real64) for tests/test_fortran_gpu.py
 !!       to compare with the oracle's F08-vector flavour.
-!!   nka_vector_driver bench NFIELD NPER MVEC STEPS
+!!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
 
@@ -21,7 +21,8 @@ program nka_vector_driver
   implicit none
 
   character(256) :: mode, arg, outfile
-  integer :: nfield, mvec, ncalls
+  integer :: nfield, mvec, ncalls, icompact = 0
+  logical :: compact
   integer(i8) :: nper
   integer(i8) :: lcg_state = 1
 
@@ -33,8 +34,16 @@ program nka_vector_driver
   select case (trim(mode))
   case ('check')
     call get_command_argument(6, outfile)
+    if (command_argument_count() >= 7) then
+      call get_command_argument(7, arg); read(arg,*) icompact
+    end if
+    compact = icompact /= 0
     call run_check
   case ('bench')
+    if (command_argument_count() >= 6) then
+      call get_command_argument(6, arg); read(arg,*) icompact
+    end if
+    compact = icompact /= 0
     call run_bench
   case default
     error stop 'usage: nka_vector_driver check|bench NFIELD NPER MVEC NCALLS [OUTFILE]'
@@ -57,7 +66,7 @@ contains
     n = nfield * nper
     ws = hip_block_vector_workspace(0)
     call f%init(nfield, nper, ws)
-    call accel%init(f, mvec)
+    call accel%init(f, mvec, compact=compact)
     allocate(host(n), pool(n,3), coef(3))
     do k = 1, 3
       do i = 1, n
@@ -106,7 +115,7 @@ contains
     ninp = warm + ncalls
     ws = hip_block_vector_workspace(0)
     call f%init(nfield, nper, ws)
-    call accel%init(f, mvec)
+    call accel%init(f, mvec, compact=compact)
     !! independent inputs, resident on the device before the timed region
     allocate(inputs(ninp), host(nper))
     do t = 1, ninp
@@ -131,7 +140,8 @@ contains
     call system_clock(c1)
     secs = real(c1 - c0, r8) / real(rate, r8)
     per = secs / ncalls
-    write(*,'(a,i0,a,i0,a,i0)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec
+    write(*,'(a,i0,a,i0,a,i0,a,l1)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec, &
+                                     ' compact=', compact
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
     !! bytes the hooks move per update: hook by hook 8n(12+8m); with the batched
     !! hooks of hip_block_vector 8n(16+3m); contract figure 8n(11+3m)

@@ -45,6 +45,7 @@ module vector_class
     procedure :: dot_many
     procedure :: dot_pair_many
     procedure :: update_many
+    procedure :: axpy_many
   end type
 
   abstract interface
@@ -225,6 +226,18 @@ contains
     integer :: j
     do j = 1, size(idx)
       call this%update(a(j), xs(idx(j)), b(j), ys(idx(j)))
+    end do
+  end subroutine
+
+  !! this <- this + sum_j a(j)*xs(idx(j)), applied in order j = 1..size(idx).
+  subroutine axpy_many(this, a, xs, idx)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:)
+    class(vector), intent(in) :: xs(:)
+    integer, intent(in) :: idx(:)
+    integer :: j
+    do j = 1, size(idx)
+      call this%update(a(j), xs(idx(j)))
     end do
   end subroutine
 

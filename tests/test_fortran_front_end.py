@@ -48,13 +48,15 @@ def test_config1_through_fortran_front_end_on_gpu(fortran_build, args, key, flav
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compact", [0, 1])
 @pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8)])
-def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, tmp_path, nfield, nper, mvec, ncalls):
+def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, tmp_path, nfield, nper, mvec, ncalls,
+                                                        compact):
     """vector_class hooks on a device-resident block vector, driven by the
     vector flavour of nka_type, against the oracle's F08-vector flavour."""
     out = tmp_path / "vec.bin"
     p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "check", str(nfield), str(nper),
-                        str(mvec), str(ncalls), str(out)], capture_output=True, text=True, timeout=300)
+                        str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     n = nfield * nper
     raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * n + 1)

@@ -88,6 +88,14 @@ def test_batched_hooks_equal_the_loops_they_replace(ws, n, count):
         ref = (a[j] * X[j] + b[j] * Y[j]) + ref
     assert np.array_equal(zd.cpu().numpy(), ref)
 
+    # axpy_many == count successive update1_ calls, bit for bit
+    zd2 = _dev(torch, z0)
+    assert L.nka_hip_vec_axpy_many(h, n, C.c_void_p(zd2.data_ptr()), a.ctypes.data_as(dp), xs, count) == 0
+    ref2 = z0.copy()
+    for j in range(count):
+        ref2 = a[j] * X[j] + ref2
+    assert np.array_equal(zd2.cpu().numpy(), ref2)
+
     # dot_many == count dot_ calls within the reduction tolerance
     vals = np.zeros(count)
     wd = _dev(torch, z0)
