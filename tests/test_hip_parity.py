@@ -557,3 +557,53 @@ def test_steady_state_update_is_hipgraph_capturable(torch_cuda):
     assert acc.num_vec() == ref.num_vec() == m
     acc.relax()
     assert not acc.capture_safe()
+
+
+@pytest.mark.parametrize("m,seed", [(2, 0), (5, 1), (9, 2), (5, 3), (33, 4)])
+def test_randomised_call_sequences_against_oracle(torch_cuda, oracle, m, seed):
+    """Long random sequences of every public operation -- updates with fresh,
+    dependent, repeated and zero inputs, relax, restart, set_vec_tol -- must keep
+    the device state machine (and the host's bounds that size the kernels) in
+    lock step with the oracle: num_vec, list order and free list after EVERY
+    call, values within the conditioning-aware tolerance."""
+    n = 257
+    rng = np.random.default_rng(1000 + seed)
+    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    nupd = 0
+    for step in range(300):
+        r = rng.random()
+        if r < 0.80:
+            kind = rng.random()
+            if kind < 0.55:
+                x = rng.standard_normal(n)
+            elif kind < 0.85:
+                x = rng.standard_normal(3) @ basis          # dependent: forces drops
+            elif kind < 0.95:
+                x = prev.copy()                             # repeated: s == 0 -> relax
+            else:
+                x = np.zeros(n)
+            prev = x
+            f = x.copy()
+            ora.accel_update(f)
+            ft = torch_cuda.from_numpy(x.copy()).cuda()
+            acc.accel_update(ft)
+            nupd += 1
+            st = acc.state()
+            nx = np.linalg.norm(x)
+            if nx > 0:
+                assert S.rel_err(ft.cpu().numpy(), f, x) <= cond_tol(st, 1e-11), (step, nupd)
+        elif r < 0.88:
+            acc.relax(); ora.relax()
+        elif r < 0.93:
+            acc.restart(); ora.restart()
+        else:
+            vt = float(10.0 ** rng.uniform(-3, -0.3))
+            acc.set_vec_tol(vt); ora.set_vec_tol(vt)
+        assert acc.num_vec() == ora.num_vec(), step
+        sa, so = acc.state(), ora.state()
+        assert sa.list_order() == so.list_order(), step
+        assert sa.free_order() == so.free_order(), step
+        assert (sa.subspace, sa.pending) == (so.subspace, so.pending), step
+    assert acc.defined()
