@@ -1,5 +1,6 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+"""Host-array entry point timed with the PCIe copies of f included (n=1e8, m=20)."""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, nka_amd
 from nka_amd import synth
 torch.cuda.set_device(0)
