@@ -13,16 +13,25 @@ scaling, BASELINE configs[3]); the only exchange is ONE RCCL all-reduce of
 2+2*mvec doubles per update (the norm and both Gram rows), on the kernel stream.
 
 Prints ONE JSON line (rank 0) with the driver's keys plus
-  roofline     : algorithmic bytes of one update, 8*n*(11+L+2k),
-                 over the mean device time of an update measured with HIP events
-                 on the kernel stream during the timed steps; per-kernel figures
-                 for PA k_dots / PB k_combine under "kernels" with the bytes each
-                 launch actually moves (PB is the dominant kernel)
+  roofline     : PHYSICAL fractions only.  Top level = the dominant kernel (PB
+                 k_combine): bytes that launch really moves (byte model confirmed by
+                 the PMC passes under profiles/) / its mean duration over the timed
+                 steps (HIP events on the kernel stream) / 8 TB/s; `whole_update`
+                 = PA + scalar step + PB the same way; `kernels` per launch.  The
+                 contract's B_alg = 8n(11+L+2k) (a three-pass
+                 schedule that moves more bytes than this one) appears only as
+                 `contract_bytes_ratio` / `contract_GBps`, never as a fraction.
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
                  oracle port timed on this box's host on a bounded sample.
   also_f08_rounding : the same workload and protocol measured a second time in
-                 the same run with the src-F08 rounding (the headline `value` is
-                 the src-C rounding with compact storage).
+                 the same run with the src-F08 rounding and two stored vectors per
+                 pair.  The headline `value` mirrors the src-C rounding of the
+                 combine with compact storage; both are checked
+                 against the compiled src-F08 reference in tests/ (decisions exact,
+                 values within the stated tolerance).
+  replica_check (N > 1): digest of the replicated scalar state of every rank,
+                 compared after warm-up and after the timed steps (outside the
+                 timed region); a mismatch aborts the job.
 """
 from __future__ import annotations
 
@@ -95,6 +104,87 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6):
     }
 
 
+FLAVOR_TEXT = {"c": "src-C rounding f += c*(v-w), compact storage (v slot keeps v'-w'); checked against the "
+                    "src-F08 reference within the stated tolerance, decisions exact",
+               "f08": "src-F08 rounding (f - c*w) + c*v, two stored vectors per pair",
+               "f08vec": "src-F08-vector rounding ((-c)*w + c*v) + f, normalise by reciprocal"}
+
+
+def words_moved(flavor: str, L: int, k: int):
+    """8-byte words per element each launch of the two-pass schedule really moves
+    (confirmed by the PMC passes under profiles/): PA reads w1, f and the L stored
+    w; PB reads f and the k pairs (one vector per pair with compact storage, the
+    pending pair always as two) and writes w1', v1', w_new, v_new, f."""
+    pb_reads = (2 + k) if flavor == "c" else (1 + 2 * k)
+    return {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + 5}
+
+
+def pmc_traffic(flavor: str, n_local: int, m: int):
+    """HBM bytes per launch from the newest rocprofv3 PMC summary of THIS workload
+    (tools/rocprof_bench.sh + tools/pmc_summary.py, committed under profiles/)."""
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{flavor}.json")), reverse=True):
+        try:
+            with open(cand) as fh:
+                pm = json.load(fh)
+            if pm.get("n") == n_local and pm.get("mvec") == m and pm.get("hbm_bytes_per_update"):
+                return pm, os.path.relpath(cand, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
+def roofline_block(flavor: str, n_local: int, m: int, mean, copy_gbps):
+    """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
+    PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
+    PMC counters) / mean launch duration (HIP events on the kernel stream during
+    the timed steps) / 8 TB/s, hence <= 1.  Top level = the dominant kernel (PB
+    k_combine); `whole_update` = both passes and the scalar step together.  The
+    contract's figure B_alg = 8n(11+L+2k) of SURVEY.md 8(d) assumes a three-pass
+    schedule that moves MORE bytes than this one; its ratio to the bytes moved
+    is `contract_bytes_ratio`, and `contract_GBps` = B_alg / time is a rate of
+    useful work, not a bandwidth (it may exceed the peak and is never `frac`)."""
+    L = k = m
+    words = words_moved(flavor, L, k)
+    ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}
+    pm, pm_src = pmc_traffic(flavor, n_local, m)
+    pmk = {"PA_k_dots": "k_dots", "PB_k_combine": "k_combine"}
+    kernels = {}
+    for name, w in words.items():
+        t = ms[name] * 1e-3
+        b = 8.0 * n_local * w
+        tr = None
+        if pm and pmk[name] in pm.get("kernels", {}):
+            kk = pm["kernels"][pmk[name]]
+            tr = kk["read_bytes"] + kk["write_bytes"]
+        kernels[name] = {"bytes_moved": b, "words_per_element": w, "mean_ms": ms[name],
+                         "achieved": (b / t / 1e9) if t > 0 else None,
+                         "frac": (b / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else None,
+                         "traffic": tr}
+    kernels["k_solve"] = {"mean_ms": mean[1]}
+    dom = max(("PA_k_dots", "PB_k_combine"), key=lambda nm: ms[nm])
+    upd_s = mean[3] * 1e-3
+    moved = 8.0 * n_local * sum(words.values())
+    b_alg = 8.0 * n_local * (11 + L + 2 * k)
+    return {
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        "kernel": dom, "achieved": kernels[dom]["achieved"], "frac": kernels[dom]["frac"],
+        "traffic": kernels[dom]["traffic"], "traffic_source": pm_src,
+        "what": "dominant kernel: bytes the launch moves (8*n_local*words_per_element; PMC-confirmed) / mean launch "
+                "duration over the timed steps (HIP events on the kernel stream) / 8 TB/s",
+        "whole_update": {"bytes_moved": moved, "mean_ms": mean[3],
+                         "achieved": (moved / upd_s / 1e9) if upd_s > 0 else None,
+                         "frac": (moved / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
+                         "traffic": pm["hbm_bytes_per_update"] if pm else None,
+                         "what": "PA + scalar step + PB, first kernel start .. last kernel end"},
+        "kernels": kernels,
+        "contract_bytes_per_update": b_alg,
+        "contract_bytes_ratio": b_alg / moved,
+        "contract_GBps": (b_alg / upd_s / 1e9) if upd_s > 0 else None,
+        "copy_ceiling_GBps": copy_gbps,
+    }
+
+
 def main():
     args = parse()
     import torch
@@ -106,6 +196,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        # a sharded run can only hang in a collective: never wait for ever (SIGALRM ends the
+        # rank with a traceback and a non-zero code; torchrun then takes the others down)
+        import faulthandler
+        import signal
+        limit = int(os.environ.get("NKA_BENCH_WATCHDOG_S", "900"))
+        faulthandler.register(signal.SIGALRM, all_threads=True, chain=True)
+        signal.alarm(limit)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -114,7 +212,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
 
     n_global, m = int(args.n), args.mvec
     lo, hi = nd.slice_bounds(n_global, world, rank)
@@ -137,18 +236,23 @@ def main():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29511")
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            hook = args.allreduce if hook_box[0] == "none" else hook_box[0]
-            if hook == "rccl":
-                try:
-                    nd.attach_rccl(acc, rank, world)
-                except Exception as exc:   # collective failure: every rank lands here together
-                    print(f"[bench] RCCL communicator failed ({exc!r}); using the torch.distributed hook",
-                          file=sys.stderr)
-                    hook = "torch"
-            if hook == "torch":
-                nd.attach_torch_allreduce(acc)
-            hook_box[0] = hook
+            # collective decision (all ranks end up with the same hook) + a proven test all-reduce
+            prefer = args.allreduce if hook_box[0] == "none" else hook_box[0]
+            hook_box[0] = nd.attach_allreduce(acc, rank, world, prefer=prefer)
         return acc
+
+    def check_replicas(acc, where):
+        """The scalar state (lists, h, c, all-reduced sums) is replicated: every rank
+        must hold the same bits, or the ranks have diverged.  Outside
+        the timed region.  Aborts the whole job loudly on a mismatch."""
+        digs = nd.replica_digests(acc)
+        same = all(d == digs[0] for d in digs)
+        if not same:
+            msg = f"[bench] FATAL: replicated NKA state differs across ranks {where}: " + \
+                  ", ".join(f"rank{r}={d:016x}" for r, d in enumerate(digs))
+            print(msg, file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        return {"where": where, "ranks": len(digs), "digest": f"{digs[0]:016x}", "identical": True}
 
     acc = make_acc(args.flavor)
 
@@ -182,6 +286,7 @@ def main():
             acc.accel_update(pool[t % P])
         sync_all()
         nv0 = acc.num_vec()
+        checks = [check_replicas(acc, "after warm-up")] if world > 1 or hook_box[0] != "none" else []
         acc.set_timing(min(K, 4096))
         sync_all()
         t0 = time.perf_counter()
@@ -199,9 +304,11 @@ def main():
         nrec = min(K, 4096)
         ph = [acc.timing_ms(b) for b in range(nrec)]
         mean = [sum(p[i] for p in ph) / nrec for i in range(4)]
-        return elapsed, mean, nv0, acc.num_vec()
+        if checks:
+            checks.append(check_replicas(acc, "after the timed steps"))
+        return elapsed, mean, nv0, acc.num_vec(), checks
 
-    elapsed, mean, nv, nv_end = measure(acc)
+    elapsed, mean, nv, nv_end, replica_check = measure(acc)
     steady = (nv == m)
 
     # device-copy ceiling measured in the same run
@@ -228,47 +335,15 @@ def main():
     if args.flavor == "c" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
         acc.delete()
         acc = make_acc("f08")
-        e2, mean2, nv2, nv2_end = measure(acc)
-        also = {"flavor": "src-F08 rounding (f - c*w) + c*v, two stored vectors per pair",
+        e2, mean2, nv2, nv2_end, _ = measure(acc)
+        also = {"flavor": FLAVOR_TEXT["f08"],
                 "value": K / e2, "unit": "updates/s", "ms_per_step": 1e3 * e2 / K,
                 "steady_state": bool(nv2 == m and nv2_end == m),
-                "roofline_frac": 8.0 * n_local * (11 + 3 * m) / (mean2[3] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "frac_of_bytes_moved": 8.0 * n_local * (8 + 3 * m) / (mean2[3] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "kernels_mean_ms": {"PA_k_dots": mean2[0], "k_solve": mean2[1], "PB_k_combine": mean2[2]}}
+                "roofline": roofline_block("f08", n_local, m, mean2, None)}
 
     if rank == 0:
         L = k = m
-        # words (8 B) per element each launch moves: PA reads w1, f and L stored w's;
-        # PB reads f + k (w,v) pairs and writes w1', v1', w_new, v_new, f
-        pb_reads = (2 + k) if args.flavor == "c" else (1 + 2 * k)   # compact storage reads one vector per pair
-        words = {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + 5}
-        b_alg = 8.0 * n_local * (11 + L + 2 * k)                 # SURVEY.md 8(d), per update, per GPU
-        upd_s = mean[3] * 1e-3
-        # Attribution of the contract's algorithmic words 11+L+2k (P1 2, P2 5+L, P3 4+2k)
-        # to the two launches of this schedule: PA does P1 and the reading/dot part of P2
-        # (2 + 2+L); PB does P3 plus P2's normalisation traffic (v1 read, w1'/v1' writes: 4+2k + 3).
-        alg_words = {"PA_k_dots": 4 + L, "PB_k_combine": 7 + 2 * k}
-        kernels = {}
-        for (name, w), ms in zip(words.items(), (mean[0], mean[2])):
-            kernels[name] = {"bytes_moved": 8.0 * n_local * w, "mean_ms": ms,
-                             "GBps": (8.0 * n_local * w / (ms * 1e-3) / 1e9) if ms > 0 else None,
-                             "algorithmic_bytes": 8.0 * n_local * alg_words[name],
-                             "algorithmic_GBps": (8.0 * n_local * alg_words[name] / (ms * 1e-3) / 1e9) if ms > 0 else None,
-                             "frac": (8.0 * n_local * alg_words[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms > 0 else None}
-        kernels["k_solve"] = {"mean_ms": mean[1]}
-        achieved = b_alg / upd_s / 1e9 if upd_s > 0 else 0.0
-        # HBM bytes per update from the rocprofv3 PMC passes of THIS workload (tools/rocprof_bench.sh +
-        # tools/pmc_summary.py, committed under profiles/); null if no matching measurement is present
-        traffic, traffic_src = None, None
-        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{args.flavor}.json")), reverse=True):
-            try:
-                with open(cand) as fh:
-                    pm = json.load(fh)
-                if pm.get("n") == n_local and pm.get("mvec") == m and pm.get("hbm_bytes_per_update"):
-                    traffic, traffic_src = pm["hbm_bytes_per_update"], os.path.relpath(cand, ROOT)
-                    break
-            except Exception:
-                pass
+        rl = roofline_block(args.flavor, n_local, m, mean, copy_gbps)
         out = {
             "metric": ("NKA updates/sec + achieved HBM GB/s at n=1e8, m=20 fp64; 1/2/4/8 GPUs"   # BASELINE.json
                        if (n_global, m) == (10**8, 20) else
@@ -279,23 +354,18 @@ def main():
             "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction "
                                    f"vectors, n={n_global} (global), mvec={m}, fp64, subspace full (num_vec={nv})",
                        "n_global": n_global, "n_local": n_local, "mvec": m,
-                       "flavor": {"c": "src-C rounding f += c*(v-w), compact storage",
-                                  "f08": "src-F08 rounding (f - c*w) + c*v",
-                                  "f08vec": "src-F08-vector rounding"}[args.flavor],
+                       "flavor": FLAVOR_TEXT[args.flavor],
                        "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}",
                        "steady_state": bool(steady and nv_end == m), "prime_steps": prime,
                        "inputs_resident": not refill_in_timed_region},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "what": "whole accel_update on one GPU: algorithmic bytes 8*n_local*(11+L+2k) / mean "
-                                 "device time first-kernel-start..last-kernel-end (HIP events, kernel stream)",
-                         "algorithmic_bytes_per_update": b_alg, "mean_update_ms": mean[3],
-                         "bytes_moved_per_update": 8.0 * n_local * sum(words.values()),
-                         "frac_of_bytes_moved": 8.0 * n_local * sum(words.values()) / upd_s / 1e9 / HBM_PEAK_GBPS,
-                         "dominant_kernel": "PB_k_combine", "kernels": kernels,
-                         "copy_ceiling_GBps": copy_gbps},
-            "aggregate_algorithmic_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
+            "roofline": rl,
+            # whole-job rate in the contract's unit (SURVEY.md 8d bytes x updates/s); NOT a bandwidth
+            "aggregate_contract_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
         }
+        if replica_check:
+            out["replica_check"] = replica_check
+        if hook_box[0] == "rccl":
+            out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:
             out["also_f08_rounding"] = also
         if world == 1 and not args.no_cpu_baseline:

@@ -6,10 +6,13 @@
  * Same names, argument order and meaning.  `f` is HOST memory, as in the
  * reference (nka_accel_update copies it to the GPU and back); a caller whose
  * vectors already live in HBM uses nka_accel_update_dev.  The reference's `dp`
- * argument (a host dot product, .c:196, 227-231) cannot see device memory: it
- * must be NULL here, and a multi-rank run installs nka_hip_set_allreduce /
- * nka_hip_comm_init_rank on the returned handle instead.  Failed preconditions
- * abort like the reference's assert() (.c:216-218).
+ * argument (.c:196, 211, 227-231): NULL selects the device sums (the fast
+ * path; a multi-rank run then installs nka_hip_set_allreduce /
+ * nka_hip_comm_init_rank on the returned handle); a non-NULL dp is honoured
+ * through nka_hip_set_host_dot -- every inner product of every update is then
+ * evaluated by dp on host copies of the operands in the reference's own order
+ * (slow compatibility path, see include/nka_hip.h).  Failed preconditions abort
+ * like the reference's assert() (.c:216-218).
  */
 #ifndef NKA_C_COMPAT_H
 #define NKA_C_COMPAT_H
@@ -28,13 +31,23 @@ static inline void nka_compat_check_(int rc, const char *what) {
   }
 }
 
+typedef double (*nka_compat_dp_fn_)(int, double *, double *);
+
+/* nka_hip_host_dot_fn over the reference's dp(int, double*, double*): ctx is dp itself */
+static inline double nka_compat_dp_trampoline_(void *ctx, int64_t n, const double *x, const double *y) {
+  union { void *p; nka_compat_dp_fn_ f; } u;
+  u.p = ctx;
+  return u.f((int)n, (double *)x, (double *)y);
+}
+
 static inline NKA nka_init(int vlen, int mvec, double vtol, double (*dp)(int, double *, double *)) {
   NKA a = 0;
-  if (dp != 0) {
-    fprintf(stderr, "nka_init: a host dot product cannot be used on device vectors; pass NULL\n");
-    abort();
-  }
   nka_compat_check_(nka_hip_create(&a, vlen, mvec, vtol, NKA_HIP_FLAVOR_C, 0, 0), "nka_init");
+  if (dp != 0) {                                   /* .c:227-231 */
+    union { void *p; nka_compat_dp_fn_ f; } u;
+    u.f = dp;
+    nka_compat_check_(nka_hip_set_host_dot(a, nka_compat_dp_trampoline_, u.p), "nka_init(dp)");
+  }
   return a;
 }
 static inline void nka_delete(NKA a) { nka_hip_destroy(a); }

@@ -61,7 +61,9 @@ enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C =
  * vtol, dp)  (C .h:4, .c:211-258).  vlen_local is THIS rank's slice length
  * (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).
  * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = HIP's
- * default stream).  Allocates 2*(mvec+1) slot vectors on the device. */
+ * default stream).  Allocates 2*(mvec+1) slot vectors on the device.
+ * mvec <= 140: the scalar step keeps the (mvec+1)^2 matrix in the 160 KiB LDS
+ * of one CU (NKA_HIP_EINVAL beyond; the reference has no limit). */
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
 
@@ -104,7 +106,7 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol);
 int nka_hip_num_vec(nka_hip_t a);      /* F08:221-231, C .h:9  ; <0 on error */
 int nka_hip_max_vec(nka_hip_t a);      /* F08:233-236, C .h:10 */
 int64_t nka_hip_vec_len(nka_hip_t a);  /* F08:238-241, C .h:11 (local length) */
-double nka_hip_vec_tol(nka_hip_t a);   /* F08:243-246, C .h:12 */
+double nka_hip_vec_tol(nka_hip_t a);   /* F08:243-246, C .h:12 ; -1 (and last_error) on a NULL handle */
 int nka_hip_defined(nka_hip_t a);      /* F08:460-524 ; 1 = well defined */
 
 /* List / factor state for parity tests (the reference keeps these private,
@@ -138,11 +140,50 @@ int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);
 typedef int (*nka_hip_allreduce_fn)(void *ctx, double *buf, int32_t count, void *stream);
 int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx);
 
+/* If the hook (or the built-in RCCL all-reduce) fails, nka_hip_accel_update
+ * returns NKA_HIP_ECOMM with the update NOT done: only scratch sums were
+ * written; f, the stored vectors, the lists and the host bookkeeping are as
+ * before the call. */
+
 /* Built-in hook: RCCL all-reduce over xGMI on the handle's stream.
  * nka_hip_comm_unique_id fills 128 bytes (an ncclUniqueId) on one rank; the
- * caller broadcasts it by any means; every rank then calls comm_init_rank. */
+ * caller broadcasts it by any means; every rank then calls comm_init_rank.
+ * RCCL is bound at first use (dlopen): the librccl.so.1 already mapped into the
+ * process if there is one (PyTorch brings its own), else the ROCm
+ * installation's -- one copy per process either way; nka_hip_comm_library
+ * reports the file.  nka_hip_comm_destroy drops the communicator and the hook. */
 int nka_hip_comm_unique_id(void *id128);
 int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank);
+int nka_hip_comm_destroy(nka_hip_t a);
+int nka_hip_comm_library(char *path, int32_t len);
+
+/* Run the installed all-reduce hook once on `count` doubles at device address
+ * buf_dev, on the handle's stream (no-op without a hook): lets a launcher check
+ * the communicator before the first update. */
+int nka_hip_allreduce_now(nka_hip_t a, double *buf_dev, int32_t count);
+
+/* 64-bit FNV-1a digest of the device-resident scalar state (flags, lists, h, c,
+ * the reduced sums of the last update).  In a sharded run that state is
+ * replicated: every rank must report the same digest after the same call
+ * sequence -- the check SURVEY.md 8(e) asks for, since s == 0, the drop
+ * decisions and the slot choices are taken independently per rank (F08:58-64).
+ * Synchronises the stream. */
+int nka_hip_state_digest(nka_hip_t a, uint64_t *digest);
+
+/* Source compatibility with  call a%set_dot_prod(dot_prod)  (F08:209-219), the dp
+ * argument of nka_init (C .h:4, .c:196,227-231) and the optional dp dummy of the
+ * F95 nka_accel_update (src-F95/nka_type.F90:278-291): a user dot product over
+ * HOST arrays.  With fn installed, the inner products of every update are
+ * evaluated by handing host copies of this rank's slices to fn in the
+ * reference's own order and with its operands -- fn(d,d) with d = w1 - f, then
+ * on w1' = d/s the Gram row fn(w1', w_k) and the projections fn(f, w_j) -- while
+ * the scalar step, the combine and the ring stores stay on the device.  fn must
+ * return the GLOBAL dot product (as in the reference, F08:58-64); the all-reduce
+ * hook is not applied on top.  2+L vectors cross PCIe per update and the call
+ * synchronises: a compatibility path, orders of magnitude slower than the
+ * device sums.  fn = NULL restores them. */
+typedef double (*nka_hip_host_dot_fn)(void *ctx, int64_t n, const double *x, const double *y);
+int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx);
 
 /* ---- instrumentation ---------------------------------------------------- */
 

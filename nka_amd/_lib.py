@@ -11,6 +11,7 @@ _LIB = None
 _i32p = C.POINTER(C.c_int32)
 _dp = C.POINTER(C.c_double)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+HOST_DOT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 # name -> (restype, argtypes): every symbol include/nka_hip.h declares
 SIGNATURES = {
@@ -35,6 +36,11 @@ SIGNATURES = {
     "nka_hip_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "nka_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "nka_hip_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_comm_library": (C.c_int, [C.c_char_p, C.c_int32]),
+    "nka_hip_allreduce_now": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "nka_hip_state_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "nka_hip_set_host_dot": (C.c_int, [C.c_void_p, HOST_DOT_FN, C.c_void_p]),
     "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

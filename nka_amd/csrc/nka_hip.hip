@@ -80,6 +80,56 @@ int env_int(const char *name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+// RCCL is bound at first use, not at link time, so that a process holds exactly
+// ONE copy of it: if a librccl.so.1 is already mapped (PyTorch ships its own and
+// loads it with `import torch`), that copy is used -- two RCCLs in one process
+// would each bring their own communicator state and kernels --, otherwise the
+// ROCm installation's (library RUNPATH /opt/rocm/lib).  NKA_HIP_RCCL_LIB names
+// another file.  Single-GPU users never load the 570 MB library at all.
+struct Rccl {
+  void *handle = nullptr;
+  std::string path, err;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  Rccl() {
+    const char *user = getenv("NKA_HIP_RCCL_LIB");
+    if (user && *user) {
+      handle = dlopen(user, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);   // the copy already in this process
+      if (!handle) handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!handle) {
+      const char *e = dlerror();
+      err = std::string("cannot load RCCL: ") + (e ? e : "unknown dlopen error");
+      return;
+    }
+#define NKA_SYM(name) name = reinterpret_cast<decltype(name)>(dlsym(handle, "nccl" #name))
+    NKA_SYM(GetUniqueId);
+    NKA_SYM(CommInitRank);
+    NKA_SYM(CommDestroy);
+    NKA_SYM(AllReduce);
+    NKA_SYM(GetErrorString);
+#undef NKA_SYM
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+      err = "the loaded RCCL lacks a required ncclXxx symbol";
+      handle = nullptr;
+      return;
+    }
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(AllReduce), &info) && info.dli_fname) path = info.dli_fname;
+  }
+  bool ok() const { return handle != nullptr; }
+};
+const Rccl &rccl() {
+  static const Rccl r;
+  return r;
+}
+
 }  // namespace
 
 struct nka_hip_state {
@@ -107,6 +157,8 @@ struct nka_hip_state {
   nka_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_ctx = nullptr;
   ncclComm_t comm = nullptr;
+  nka_hip_host_dot_fn host_dot = nullptr;   // user dot product on host copies (compatibility path)
+  void *host_dot_ctx = nullptr;
   // instrumentation
   // kTimingEvents events per update, in a ring of timing_cap updates
   int timing_cap = 0;
@@ -142,25 +194,25 @@ int grid_for(const nka_hip_state *a, int which, int vec, int occ, int nloads) {
 
 int rccl_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
   auto *a = static_cast<nka_hip_state *>(ctx);
-  ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, a->comm, (hipStream_t)stream);
-  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, a->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
   return 0;
 }
 
 // ---- kernel dispatch by unroll width ------------------------------------------
 template <int MAXL, int VEC>
-int launch_dots_1(const nka_hip_state *a, const double *f, int pass) {
+int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) {
   static const int occ = occupancy_of(k_dots<MAXL, VEC>);
   const int g = grid_for(a, 0, VEC, occ, MAXL + 2);
   hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, g, pass);
+                     a->partials, g, pass, npass * MAXL);
   return g;
 }
 
-int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass) {
+int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass, int npass) {
 #define CASE(L) \
-  case L: return launch_dots_1<L, 2>(a, f, pass);
+  case L: return launch_dots_1<L, 2>(a, f, pass, npass);
   switch (maxl) {
     CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
   }
@@ -220,6 +272,11 @@ struct RoctxRange {
 
 constexpr int kTimingEvents = 4;
 
+constexpr size_t kMaxDynamicLds = 160 * 1024;   // gfx950: LDS per CU = per workgroup maximum
+constexpr int kMaxMvec = 140;                   // largest mvec with lst_smem_bytes(mvec) <= kMaxDynamicLds
+static_assert(lst_smem_bytes(kMaxMvec) <= kMaxDynamicLds && lst_smem_bytes(kMaxMvec + 1) > kMaxDynamicLds,
+              "kMaxMvec out of step with lst_smem_bytes");
+
 int record(nka_hip_state *a, int i) {
   if (a->timing_cap <= 0) return 0;
   const int slot = (int)(a->timing_count % a->timing_cap);
@@ -242,6 +299,12 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   if (vlen_local < 0) return fail(NKA_HIP_EINVAL, "nka_hip_create: vlen must be >= 0");
   if (!(vtol > 0.0)) return fail(NKA_HIP_EINVAL, "nka_hip_create: vtol must be > 0");
   if (flavor < 0 || flavor > 2) return fail(NKA_HIP_EINVAL, "nka_hip_create: unknown flavor");
+  // The list-scan kernels keep h, c and the links of all mvec+1 slots in LDS
+  // (8*(mvec+2)^2 bytes and change): gfx950's 160 KiB per workgroup bound mvec.
+  // (The reference has no limit; practical subspaces are 5..20 vectors.)
+  if (lst_smem_bytes(mvec) > kMaxDynamicLds)
+    return fail(NKA_HIP_EINVAL, "nka_hip_create: mvec too large for the device-resident scalar step (mvec <= " +
+                                    std::to_string(kMaxMvec) + ")");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(NKA_HIP_EINVAL, "nka_hip_create: no such HIP device");
@@ -265,6 +328,18 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   // NULL is HIP's default (null) stream, as everywhere in HIP: work is ordered
   // with whatever else the caller enqueues there.
   a->stream = (hipStream_t)stream;
+
+  // above the default 64 KiB of dynamic LDS the kernels must opt in (mvec >= 88)
+  if (lst_smem_bytes(mvec) > 64 * 1024) {
+    const int bytes = (int)lst_smem_bytes(mvec);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_restart), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_relax), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      delete a;
+      return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(e));
+    }
+  }
 
   // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
   // the slot stride is padded to 256 B so every slot base allows 16-B loads,
@@ -332,7 +407,7 @@ int nka_hip_destroy(nka_hip_t a) {
   if (!a) return 0;
   hipSetDevice(a->device);
   hipStreamSynchronize(a->stream);
-  if (a->comm) ncclCommDestroy(a->comm);
+  if (a->comm) rccl().CommDestroy(a->comm);
   hipFree(a->vs.v);
   hipFree(a->vs.w);
   hipFree(a->ctl.ic);
@@ -378,6 +453,99 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
   return 0;
 }
 
+// ---- the three stages of an update, enqueued on the handle's stream -------------
+static int enqueue_solve(nka_hip_t a, int mode) {
+  hipStream_t s = a->stream;
+  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
+    const size_t sm = solve_wave_smem_bytes(a->mvec);
+    const int ns = solve_pairs_per_lane(a->mvec);
+#define SOLVE(NS) hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode)
+    if (ns <= 1) SOLVE(1);
+    else if (ns <= 2) SOLVE(2);
+    else if (ns <= 4) SOLVE(4);
+    else if (ns <= 6) SOLVE(6);
+    else if (ns <= 9) SOLVE(9);
+    else if (ns <= 13) SOLVE(13);
+    else SOLVE(19);
+#undef SOLVE
+  } else {
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, mode);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// PB: normalise + combine + ring stores (F08:282-283, 361, 395-404).
+// After the subspace update the list holds at most min(list_ub, mvec) vectors.
+static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
+  const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
+  const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
+  for (int p = 0; p < npass; p++) {
+    const int last = (p == npass - 1);
+    if (vec == 2) {
+      switch (a->flavor) {
+        case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_w<2, 1>(maxk, a, f, p, last); break;
+        case NKA_HIP_FLAVOR_C: launch_combine_w<2, 2>(maxk, a, f, p, last); break;
+        default: launch_combine_w<2, 0>(maxk, a, f, p, last);
+      }
+    } else {
+      switch (a->flavor) {
+        case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_1<4, 1, 1>(a, f, p, last); break;
+        case NKA_HIP_FLAVOR_C: launch_combine_1<4, 1, 2>(a, f, p, last); break;
+        default: launch_combine_1<4, 1, 0>(a, f, p, last);
+      }
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The inner products of an update through the USER's host dot product
+// (nka_hip_set_host_dot): the reference's own sequence of dp calls on host copies
+// of the operands -- dp(d,d) with d = w1 - f (F08:266-267), then on the
+// normalised w1' = d/s the Gram row dp(w1', w_k) (F08:288) and the projections
+// dp(f, w_j) (F08:371) -- written to red[] for the device scalar step (mode
+// kSolvePrenorm).  Synchronous and PCIe-bound by construction: a compatibility
+// path, never the measured one.
+static int host_dot_sums(nka_hip_t a, const double *f) {
+  const int64_t n = a->n;
+  const int mvec = a->mvec;
+  const bool rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR);
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  std::vector<int32_t> ic(a->ctl.ic_count());
+  HIP_TRY(hipMemcpy(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost));
+  const int pending = ic[IC_PLAN_PENDING], first = ic[IC_PLAN_FIRST], nolder = ic[IC_PLAN_NOLDER];
+  const int32_t *slots = ic.data() + (a->ctl.plan_slots() - a->ctl.ic);
+  if (nolder < 0 || nolder > mvec + 1 || (pending && (first < 1 || first > mvec + 1)))
+    return fail(NKA_HIP_ESTATE, "host dot path: corrupt dot plan on the device");
+  const size_t nb = sizeof(double) * (size_t)n;
+  std::vector<double> hf((size_t)n), hw1(pending ? (size_t)n : 0), hk((size_t)n);
+  std::vector<double> red((size_t)a->ctl.red_count(), 0.0);
+  if (n > 0) HIP_TRY(hipMemcpy(hf.data(), f, nb, hipMemcpyDeviceToHost));
+  bool normed = false;
+  if (pending) {
+    if (n > 0) HIP_TRY(hipMemcpy(hw1.data(), a->vs.w + (size_t)(first - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) hw1[i] = hw1[i] - hf[i];                     // F08:266
+    red[0] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hw1.data());           // F08:267 (s = sqrt of it on the device)
+    const double s = std::sqrt(red[0]);
+    if (s != 0.0) {                                                               // F08:275, else relax
+      normed = true;
+      const double rs = 1.0 / s;
+      for (int64_t i = 0; i < n; i++) hw1[i] = rcp ? rs * hw1[i] : hw1[i] / s;   // F08:283 / F08V:256
+      red[1] = a->host_dot(a->host_dot_ctx, n, hf.data(), hw1.data());          // F08:371, j = first
+    }
+  }
+  for (int p = 0; p < nolder; p++) {
+    const int slot = slots[p];
+    if (slot < 1 || slot > mvec + 1) return fail(NKA_HIP_ESTATE, "host dot path: slot out of range in the dot plan");
+    if (n > 0) HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(slot - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+    if (normed) red[2 + p] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hk.data());       // F08:288
+    red[2 + mvec + p] = a->host_dot(a->host_dot_ctx, n, hf.data(), hk.data());             // F08:371
+  }
+  HIP_TRY(hipMemcpy(a->ctl.red(), red.data(), sizeof(double) * red.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
@@ -388,19 +556,26 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   hipStream_t s = a->stream;
   const bool aligned = (reinterpret_cast<uintptr_t>(f) % 16) == 0;
   const int vec = aligned ? 2 : 1;
-  const bool rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR);
+  int mode = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? kSolveRcp : 0;
   if (int rc = record(a, 0)) return rc;
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
 
   // ---- PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371) ----
   // Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
-  if (a->pending || older_ub > 0) {
+  // A failure up to and including the all-reduce leaves the update NOT done: only
+  // scratch (partials, red[]) has been written; f, the stored vectors, the lists and
+  // the host-side bookkeeping are untouched, so the same call may be repeated.
+  if (a->host_dot) {
+    RoctxRange range("nka:PA host dot products");
+    if (int rc = host_dot_sums(a, f)) return rc;
+    mode |= kSolvePrenorm;
+  } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
     const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
     const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
     for (int p = 0; p < npass; p++) {
-      if (vec == 2) launch_dots_w(maxl, a, f, p);
-      else launch_dots_1<4, 1>(a, f, p);
+      if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
+      else launch_dots_1<4, 1>(a, f, p, npass);
     }
     HIP_TRY(hipGetLastError());
     // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
@@ -411,48 +586,11 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
   RoctxRange range_tail("nka:solve + PB combine");
-  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
-    const size_t sm = solve_wave_smem_bytes(a->mvec);
-    const int ns = solve_pairs_per_lane(a->mvec);
-#define SOLVE(NS) hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, rcp ? 1 : 0)
-    if (ns <= 1) SOLVE(1);
-    else if (ns <= 2) SOLVE(2);
-    else if (ns <= 4) SOLVE(4);
-    else if (ns <= 6) SOLVE(6);
-    else if (ns <= 9) SOLVE(9);
-    else if (ns <= 13) SOLVE(13);
-    else SOLVE(19);
-#undef SOLVE
-  } else {
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, rcp ? 1 : 0);
-  }
-  HIP_TRY(hipGetLastError());
+  if (int rc = enqueue_solve(a, mode)) return rc;
   if (int rc = record(a, 2)) return rc;
 
-  // ---- PB: normalise + combine + ring stores (F08:282-283, 361, 395-404) ----
-  // after the subspace update the list holds at most min(list_ub, mvec) vectors
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
-  {
-    const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
-    const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
-    for (int p = 0; p < npass; p++) {
-      const int last = (p == npass - 1);
-      if (vec == 2) {
-        switch (a->flavor) {
-          case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_w<2, 1>(maxk, a, f, p, last); break;
-          case NKA_HIP_FLAVOR_C: launch_combine_w<2, 2>(maxk, a, f, p, last); break;
-          default: launch_combine_w<2, 0>(maxk, a, f, p, last);
-        }
-      } else {
-        switch (a->flavor) {
-          case NKA_HIP_FLAVOR_F08_VECTOR: launch_combine_1<4, 1, 1>(a, f, p, last); break;
-          case NKA_HIP_FLAVOR_C: launch_combine_1<4, 1, 2>(a, f, p, last); break;
-          default: launch_combine_1<4, 1, 0>(a, f, p, last);
-        }
-      }
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  if (int rc = enqueue_pb(a, f, vec, comb_ub)) return rc;
   if (int rc = record(a, 3)) return rc;
 
   if (a->timing_cap > 0) a->timing_count++;
@@ -498,7 +636,11 @@ int nka_hip_num_vec(nka_hip_t a) {
 
 int nka_hip_max_vec(nka_hip_t a) { return a ? a->mvec : fail(NKA_HIP_EINVAL, "null handle"); }
 int64_t nka_hip_vec_len(nka_hip_t a) { return a ? a->n : (int64_t)fail(NKA_HIP_EINVAL, "null handle"); }
-double nka_hip_vec_tol(nka_hip_t a) { return a ? a->vtol : 0.0; }
+double nka_hip_vec_tol(nka_hip_t a) {
+  if (a) return a->vtol;
+  fail(NKA_HIP_EINVAL, "null handle");
+  return -1.0;   // never a valid tolerance (vtol > 0)
+}
 
 int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t *first, int32_t *last,
                       int32_t *free_, int32_t *next, int32_t *prev, double *h, double *c) {
@@ -592,12 +734,20 @@ int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx) {
   return 0;
 }
 
+int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  a->host_dot = fn;
+  a->host_dot_ctx = fn ? ctx : nullptr;
+  return 0;
+}
+
 int nka_hip_comm_unique_id(void *id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
   if (!id128) return fail(NKA_HIP_EINVAL, "id buffer is NULL");
+  if (!rccl().ok()) return fail(NKA_HIP_ECOMM, rccl().err);
   ncclUniqueId id;
-  ncclResult_t r = ncclGetUniqueId(&id);
-  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  ncclResult_t r = rccl().GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
   memcpy(id128, &id, sizeof id);
   return 0;
 }
@@ -605,20 +755,75 @@ int nka_hip_comm_unique_id(void *id128) {
 int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank) {
   if (!a || !id128) return fail(NKA_HIP_EINVAL, "null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "bad rank / nranks");
+  if (!rccl().ok()) return fail(NKA_HIP_ECOMM, rccl().err);
   HIP_TRY(hipSetDevice(a->device));
   if (a->comm) {
-    ncclCommDestroy(a->comm);
+    rccl().CommDestroy(a->comm);
     a->comm = nullptr;
+    if (a->allreduce == rccl_allreduce) a->allreduce = nullptr;
   }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
-  ncclResult_t r = ncclCommInitRank(&a->comm, nranks, id, rank);
+  ncclResult_t r = rccl().CommInitRank(&a->comm, nranks, id, rank);
   if (r != ncclSuccess) {
     a->comm = nullptr;
-    return fail(NKA_HIP_ECOMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return fail(NKA_HIP_ECOMM, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
   }
   a->allreduce = rccl_allreduce;
   a->allreduce_ctx = a;
+  return 0;
+}
+
+int nka_hip_comm_destroy(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (a->comm) {
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    rccl().CommDestroy(a->comm);
+    a->comm = nullptr;
+  }
+  if (a->allreduce == rccl_allreduce) {
+    a->allreduce = nullptr;
+    a->allreduce_ctx = nullptr;
+  }
+  return 0;
+}
+
+int nka_hip_comm_library(char *path, int32_t len) {
+  if (!path || len <= 0) return fail(NKA_HIP_EINVAL, "bad buffer");
+  if (!rccl().ok()) return fail(NKA_HIP_ECOMM, rccl().err);
+  snprintf(path, (size_t)len, "%s", rccl().path.c_str());
+  return 0;
+}
+
+int nka_hip_allreduce_now(nka_hip_t a, double *buf_dev, int32_t count) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (count < 0) return fail(NKA_HIP_EINVAL, "negative count");
+  HIP_TRY(hipSetDevice(a->device));
+  if (int rc = nka_detail::check_device_span(buf_dev, count, "allreduce_now: buf")) return rc;
+  if (a->allreduce && count > 0)
+    if (int rc = a->allreduce(a->allreduce_ctx, buf_dev, count, a->stream))
+      return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+  return 0;
+}
+
+// FNV-1a over the two control blocks as they stand on the device.
+int nka_hip_state_digest(nka_hip_t a, uint64_t *digest) {
+  if (!a || !digest) return fail(NKA_HIP_EINVAL, "null argument");
+  std::vector<int32_t> ic;
+  std::vector<double> dc;
+  if (int rc = fetch_state(a, ic, dc)) return rc;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](const void *p, size_t nbytes) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < nbytes; i++) {
+      h ^= b[i];
+      h *= 1099511628211ull;
+    }
+  };
+  mix(ic.data(), ic.size() * sizeof(int32_t));
+  mix(dc.data(), dc.size() * sizeof(double));
+  *digest = h;
   return 0;
 }
 

@@ -262,14 +262,21 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 // per column (grid = 2*MAXL+2 blocks of 64): each lane sums its strided share in
 // order, then a butterfly -- the same bits on every run.
 constexpr int kFinThreads = 64;
+// `ncover` = entries of each row that the passes of this update write (npass*MAXL):
+// pass 0 zeroes the rest, so red[] never carries stale sums into the all-reduce.
 template <int MAXL>
 __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const double *__restrict__ partials, int G,
-                                                               int pass) {
+                                                               int pass, int ncover) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int base = pass * MAXL;
+  if (pass == 0 && c == 0)
+    for (int p = ncover + lane; p < ctl.mvec; p += kFinThreads) {
+      ctl.red()[2 + p] = 0.0;
+      ctl.red()[2 + ctl.mvec + p] = 0.0;
+    }
   int dst = -1;
   bool live = false;
   if (c < 2) {
@@ -540,7 +547,7 @@ __device__ inline void lst_load(Lst &L, const Ctl &ctl, unsigned char *smem) {
   __syncthreads();
 }
 
-__host__ __device__ inline size_t lst_smem_bytes(int mvec) {
+__host__ __device__ constexpr size_t lst_smem_bytes(int mvec) {
   const int m1 = mvec + 1;
   return (size_t)((m1 + 1) * (m1 + 1) + (m1 + 1)) * sizeof(double) + 2 * (size_t)(m1 + 1) * sizeof(int32_t);
 }
@@ -588,9 +595,17 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
   lst_store(L, ctl);
 }
 
-// The scalar part of accel_update between PA and PB.  `rcp` selects the
-// F08-vector flavour, whose normalisation is a multiplication by 1/s.
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int rcp) {
+// `mode` of the scalar step.  kSolveRcp: the F08-vector flavour, whose
+// normalisation is a multiplication by 1/s.  kSolvePrenorm: red[1] and the Gram
+// row red[2..] were already evaluated on the NORMALISED w1' (the host
+// dot-product path, nka_hip_set_host_dot) and are taken as they are.
+enum { kSolveRcp = 1, kSolvePrenorm = 2 };
+__device__ __forceinline__ double solve_nrm(double x, double s, double rs, int mode) {
+  return (mode & kSolvePrenorm) ? x : ((mode & kSolveRcp) ? rs * x : x / s);
+}
+
+// The scalar part of accel_update between PA and PB, reference loops verbatim on one lane.
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem);
@@ -613,14 +628,14 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     if (L.pending) {
       normed = true;
       // Gram row of w1' = d/s from the raw sums <d,w_k> of PA (F08:286-290)
-      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = rcp ? rs * red[2 + p] : red[2 + p] / s;
+      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = solve_nrm(red[2 + p], s, rs, mode);
       lst_factor(L);
     }
     const int slot = L.free_;
     L.free_ = L.next[slot];
     int ncomb = 0;
     if (L.subspace) {
-      if (normed) L.c[entry_first] = rcp ? rs * red[1] : red[1] / s;   // <f,w1'> = <f,d>/s
+      if (normed) L.c[entry_first] = solve_nrm(red[1], s, rs, mode);   // <f,w1'> = <f,d>/s
       for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
       lst_solve(L);
       for (int k = L.first; k != 0; k = L.next[k]) {
@@ -677,7 +692,7 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
 // wavefront issues ~1 instruction per 4-5 cycles, so instruction COUNT, not
 // latency, sets the run time here (NS = 19 for every mvec took 50 us at m = 20).
 template <int NS>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int rcp) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem);
@@ -712,10 +727,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int rcp) 
   {
     const double rs = 1.0 / s;
     for (int p = lane; p < nolder; p += kSolveThreads) {
-      if (normed) L.H(L.first, psL[p]) = rcp ? rs * redL[2 + p] : redL[2 + p] / s;   // F08:286-290
+      if (normed) L.H(L.first, psL[p]) = solve_nrm(redL[2 + p], s, rs, mode);         // F08:286-290
       L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
     }
-    if (normed && lane == 0) L.c[entry_first] = rcp ? rs * redL[1] : redL[1] / s;    // <f,w1'> = <f,d>/s
+    if (normed && lane == 0) L.c[entry_first] = solve_nrm(redL[1], s, rs, mode);     // <f,w1'> = <f,d>/s
   }
   int nl = 0;
   for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;

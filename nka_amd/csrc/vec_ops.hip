@@ -290,15 +290,20 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   HIP_TRYV(hipSetDevice(device));
   auto *ws = new nka_hip_vec_ws();
   ws->device = device;
-  hipDeviceProp_t prop;
-  HIP_TRYV(hipGetDeviceProperties(&prop, device));
-  ws->num_cu = prop.multiProcessorCount;
   ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
-  HIP_TRYV(hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1)));
-  HIP_TRYV(hipMalloc((void **)&ws->results, sizeof(double) * (2 * kManyMax + 1)));
-  HIP_TRYV(hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault));
-  HIP_TRYV(hipMalloc((void **)&ws->result, sizeof(double)));
-  HIP_TRYV(hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault));
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e == hipSuccess) ws->num_cu = prop.multiProcessorCount;
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->results, sizeof(double) * (2 * kManyMax + 1));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->result, sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {   // free whatever was obtained (hipFree / hipHostFree accept NULL)
+    nka_hip_vec_workspace_destroy(ws);
+    return nka_detail::set_error(e == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,
+                                 std::string("vec_workspace_create: ") + hipGetErrorString(e));
+  }
   *out = ws;
   return 0;
 }

@@ -26,13 +26,47 @@ def slice_bounds(n_global: int, world_size: int, rank: int):
     return lo, hi
 
 
-def broadcast_unique_id(make_id, rank: int, group=None) -> bytes:
+def broadcast_unique_id(make_id, rank: int, group=None):
     """Rank 0 creates the 128-byte RCCL unique id; everyone receives it through
-    torch.distributed (any backend)."""
+    torch.distributed (any backend).  If rank 0 cannot create it, every rank
+    receives the error text instead and raises the same exception."""
     import torch.distributed as dist
-    box = [make_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = ("ok", make_id())
+        except Exception as exc:      # noqa: BLE001 -- shipped to every rank below
+            box[0] = ("error", repr(exc))
     dist.broadcast_object_list(box, src=0, group=group)
-    return box[0]
+    kind, payload = box[0]
+    if kind != "ok":
+        raise RuntimeError(f"rank 0 could not create the RCCL unique id: {payload}")
+    return payload
+
+
+def all_agree(ok: bool, group=None) -> bool:
+    """True iff `ok` holds on EVERY rank (a collective MIN through
+    torch.distributed), so that a fallback decision is the same everywhere."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()) == 1)
+
+
+def check_allreduce(acc, rank: int, world_size: int) -> bool:
+    """One all-reduce through the hook installed on `acc`, on known values:
+    rank r contributes (r+1)*[1, 2, 3]; every rank must read N(N+1)/2*[1, 2, 3]."""
+    import torch
+    t = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, device=f"cuda:{acc._device}") * (rank + 1)
+    try:
+        acc.allreduce_now(t)
+        torch.cuda.synchronize(acc._device)
+        want = world_size * (world_size + 1) / 2.0
+        return bool((t.cpu() == torch.tensor([want, 2 * want, 3 * want], dtype=torch.float64)).all())
+    except Exception:     # noqa: BLE001 -- reported through all_agree by the caller
+        return False
 
 
 def attach_rccl(acc, rank: int, world_size: int, group=None):
@@ -43,9 +77,48 @@ def attach_rccl(acc, rank: int, world_size: int, group=None):
     return acc
 
 
+def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", group=None) -> str:
+    """Install the per-update all-reduce on `acc` and PROVE it before first use.
+    `prefer` = "rccl": the library's own communicator on the accelerator's stream
+    (lowest latency); if creating it or the test all-reduce fails on ANY rank,
+    every rank drops it and installs the torch.distributed hook instead -- the
+    decision is collective, so ranks can never disagree about who reduces with
+    whom.  Returns the hook in use ("rccl" or "torch").  Raises if the torch
+    hook fails its test as well."""
+    import sys
+    hook = prefer
+    if hook == "rccl":
+        ok = True
+        try:
+            attach_rccl(acc, rank, world_size, group)
+        except Exception as exc:      # noqa: BLE001
+            print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr)
+            ok = False
+        ok = all_agree(ok, group)
+        if ok:
+            ok = all_agree(check_allreduce(acc, rank, world_size), group)
+        if not ok:
+            if rank == 0:
+                print("[nka_amd.dist] RCCL hook unusable on at least one rank; every rank switches to the "
+                      "torch.distributed hook", file=sys.stderr)
+            try:
+                acc.drop_rccl()
+            except Exception:         # noqa: BLE001
+                pass
+            hook = "torch"
+    if hook == "torch":
+        attach_torch_allreduce(acc, group)
+        if not all_agree(check_allreduce(acc, rank, world_size), group):
+            raise RuntimeError("the torch.distributed all-reduce hook failed its self-test")
+    return hook
+
+
 def attach_torch_allreduce(acc, group=None):
     """Alternative hook: route the all-reduce through torch.distributed (RCCL
-    under the nccl backend) on a tensor aliasing the library's device buffer."""
+    under the nccl backend) on a tensor aliasing the library's device buffer.
+    The collective is issued under the stream the library passes in, so it is
+    ordered between the final sums of PA and the scalar step whatever stream the
+    accelerator was bound to."""
     import torch
     import torch.distributed as dist
 
@@ -54,8 +127,29 @@ def attach_torch_allreduce(acc, group=None):
             self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
     def hook(ptr, count, stream):
-        t = torch.as_tensor(_Alias(ptr, count), device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if stream:
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=acc._device))
+        else:       # 0 = HIP's default (null) stream
+            ctx = torch.cuda.stream(torch.cuda.default_stream(acc._device))
+        with ctx:
+            t = torch.as_tensor(_Alias(ptr, count), device=f"cuda:{acc._device}")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     acc.set_dot_prod(hook)
     return acc
+
+
+def replica_digests(acc, group=None):
+    """Digest of the replicated scalar state of `acc` from every rank (list of
+    ints, same on all ranks).  All entries equal <=> the ranks took the same
+    s == 0 / drop / slot decisions on the same all-reduced sums."""
+    import torch
+    import torch.distributed as dist
+    d = acc.state_digest()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [d]
+    dev = f"cuda:{acc._device}" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([d - (1 << 64) if d >= (1 << 63) else d], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [int(x.item()) & ((1 << 64) - 1) for x in out]

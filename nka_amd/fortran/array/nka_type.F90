@@ -14,9 +14,18 @@
 !!    (real(r8), intent(inout) :: f(:), F08:252) and copies f to the device and
 !!    back; accel_update_dev(f_dev) takes device memory (type(c_ptr)) and is the
 !!    entry a GPU-resident solver uses (no PCIe traffic, asynchronous).
-!!  * set_dot_prod (F08:209-214) becomes set_allreduce / use_rccl: the local
-!!    partial sums are already on the device, so the distribution hook is their
-!!    global SUM (one call per update, 2+2*mvec doubles), not a dot product.
+!!  * the FAST distribution hook is set_allreduce / use_rccl: the local partial
+!!    sums are already on the device, so what a sharded run needs is their global
+!!    SUM (one call per update, 2+2*mvec doubles), not a dot product.
+!!    set_dot_prod(dot_prod) (F08:209-219) is kept for source compatibility,
+!!    same abstract interface: the update then evaluates the reference's own
+!!    sequence of dot_prod calls on HOST copies of the operands (2+L vectors cross
+!!    PCIe per update; the scalar step, the combine and the stores stay on the
+!!    device) -- a slow path for callers that cannot change, see
+!!    nka_hip_set_host_dot in include/nka_hip.h.
+!!  * the object is a HANDLE and cannot be copied: intrinsic assignment of one
+!!    nka to another would duplicate the handle (double free); the defined
+!!    assignment below stops with a message instead.  Pass objects by reference.
 !!  * init takes optional flavor / device / stream arguments.
 
 module nka_type
@@ -27,12 +36,28 @@ module nka_type
   implicit none
   private
 
+  !! user dot product, the reference's interface (F08:216-219: assumed-shape x, y)
+  abstract interface
+    function dp(x, y)
+      import :: r8
+      real(r8), intent(in) :: x(:), y(:)
+      real(r8) :: dp
+    end function
+  end interface
+
+  !! what the C-side trampoline needs to find the user's procedure again
+  type :: dp_holder
+    procedure(dp), pointer, nopass :: fn => null()
+  end type
+
   type, public :: nka
     private
     type(c_ptr) :: handle = c_null_ptr
+    type(dp_holder), pointer :: user_dp => null()
   contains
     procedure :: init
     procedure :: set_vec_tol
+    procedure :: set_dot_prod
     procedure :: set_allreduce
     procedure :: use_rccl
     procedure :: vec_len
@@ -46,6 +71,8 @@ module nka_type
     procedure :: defined
     procedure :: set_timing
     procedure :: get_timing
+    procedure, private :: no_copy
+    generic :: assignment(=) => no_copy
     final :: nka_delete
   end type nka
 
@@ -77,7 +104,39 @@ contains
     integer(c_int) :: rc
     if (c_associated(this%handle)) rc = nka_hip_destroy(this%handle)
     this%handle = c_null_ptr
+    if (associated(this%user_dp)) deallocate(this%user_dp)
   end subroutine
+
+  !! The reference type has allocatable components and copies deeply; this one is
+  !! a device handle.  A copy would alias it and free it twice.
+  subroutine no_copy(lhs, rhs)
+    class(nka), intent(inout) :: lhs
+    class(nka), intent(in) :: rhs
+    error stop 'nka (device handle) cannot be copied by assignment; pass the object by reference'
+  end subroutine
+
+  !! call a%set_dot_prod(dot_prod)                             F08:209-214
+  !! dot_prod must return the GLOBAL dot product of its arguments (F08:58-64).
+  subroutine set_dot_prod(this, dot_prod)
+    class(nka), intent(inout) :: this
+    procedure(dp), pointer, intent(in) :: dot_prod
+    if (.not.associated(dot_prod)) error stop 'nka%set_dot_prod: dot_prod is not associated'   ! F08:212
+    if (.not.associated(this%user_dp)) allocate(this%user_dp)
+    this%user_dp%fn => dot_prod
+    call nka_hip_check(nka_hip_set_host_dot(this%handle, c_funloc(host_dot_trampoline), c_loc(this%user_dp)), &
+                       'nka%set_dot_prod')
+  end subroutine
+
+  !! nka_hip_host_dot_fn: C calls this with host copies of the operands.
+  function host_dot_trampoline(ctx, n, x, y) bind(C) result(d)
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), value :: n
+    real(c_double), intent(in) :: x(*), y(*)
+    real(c_double) :: d
+    type(dp_holder), pointer :: h
+    call c_f_pointer(ctx, h)
+    d = h%fn(x(1:n), y(1:n))
+  end function
 
   subroutine nka_delete(this)
     type(nka), intent(inout) :: this

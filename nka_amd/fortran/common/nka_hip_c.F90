@@ -70,6 +70,20 @@ module nka_hip_c
       type(c_ptr), value :: handle, ctx
       type(c_funptr), value :: fn
     end function
+    integer(c_int) function nka_hip_set_host_dot(handle, fn, ctx) bind(C)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: handle, ctx
+      type(c_funptr), value :: fn
+    end function
+    integer(c_int) function nka_hip_state_digest(handle, digest) bind(C)
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: handle
+      integer(c_int64_t), intent(out) :: digest
+    end function
+    integer(c_int) function nka_hip_comm_destroy(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
     integer(c_int) function nka_hip_comm_unique_id(id128) bind(C)
       import :: c_int, c_char
       character(kind=c_char), intent(out) :: id128(128)

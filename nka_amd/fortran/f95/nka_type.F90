@@ -8,9 +8,11 @@
 !! is a handle; every vector and the scalar step live on the GPU.
 !!
 !! The reference's optional per-call dummy procedure DP (src-F95/nka_type.F90:
-!! 284-291) is a host dot product and cannot see device memory; the device
-!! equivalent is installed once with nka_set_allreduce (see the array flavour).
-!! nka_accel_update_dev takes device memory (type(c_ptr)).
+!! 284-291) is kept with its interface: when present, the inner products of THAT
+!! call are evaluated by DP on host copies of the operands, in the reference's
+!! own order (slow compatibility path, nka_hip_set_host_dot in include/nka_hip.h).
+!! The fast distribution hook is nka_set_allreduce (global sum of the device
+!! partial sums).  nka_accel_update_dev takes device memory (type(c_ptr)).
 
 module nka_type
 
@@ -25,6 +27,17 @@ module nka_type
     private
     type(c_ptr) :: handle = c_null_ptr
   end type nka
+
+  !! the dummy DP of the nka_accel_update call in progress (the object is not
+  !! thread safe in the reference either, SURVEY.md 8b)
+  abstract interface
+    pure function dp_iface(x, y)
+      integer, parameter :: r8 = selected_real_kind(15)
+      real(r8), intent(in) :: x(:), y(:)
+      real(r8) :: dp_iface
+    end function
+  end interface
+  procedure(dp_iface), pointer, save :: call_dp => null()
 
   public :: nka_init, nka_delete, nka_set_vec_tol, nka_defined
   public :: nka_vec_len, nka_num_vec, nka_max_vec, nka_vec_tol, nka_real_kind
@@ -60,19 +73,47 @@ contains
     call nka_hip_check(nka_hip_set_allreduce(this%handle, fn, ctx), 'nka_set_allreduce')
   end subroutine
 
-  subroutine nka_accel_update(this, f)                        ! :278-473 (host array)
+  subroutine nka_accel_update(this, f, dp)                    ! :278-473 (host array)
     type(nka), intent(inout) :: this
     real(r8), intent(inout) :: f(:)
+    !! Optional dot product to use instead of the device sums (:284-291).
+    interface
+      pure function dp(x, y)
+        integer, parameter :: r8 = selected_real_kind(15)
+        real(r8), intent(in) :: x(:), y(:)
+        real(r8) :: dp
+      end function dp
+    end interface
+    optional :: dp
     real(r8), allocatable :: tmp(:)
+    integer(c_int) :: rc
     if (size(f) /= nka_vec_len(this)) stop 'nka_accel_update: size(f) /= nka_vec_len(this)'
+    if (present(dp)) then
+      call_dp => dp
+      call nka_hip_check(nka_hip_set_host_dot(this%handle, c_funloc(per_call_dot), c_null_ptr), 'nka_accel_update')
+    end if
     if (is_contiguous(f)) then
-      call nka_hip_check(nka_hip_accel_update_host(this%handle, f), 'nka_accel_update')
+      rc = nka_hip_accel_update_host(this%handle, f)
     else
       tmp = f
-      call nka_hip_check(nka_hip_accel_update_host(this%handle, tmp), 'nka_accel_update')
+      rc = nka_hip_accel_update_host(this%handle, tmp)
       f = tmp
     end if
+    if (present(dp)) then
+      call nka_hip_check(nka_hip_set_host_dot(this%handle, c_null_funptr, c_null_ptr), 'nka_accel_update')
+      call_dp => null()
+    end if
+    call nka_hip_check(rc, 'nka_accel_update')
   end subroutine
+
+  !! nka_hip_host_dot_fn for the duration of ONE nka_accel_update call
+  function per_call_dot(ctx, n, x, y) bind(C) result(d)
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), value :: n
+    real(c_double), intent(in) :: x(*), y(*)
+    real(c_double) :: d
+    d = call_dp(x(1:n), y(1:n))
+  end function
 
   subroutine nka_accel_update_dev(this, f_dev)
     type(nka), intent(inout) :: this

@@ -7,6 +7,14 @@
 !!       dependence drops occur) and writes, per call, num_vec and the returned
 !!       vector to OUTFILE (stream, native real64) for tests/test_fortran_gpu.py
 !!       to compare with the oracle's F08-vector flavour.
+!!   nka_vector_driver checktile NFIELD NPER MVEC NCALLS OUTFILE COMPACT R
+!!       the same at BASELINE size without a BASELINE-size oracle: the small LCG
+!!       input x of length n0 = NFIELD*NPER is tiled R times into a block vector
+!!       of NFIELD fields of NPER*R (X(i) = x(mod(i,n0))).  Every inner product is
+!!       R times the small one, so with R = 4^k the returned vector is the tiled
+!!       small result up to the rounding of the sums (tests/test_hip_fullsize.py).
+!!       Written per call: x, num_vec, the FIRST tile of the result, and the
+!!       2-norm of (result - tiled first tile), which must be exactly zero.
 !!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
@@ -21,7 +29,7 @@ program nka_vector_driver
   implicit none
 
   character(256) :: mode, arg, outfile
-  integer :: nfield, mvec, ncalls, icompact = 0
+  integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1
   logical :: compact
   integer(i8) :: nper
   integer(i8) :: lcg_state = 1
@@ -39,6 +47,12 @@ program nka_vector_driver
     end if
     compact = icompact /= 0
     call run_check
+  case ('checktile')
+    call get_command_argument(6, outfile)
+    call get_command_argument(7, arg); read(arg,*) icompact
+    call get_command_argument(8, arg); read(arg,*) rtile
+    compact = icompact /= 0
+    call run_checktile
   case ('bench')
     if (command_argument_count() >= 6) then
       call get_command_argument(6, arg); read(arg,*) icompact
@@ -99,6 +113,62 @@ contains
     close(lun)
     if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
     write(*,'(a,i0,a,i0)') 'check: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
+  end subroutine
+
+  subroutine run_checktile
+    type(hip_block_vector) :: f
+    type(nka) :: accel
+    type(c_ptr) :: ws
+    real(r8), allocatable :: small(:), big(:), pool(:,:), coef(:)
+    real(r8) :: dev
+    integer :: t, k, lun, r
+    integer(i8) :: n0, nbig, nperbig, i
+    n0 = nfield * nper
+    nbig = n0 * rtile
+    nperbig = nper * rtile
+    ws = hip_block_vector_workspace(0)
+    call f%init(nfield, nperbig, ws)
+    call accel%init(f, mvec, compact=compact)
+    allocate(small(n0), big(nbig), pool(n0,3), coef(3))
+    do k = 1, 3
+      do i = 1, n0
+        pool(i,k) = lcg()
+      end do
+    end do
+    open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    do t = 1, ncalls
+      if (mod(t, 7) == 0) then
+        do k = 1, 3
+          coef(k) = lcg()
+        end do
+        small = coef(1)*pool(:,1) + coef(2)*pool(:,2) + coef(3)*pool(:,3)
+      else
+        do i = 1, n0
+          small(i) = lcg()
+        end do
+      end if
+      write(lun) small
+      do r = 0, rtile-1
+        big(r*n0+1:(r+1)*n0) = small
+      end do
+      do k = 1, nfield
+        call f%set_field(k, big((k-1)*nperbig+1:k*nperbig))
+      end do
+      call accel%accel_update(f)
+      do k = 1, nfield
+        call f%get_field(k, big((k-1)*nperbig+1:k*nperbig))
+      end do
+      dev = 0.0_r8
+      do r = 1, rtile-1
+        dev = dev + sum((big(r*n0+1:(r+1)*n0) - big(1:n0))**2)
+      end do
+      write(lun) real(accel%num_vec(), r8)
+      write(lun) big(1:n0)
+      write(lun) sqrt(dev)
+    end do
+    close(lun)
+    if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
+    write(*,'(a,i0,a,i0,a,i0)') 'checktile: n = ', nbig, ', wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
   end subroutine
 
   subroutine run_bench

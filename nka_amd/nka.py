@@ -58,6 +58,7 @@ class nka:  # noqa: N801  (the reference's type name)
         self._h = None
         self._L = _lib.load()      # raises if the HIP library is missing: no CPU path
         self._cb = None
+        self._hd = None
 
     # -- call a%init(vlen, mvec)                      F08:185-200
     def init(self, vlen: int, mvec: int, *, flavor: int = FLAVOR_F08, device: int | None = None,
@@ -126,10 +127,51 @@ class nka:  # noqa: N801  (the reference's type name)
         self._cb = _lib.ALLREDUCE_FN(tramp)
         _check(self._L.nka_hip_set_allreduce(self._handle(), self._cb, None), "set_allreduce")
 
+    def set_host_dot(self, dot):
+        """Source compatibility with the reference's user dot product
+        (set_dot_prod(dp), F08:209-219): dot(x, y) -> float over HOST numpy views
+        of this rank's slices, returning the GLOBAL dot product.  The update then
+        evaluates its inner products by calling it in the reference's order on host
+        copies (slow, synchronous: see nka_hip_set_host_dot).  None restores the
+        device sums."""
+        if dot is None:
+            self._hd = None
+            _check(self._L.nka_hip_set_host_dot(self._handle(), C.cast(None, _lib.HOST_DOT_FN), None), "set_host_dot")
+            return
+
+        def tramp(_ctx, n, x, y):
+            xa = np.ctypeslib.as_array(x, shape=(n,)) if n else np.zeros(0)
+            ya = np.ctypeslib.as_array(y, shape=(n,)) if n else np.zeros(0)
+            return float(dot(xa, ya))
+
+        self._hd = _lib.HOST_DOT_FN(tramp)
+        _check(self._L.nka_hip_set_host_dot(self._handle(), self._hd, None), "set_host_dot")
+
     def use_rccl(self, unique_id: bytes, nranks: int, rank: int):
-        """Built-in hook: one RCCL all-reduce per Gram row on the object's stream."""
+        """Built-in hook: ONE RCCL all-reduce per update on the object's stream."""
         buf = C.create_string_buffer(unique_id, 128)
         _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank")
+
+    def drop_rccl(self):
+        _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy")
+
+    @staticmethod
+    def rccl_library() -> str:
+        """Path of the RCCL shared object the library bound (one copy per process)."""
+        buf = C.create_string_buffer(1024)
+        _check(_lib.load().nka_hip_comm_library(buf, 1024), "comm_library")
+        return buf.value.decode()
+
+    def allreduce_now(self, t):
+        """Run the installed all-reduce hook on a float64 CUDA tensor (in place)."""
+        _check(self._L.nka_hip_allreduce_now(self._handle(), C.c_void_p(t.data_ptr()), int(t.numel())), "allreduce_now")
+        return t
+
+    def state_digest(self) -> int:
+        """Digest of the replicated scalar state; equal on every rank of a sharded run."""
+        d = C.c_uint64()
+        _check(self._L.nka_hip_state_digest(self._handle(), C.byref(d)), "state_digest")
+        return int(d.value)
 
     @staticmethod
     def rccl_unique_id() -> bytes:

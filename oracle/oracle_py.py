@@ -309,6 +309,7 @@ class RefC:
             L.nka_accel_update.argtypes = [C.c_void_p, _dp]
             L.nka_num_vec.argtypes = [C.c_void_p]
             L.ref_c_get_state.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _dp]
+            L.ref_c_set_vec_tol.argtypes = [C.c_void_p, C.c_double]
             L.ref_c_w.argtypes = [C.c_void_p, C.c_int]
             L.ref_c_w.restype = _dp
             L.ref_c_v.argtypes = [C.c_void_p, C.c_int]
@@ -321,6 +322,11 @@ class RefC:
         if getattr(self, "_h", None):
             RefC._L.nka_delete(self._h)
             self._h = None
+
+    def set_vec_tol(self, vtol: float):
+        """Not in the C API (vtol is a constructor argument, .c:211): writes the field
+        the drop test reads (.c:362) -- see oracle/ref_c_shim.c."""
+        RefC._L.ref_c_set_vec_tol(self._h, float(vtol))
 
     def accel_update(self, f):
         RefC._L.nka_accel_update(self._h, _ptr(f))

@@ -34,5 +34,11 @@ void ref_c_get_state(NKA a, int *subspace, int *pending, int *first, int *last, 
     for (int i = 0; i < n; i++) h[i + (size_t)j * n] = a->h[i][j];
 }
 
+/* The C API fixes vtol at construction (.c:211); the Fortran flavours can change
+ * it mid-stream (set_vec_tol, F08:202-207).  The drop test reads state->vtol on
+ * every update (.c:362), so scenarios with a mid-stream change are replayed on
+ * the C reference by writing the field. */
+void ref_c_set_vec_tol(NKA a, double vtol) { a->vtol = vtol; }
+
 const double *ref_c_w(NKA a, int slot1) { return a->w[slot1 - 1]; }
 const double *ref_c_v(NKA a, int slot1) { return a->v[slot1 - 1]; }

@@ -29,9 +29,13 @@ class _Alias:
 
 
 def main():
+    # NKA_TEST_RCCL=1 (two-GPU boxes): one GPU per rank and the library's own RCCL
+    # all-reduce on the kernel stream, installed and proven by nd.attach_allreduce;
+    # default: both ranks share cuda:0 and the hook stages through gloo (see above)
+    use_rccl = os.environ.get("NKA_TEST_RCCL") == "1"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank if use_rccl else 0)
     n, m, calls = 200003, 6, 16
     lo, hi = nd.slice_bounds(n, world, rank)
     counts = []
@@ -45,7 +49,11 @@ def main():
 
     for flavor in (nka_amd.FLAVOR_F08, nka_amd.FLAVOR_C):
         acc = nka_amd.nka().init(hi - lo, m, flavor=flavor)
-        acc.set_dot_prod(hook)
+        if use_rccl:
+            which = nd.attach_allreduce(acc, rank, world, prefer="rccl")
+            assert which == "rccl", which
+        else:
+            acc.set_dot_prod(hook)
         full = O.OracleNKA(n, m, flavor)
         basis = np.stack([synth.fill_numpy(3, 50 + j, 0, n, n) for j in range(3)])
         for t in range(calls):
@@ -64,15 +72,18 @@ def main():
             dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
             assert torch.equal(cmax, cmin), (rank, flavor, t)
+            digs = nd.replica_digests(acc)
+            assert all(d == digs[0] for d in digs), (rank, flavor, t, digs)
             piv = min([abs(st.h[k - 1, k - 1]) for k in st.list_order()[1:]] + [1.0])
             err = np.linalg.norm(out - f_full[lo:hi]) / np.linalg.norm(x)
-            assert err <= 1e-12 / piv**2, (rank, flavor, t, err)
+            assert err <= (1e-12 if piv > 0.5 else 1e-12 / piv**2), (rank, flavor, t, err, piv)
             if t == 9:
                 acc.relax(); full.relax()
         assert acc.defined()
         acc.delete()
-    assert set(counts) == {2 + 2 * m}
-    print(f"rank {rank}/{world} slice [{lo},{hi}) OK", flush=True)
+    if not use_rccl:
+        assert set(counts) == {2 + 2 * m}
+    print(f"rank {rank}/{world} slice [{lo},{hi}) hook={'rccl' if use_rccl else 'gloo-staged'} OK", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

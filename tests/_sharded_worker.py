@@ -30,6 +30,20 @@ def main():
     uid = nd.broadcast_unique_id(lambda: bytes(range(128)), rank)
     assert uid == bytes(range(128))
 
+    # a failure on rank 0 reaches EVERY rank as the same exception (no rank is left waiting)
+    def boom():
+        raise OSError("no RCCL here")
+    try:
+        nd.broadcast_unique_id(boom, rank)
+        raise AssertionError("expected a RuntimeError on every rank")
+    except RuntimeError as exc:
+        assert "no RCCL here" in str(exc)
+
+    # collective agreement: one dissenting rank turns the decision on all ranks
+    assert nd.all_agree(True) is True
+    assert nd.all_agree(rank != world - 1) is False
+    assert nd.all_agree(False) is False
+
     def global_dot(x, y):
         t = torch.tensor([float(np.dot(x, y))], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

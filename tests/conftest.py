@@ -26,3 +26,23 @@ def oracle():
     from oracle import oracle_py
     oracle_py.lib()
     return oracle_py
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Worst observed parity error per test (tests/parity_util.py)."""
+    try:
+        import parity_util as P
+    except Exception:
+        return
+    if not P.WORST:
+        return
+    path = P.dump(ROOT)
+    tr = terminalreporter
+    tr.write_sep("-", "worst observed parity errors (||f_hip - f_ref|| / ||f_in||)")
+    for key in sorted(P.WORST):
+        r = P.WORST[key]
+        piv = "   -  " if r["pivot"] is None else f"{r['pivot']:6.3f}"
+        tr.write_line(f"{key:<78s} worst {r['err']:.2e} (tol {r['tol']:.1e}, pivot {piv}); "
+                      f"well-conditioned worst {r['worst_well_conditioned']:.2e}; {r['checks']} checks")
+    if path:
+        tr.write_line(f"written to {path}")

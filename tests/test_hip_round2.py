@@ -1,0 +1,220 @@
+"""GPU tests of what round 2 added to the boundary: the user dot-product
+callback (set_dot_prod compatibility), the replicated-state digest, the large
+mvec range, the scratch hygiene of red[], and a real two-GPU RCCL run."""
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parity_util as P
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def pairwise_dot(x, y):
+    """A user dot product that is NOT the intrinsic one: pairwise summation."""
+    p = x * y
+    while p.size > 1:
+        if p.size % 2:
+            p = np.append(p, 0.0)
+        p = p[0::2] + p[1::2]
+    return float(p[0]) if p.size else 0.0
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cuda, oracle, flavor):
+    """set_dot_prod(dp) (F08:209-219): with the same user dp installed on the
+    oracle (its reference-faithful set_dot_prod) and on the HIP path
+    (nka_hip_set_host_dot), the device evaluates the reference's own dp calls on
+    host copies of bit-identical operands, so results agree BIT FOR BIT --
+    dependent inputs (drops), a repeated input (s == 0 -> relax), relax and
+    restart included."""
+    import nka_amd
+    n, m = 1031, 5
+    X = oracle.lcg_vectors(14, n, seed=5)
+    basis = oracle.lcg_vectors(3, n, seed=9)
+    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    ora = oracle.OracleNKA(n, m, flavor)
+    calls = [0, 0]
+
+    def dp_a(x, y):
+        calls[0] += 1
+        return pairwise_dot(x, y)
+
+    def dp_o(x, y):
+        calls[1] += 1
+        return pairwise_dot(np.asarray(x), np.asarray(y))
+
+    acc.set_host_dot(dp_a)
+    ora.set_dot_prod(dp_o)
+    coef = oracle.lcg_vectors(4, 3, seed=2)
+    for t in range(18):
+        if t % 5 == 3:
+            x = coef[t % 4] @ basis
+        elif t == 7:
+            x = prev.copy()
+        else:
+            x = X[t % 14].copy() * (1.0 + t)
+        prev = x
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        out = ft.cpu().numpy()
+        assert acc.num_vec() == ora.num_vec(), t
+        assert acc.state().list_order() == ora.state().list_order(), t
+        assert np.array_equal(out, f), (flavor, t, np.abs(out - f).max())
+        if t == 10:
+            acc.relax(); ora.relax()
+        if t == 14:
+            acc.restart(); ora.restart()
+    assert calls[0] > 0 and calls[1] > 0
+    # back to the device sums: results stay within tolerance of the oracle with the default dp
+    acc.set_host_dot(None)
+    ora2 = oracle.OracleNKA(n, m, flavor)
+    acc.restart()
+    for t in range(8):
+        x = X[t].copy()
+        f = x.copy()
+        ora2.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"after set_host_dot(None) flavor {flavor}", where=t)
+
+
+def test_state_digest_tracks_the_replicated_state(torch_cuda):
+    import nka_amd
+    n, m = 4099, 4
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((9, n))
+    a, b = nka_amd.nka().init(n, m), nka_amd.nka().init(n, m)
+    assert a.state_digest() == b.state_digest()
+    for t in range(9):
+        for acc in (a, b):
+            acc.accel_update(torch_cuda.from_numpy(X[t].copy()).cuda())
+        assert a.state_digest() == b.state_digest(), t
+    d0 = a.state_digest()
+    y = X[3].copy()
+    y[17] += 1e-9
+    a.accel_update(torch_cuda.from_numpy(X[3].copy()).cuda())
+    b.accel_update(torch_cuda.from_numpy(y).cuda())
+    assert a.state_digest() != d0
+    assert a.state_digest() != b.state_digest()     # one perturbed element changes the sums
+
+
+@pytest.mark.parametrize("m", [47, 48, 90, 140])
+def test_large_mvec_up_to_the_lds_limit(torch_cuda, oracle, m):
+    """mvec up to the documented limit of 140: the wavefront solve (mvec+1 <= 48),
+    the one-lane solve beyond, and the opt-in above 64 KiB of dynamic LDS (mvec >= 88)."""
+    import nka_amd
+    n = 600
+    rng = np.random.default_rng(m)
+    acc, ora = nka_amd.nka().init(n, m), oracle.OracleNKA(n, m)
+    basis = rng.standard_normal((3, n))
+    for t in range(m + 6):
+        x = rng.standard_normal(n) if t % 11 != 7 else rng.standard_normal(3) @ basis
+        f = x.copy()
+        ora.accel_update(f)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert acc.num_vec() == ora.num_vec(), t
+        if t % 8 == 0 or t > m:
+            assert acc.state().list_order() == ora.state().list_order(), t
+            P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t)
+    assert acc.defined() and acc.num_vec() == m
+
+
+def test_mvec_beyond_the_lds_limit_is_refused_with_a_clear_message(torch_cuda):
+    import nka_amd
+    with pytest.raises(nka_amd.NKAError, match="mvec <= 140"):
+        nka_amd.nka().init(100, 141)
+
+
+def test_reduction_scratch_is_rewritten_or_zeroed_every_update(torch_cuda):
+    """red[] is summed in place by the all-reduce: entries the current (short) list
+    does not cover must not keep sums of an earlier, longer list."""
+    import nka_amd
+    n, m = 3000, 12
+    rng = np.random.default_rng(3)
+    acc = nka_amd.nka().init(n, m)
+    for t in range(m + 3):
+        acc.accel_update(torch_cuda.from_numpy(rng.standard_normal(n)).cuda())
+    red = acc.reductions()
+    assert np.all(red[2:2 + m] != 0.0) and np.all(red[2 + m:] != 0.0)
+    acc.restart()
+    for t in range(3):
+        acc.accel_update(torch_cuda.from_numpy(rng.standard_normal(n)).cuda())
+    red = acc.reductions()
+    live = 1                                           # one older entry besides the pending pair at the third call
+    assert np.all(red[2 + live:2 + m] == 0.0), red
+    assert np.all(red[2 + m + live:] == 0.0), red
+
+
+def test_rccl_is_bound_once_and_reports_its_library(torch_cuda):
+    import nka_amd
+    path = nka_amd.nka.rccl_library()
+    assert "librccl" in path
+    maps = open("/proc/self/maps").read()
+    loaded = {ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln}
+    assert len(loaded) == 1, loaded                    # exactly one RCCL in this process (torch's, imported first)
+    assert os.path.realpath(path) in {os.path.realpath(p) for p in loaded}
+
+
+def test_vec_tol_on_a_null_handle_is_an_error_not_zero(torch_cuda):
+    import nka_amd
+    L = nka_amd.load()
+    assert L.nka_hip_vec_tol(None) == -1.0
+    assert b"null handle" in L.nka_hip_last_error()
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_two_gpu_rccl_sharded_run(torch_cuda):
+    """Row (e) with the real collective: two ranks on two GPUs, the library's own
+    RCCL communicator (ncclAllReduce over xGMI on the kernel stream), against the
+    unsharded oracle; replicated state digests equal on both ranks.  Skips on the
+    one-GPU boxes."""
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NKA_TEST_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_gpu_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-5000:]
+    assert p.stdout.count(" OK") == 2
+    assert "hook=rccl" in p.stdout
+
+
+def test_bench_two_gpus(torch_cuda):
+    """bench.py --gpus 2 launched the way the driver launches it (small n)."""
+    import json
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--vlen",
+           "4e6", "--mvec", "6", "--steps", "5"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["steady_state"]
+    assert all(c["identical"] for c in d["replica_check"])
+    assert 0.0 < d["roofline"]["frac"] <= 1.0
