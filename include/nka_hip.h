@@ -200,6 +200,12 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */
 int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
+/* Kernel-variant switches for A/B measurements inside one process (same
+ * allocations, same thermal state): "pb_pipe" = 0 (k_combine), 2 or 4
+ * (k_combine_pipe with that many load groups); "serial_solve" = 0/1.  Results are
+ * bit-identical across variants. */
+int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
+
 const char *nka_hip_last_error(void);
 /* "gfx950"-style name of the device the handle runs on, CU count. */
 int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
@@ -228,10 +234,10 @@ int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const doubl
 int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *host_result);    /* norm2   */
 /* Batched forms (optional overrides of vector%dot_many / vector%update_many,
  * nka_amd/fortran/vector/vector_class.F90): ys / xs are HOST arrays of `count`
- * device pointers.  dot_many: vals[j] = <x, ys[j]> with x read once per 16
+ * device pointers.  dot_many: vals[j] = <x, ys[j]> with x read once per 24
  * vectors.  update_many: z <- (a[j]*xs[j] + b[j]*ys[j]) + z for j = 0..count-1
  * in order -- the rounding of `count` successive update3_ calls -- with z read
- * and written once per 16 pairs. */
+ * and written once per 24 pairs. */
 int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys,
                          int32_t count, double *host_vals);
 /* Both rows of the Gram update in one pass: vals0[j] = <x0, ys[j]>,
@@ -244,6 +250,29 @@ int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const dou
 /* z <- a[j]*xs[j] + z for j = 0..count-1 in order (override of vector%axpy_many). */
 int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                           const double *const *xs, int32_t count);
+/* Fused stages of the vector-flavour update (optional overrides of
+ * vector%update_norm2 / scale_dot_pair_many / update_many_keep / axpy_many_keep;
+ * each default body is the reference's own hook sequence, F08V:237-238, 255-264 +
+ * 347, 336 + 374 + 382).  Elementwise results are rounded like those hook calls.
+ *   update_norm2:        z <- a*x + z ; *host_norm = ||z||_2
+ *   scale_dot_pair_many: w <- a*w ; v <- a*v (subtract: v <- (-1)*w + v) ; then with
+ *                        the new w: vals_w[j] = <w,ys[j]>, vals_f[j] = <f,ys[j]>,
+ *                        *cross = <f,w>
+ *   update_many_keep:    keep_in <- z ; z <- (a[j]*xs[j] + b[j]*ys[j]) + z in order ;
+ *                        keep_out <- z          (keep_in / keep_out may be NULL)
+ *   axpy_many_keep:      the same with z <- a[j]*xs[j] + z
+ * With them an update of the abstract path moves 8n(12+3m) bytes in 3 passes. */
+int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
+                             double *host_norm);
+int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a,
+                                    int32_t subtract, const double *f, const double *const *ys,
+                                    int32_t count, double *host_vals_w, double *host_vals_f,
+                                    double *host_cross);
+int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                                 const double *const *xs, const double *b, const double *const *ys,
+                                 int32_t count, double *keep_in, double *keep_out);
+int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                               const double *const *xs, int32_t count, double *keep_in, double *keep_out);
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
 int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 

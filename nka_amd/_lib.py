@@ -44,6 +44,7 @@ SIGNATURES = {
     "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nka_hip_last_error": (C.c_char_p, []),
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
@@ -65,6 +66,13 @@ SIGNATURES = {
     "nka_hip_vec_update_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                           C.POINTER(C.c_void_p), C.c_int32]),
     "nka_hip_vec_axpy_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32]),
+    "nka_hip_vec_update_norm2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, _dp]),
+    "nka_hip_vec_scale_dot_pair_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
+                                                  C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp]),
+    "nka_hip_vec_update_many_keep": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
+                                               C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p]),
+    "nka_hip_vec_axpy_many_keep": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32,
+                                             C.c_void_p, C.c_void_p]),
     "nka_hip_vec_h2d": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nka_hip_vec_d2h": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

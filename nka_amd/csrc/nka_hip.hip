@@ -150,6 +150,7 @@ struct nka_hip_state {
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
+  int pb_pipe = 0;            // groups of the software-pipelined PB (0 = k_combine, 2 or 4 = k_combine_pipe)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
@@ -239,6 +240,34 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
   return 0;
 }
 
+template <int MAXK, int COMB, int NG>
+int launch_combine_pipe_1(const nka_hip_state *a, double *f) {
+  static const int occ = occupancy_of(k_combine_pipe<MAXK, COMB, NG>);
+  const int g = grid_for(a, 1, 2, occ, (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1));
+  hipLaunchKernelGGL((k_combine_pipe<MAXK, COMB, NG>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
+  return g;
+}
+
+template <int COMB, int NG>
+int launch_combine_pipe_w(int maxk, const nka_hip_state *a, double *f) {
+#define CASE(K) \
+  case K: return launch_combine_pipe_1<K, COMB, NG>(a, f);
+  switch (maxk) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
+}
+
+template <int NG>
+int launch_combine_pipe(int flavor, int maxk, const nka_hip_state *a, double *f) {
+  switch (flavor) {
+    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_pipe_w<1, NG>(maxk, a, f);
+    case NKA_HIP_FLAVOR_C: return launch_combine_pipe_w<2, NG>(maxk, a, f);
+    default: return launch_combine_pipe_w<0, NG>(maxk, a, f);
+  }
+}
+
 int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
 
 // Optional ROCTx ranges around the phases of an update (NKA_HIP_ROCTX=1), for
@@ -322,6 +351,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
+  a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
@@ -480,6 +510,12 @@ static int enqueue_solve(nka_hip_t a, int mode) {
 static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
   const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
+  if (vec == 2 && npass == 1 && a->pb_pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
+    if (a->pb_pipe >= 4) launch_combine_pipe<4>(a->flavor, maxk, a, f);
+    else launch_combine_pipe<2>(a->flavor, maxk, a, f);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   for (int p = 0; p < npass; p++) {
     const int last = (p == npass - 1);
     if (vec == 2) {
@@ -865,6 +901,20 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   for (int i = 0; i < 2; i++) {
     if (v[i] < 0 || v[i] * a->num_cu > kMaxGrid) return fail(NKA_HIP_EINVAL, "blocks per CU out of range");
     a->bpc[i] = v[i];   // 0 = automatic
+  }
+  return 0;
+}
+
+int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
+  if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
+  const std::string k(key);
+  if (k == "pb_pipe") {
+    if (value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pb_pipe: 0, 2 or 4");
+    a->pb_pipe = value;
+  } else if (k == "serial_solve") {
+    a->serial_solve = value != 0;
+  } else {
+    return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);
   }
   return 0;
 }

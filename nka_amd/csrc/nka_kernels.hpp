@@ -422,6 +422,142 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   }
 }
 
+// ---- PB, software-pipelined over groups of pairs ---------------------------------
+// k_combine above issues every load of a tile, waits, computes, stores, and only
+// then issues the next tile: between the last return and the next issue the
+// wave has nothing in flight.  Here the MAXK pairs of a tile form NG groups of
+// GP = MAXK/NG pairs; as soon as group g of tile t has been consumed, group g of
+// the block's NEXT tile is requested into the same registers, so (NG-1)/NG of a
+// tile's loads are in flight at every moment and the CU's memory pipeline never
+// runs dry.  Same arithmetic in the same order => same bits as k_combine.
+// Single pass only (MAXK covers the list: mvec <= 32), VEC = 2.  The block's last
+// iteration prefetches its own tile again (cache hits) so that the loop body has
+// no load under a branch: the compiler's s_waitcnt vmcnt(N) counts stay exact.
+template <int MAXK, int COMB, int NG>
+__global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, double *f) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  constexpr bool RCP = (COMB == 1);
+  constexpr bool COMPACT = (COMB == 2);
+  constexpr int NW = COMPACT ? 1 : MAXK;
+  constexpr int GP = MAXK / NG;
+  static_assert(MAXK % NG == 0, "groups must divide the unroll width");
+  const int G = gridDim.x;
+  const int ncomb = ctl.ic[IC_NCOMB];
+  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
+  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
+  const int32_t *cs = ctl.comb_slots();
+  const double *cc = ctl.comb_c();
+  const bool norm0 = ctl.ic[IC_NORMED] != 0;
+  const double s = ctl.dc[DC_S];
+  const double rs = 1.0 / s;
+
+  double *wk[MAXK], *vk[MAXK];
+  double ck[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; j++) {
+    const bool live = j < ncomb;
+    const size_t off = live ? (size_t)(cs[j] - 1) * vs.stride : 0;
+    wk[j] = live ? vs.w + off : f;
+    vk[j] = live ? vs.v + off : f;
+    ck[j] = cc[j];
+  }
+  // compact storage reads w only for the pending pair that is normalised now
+  const double *w0src = (!COMPACT || norm0) ? wk[0] : f;
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  V finv, wv[NW], vv[MAXK];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    finv = ld<VEC>(f + e);
+    wv[0] = ld<VEC>(w0src + e);
+#pragma unroll
+    for (int j = 1; j < NW; j++) wv[j] = ld<VEC>(wk[j] + e);
+#pragma unroll
+    for (int j = 0; j < MAXK; j++) vv[j] = ld<VEC>(vk[j] + e);
+  }
+  for (; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t tn = (t + G < ntile) ? t + G : t;
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    V x;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 0) {
+        const V fin = finv;
+        if (norm0) {
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            const double d = ex(wv[0], q) - ex(fin, q);
+            const double wn = RCP ? rs * d : d / s;
+            const double vn = RCP ? rs * ex(vv[0], q) : ex(vv[0], q) / s;
+            setc(wv[0], q, wn);
+            setc(vv[0], q, COMPACT ? vn - wn : vn);
+          }
+          st(wk[0] + e, wv[0]);
+          st(vk[0] + e, vv[0]);
+        }
+        x = fin;
+        st(wnew + e, fin);
+      }
+#pragma unroll
+      for (int jj = 0; jj < GP; jj++) {
+        const int j = g * GP + jj;
+        if (j < ncomb) {
+#pragma unroll
+          for (int q = 0; q < VEC; q++) {
+            if (COMPACT) setc(x, q, ex(x, q) + ck[j] * ex(vv[j], q));
+            else setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wv[j < NW ? j : 0], q), ex(vv[j], q)));
+          }
+        }
+      }
+      if (g == NG - 1) {
+        st(vnew + e, x);
+        st(f + e, x);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // group g of the next tile into the registers just consumed
+      if (g == 0) {
+        finv = ld<VEC>(f + en);
+        wv[0] = ld<VEC>(w0src + en);
+      }
+#pragma unroll
+      for (int jj = 0; jj < GP; jj++) {
+        const int j = g * GP + jj;
+        if (j > 0 && j < NW) wv[j] = ld<VEC>(wk[j] + en);
+        vv[j] = ld<VEC>(vk[j] + en);
+      }
+    }
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+      const double fin = f[i];
+      double x = fin;
+#pragma unroll
+      for (int j = 0; j < MAXK; j++) {
+        if (j < ncomb) {
+          double v = vk[j][i];
+          double w = (!COMPACT || (j == 0 && norm0)) ? wk[j][i] : 0.0;
+          if (j == 0 && norm0) {
+            const double d = w - fin;
+            w = RCP ? rs * d : d / s;
+            v = RCP ? rs * v : v / s;
+            if (COMPACT) v = v - w;
+            wk[0][i] = w;
+            vk[0][i] = v;
+          }
+          x = COMPACT ? x + ck[j] * v : comb1<COMB>(x, ck[j], w, v);
+        }
+      }
+      wnew[i] = fin;
+      vnew[i] = x;
+      f[i] = x;
+    }
+  }
+}
+
 // ---- scalar kernels: list surgery + Cholesky + substitutions on one wavefront ----
 // Working copy of the control arrays in LDS (indices as in the Fortran: slots
 // 1..M1, 0 = end of list).

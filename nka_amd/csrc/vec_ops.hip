@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_dot(int64_t n, const double *__restr
 }
 
 // ---- batched hooks: one pass for many dots / many axpys -----------
-constexpr int kManyMax = 16;   // vectors per launch; longer lists run several launches
+constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24); longer lists run several launches
 struct ManyArgs {
   const double *x[kManyMax];
   const double *y[kManyMax];
@@ -249,11 +249,163 @@ __global__ __launch_bounds__(kBlock) void k_axpy_many(int64_t n, double *z, Many
     }
 }
 
-int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec) {
-  int64_t g = (int64_t)ws->num_cu * 8;
+// ---- fused stages of the vector-flavour update (vector_class: update_norm2,
+// scale_dot_pair_many, update_many_keep, axpy_many_keep) ------------------------------
+
+// z <- a*x + z (update1_, grid_vector_type.F90:127) and the partial sum of z^2 of
+// the RESULT (norm2, :185-197) in the same pass: F08V:237-238 as one kernel.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_update_norm2(int64_t n, double *z, const double *__restrict__ x, double a,
+                                                         double *__restrict__ partials) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  double acc[1] = {0.0};
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V zv = ld<VEC>(z + e);
+    const V xv = ld<VEC>(x + e);
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      const double r = a * ex(xv, q) + ex(zv, q);
+      setc(zv, q, r);
+      acc[0] = fma(r, r, acc[0]);
+    }
+    st(z + e, zv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      const double r = a * x[i] + z[i];
+      z[i] = r;
+      acc[0] = fma(r, r, acc[0]);
+    }
+  block_reduce_store<1>(acc, partials, G);
+}
+
+// F08V:255-264 + :347 in one pass: w <- a*w, v <- a*v (scale, grid_vector_type.F90:
+// 117) [SUB: then v <- (-1)*w + v, the compact option's update1_], both stored, and
+// with the NEW w: partials[j] = <w, y_j>, partials[NV+j] = <f, y_j>, partials[2NV] = <f, w>.
+template <int NV, int VEC, bool SUB>
+__global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, double *w, double *v, double a,
+                                                                const double *__restrict__ f, ManyArgs m,
+                                                                double *__restrict__ partials) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  double acc[2 * NV + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * NV + 1; j++) acc[j] = 0.0;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V wv = ld<VEC>(w + e), vv = ld<VEC>(v + e);
+    const V fv = ld<VEC>(f + e);
+    V yv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) yv[j] = ld<VEC>((j < m.count ? m.x[j] : f) + e);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      const double wn = a * ex(wv, q);
+      double vn = a * ex(vv, q);
+      if (SUB) vn = (-1.0) * wn + vn;
+      setc(wv, q, wn);
+      setc(vv, q, vn);
+      const double fq = ex(fv, q);
+      acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        acc[j] = fma(wn, ex(yv[j], q), acc[j]);
+        acc[NV + j] = fma(fq, ex(yv[j], q), acc[NV + j]);
+      }
+    }
+    st(w + e, wv);
+    st(v + e, vv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      const double wn = a * w[i];
+      double vn = a * v[i];
+      if (SUB) vn = (-1.0) * wn + vn;
+      w[i] = wn;
+      v[i] = vn;
+      const double fq = f[i];
+      acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const double y = (j < m.count ? m.x[j] : f)[i];
+        acc[j] = fma(wn, y, acc[j]);
+        acc[NV + j] = fma(fq, y, acc[NV + j]);
+      }
+    }
+  block_reduce_store<2 * NV + 1>(acc, partials, G);
+}
+
+// F08V:336, 374, 382 in one pass: keep_in <- z (the raw f kept as w_new), then
+// z <- (a_j*x_j + b_j*y_j) + z for j in order (PAIRS; update3_, grid_vector_type.F90:151)
+// or z <- a_j*x_j + z (!PAIRS; update1_, :127), then keep_out <- z (v_new).
+// keep_in / keep_out may be NULL (groups of a list longer than one launch).
+template <int NV, int VEC, bool PAIRS>
+__global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *z, ManyArgs m, double *keep_in,
+                                                             double *keep_out) {
+  using V = typename VecT<VEC>::type;
+  const int G = gridDim.x;
+  const int64_t ntile = n / (kBlock * VEC);
+  for (int64_t t = blockIdx.x; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    V zv = ld<VEC>(z + e);
+    V xv[NV], yv[PAIRS ? NV : 1];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      xv[j] = ld<VEC>((j < m.count ? m.x[j] : z) + e);
+      if (PAIRS) yv[j] = ld<VEC>((j < m.count ? m.y[j] : z) + e);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (keep_in) st(keep_in + e, zv);
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (j < m.count)
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          if (PAIRS) setc(zv, q, (m.a[j] * ex(xv[j], q) + m.b[j] * ex(yv[PAIRS ? j : 0], q)) + ex(zv, q));
+          else setc(zv, q, m.a[j] * ex(xv[j], q) + ex(zv, q));
+        }
+    if (keep_out) st(keep_out + e, zv);
+    st(z + e, zv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      double zi = z[i];
+      if (keep_in) keep_in[i] = zi;
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+        if (j < m.count) zi = PAIRS ? (m.a[j] * m.x[j][i] + m.b[j] * m.y[j][i]) + zi : m.a[j] * m.x[j][i] + zi;
+      if (keep_out) keep_out[i] = zi;
+      z[i] = zi;
+    }
+}
+
+// Persistent grid.  Light kernels (a few loads per thread) fill the chip with 8
+// blocks per CU; the fused many-vector kernels keep `nloads` 16-byte loads per
+// thread in flight and follow the rule measured for the array flavour (ONE block
+// per CU once a block has >= 22 loads per thread in flight; nka_hip.hip:grid_for).
+int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec, int nloads = 2) {
+  const int per_cu = std::max(1, std::min(8, (22 + nloads - 1) / nloads));
+  int64_t g = (int64_t)ws->num_cu * per_cu;
   g = std::min<int64_t>(g, std::max<int64_t>(n / (kBlock * vec), 1));
   return (int)std::min<int64_t>(g, kMaxGrid);
 }
+
+int width_for(int count) { return std::max(4, ((count + 3) / 4) * 4); }   // unroll width 4, 8, ..., kManyMax
+
+#define NKA_DISPATCH_NV(nv, CALL) \
+  switch (nv) {                  \
+    case 4: CALL(4); break;      \
+    case 8: CALL(8); break;      \
+    case 12: CALL(12); break;    \
+    case 16: CALL(16); break;    \
+    case 20: CALL(20); break;    \
+    default: CALL(24); break;    \
+  }
 
 bool al16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
@@ -277,6 +429,52 @@ int run_elementwise(nka_hip_vec_ws *ws, int64_t n, double *z, const double *x, c
   return 0;
 }
 
+}  // namespace
+
+namespace {
+template <bool PAIRS>
+int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs, const double *b,
+                     const double *const *ys, int32_t count, double *keep_in, double *keep_out, const char *who) {
+  if (!ws || n < 0 || count < 0 || (count > 0 && (!a || !xs || (PAIRS && (!b || !ys)))))
+    return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(z, n, who)) return rc;
+  if (keep_in) if (int rc = nka_detail::check_device_span(keep_in, n, who)) return rc;
+  if (keep_out) if (int rc = nka_detail::check_device_span(keep_out, n, who)) return rc;
+  for (int j = 0; j < count; j++) {
+    if (int rc = nka_detail::check_device_span(xs[j], n, who)) return rc;
+    if (PAIRS) if (int rc = nka_detail::check_device_span(ys[j], n, who)) return rc;
+  }
+  int base = 0;
+  do {   // at least one launch: with count == 0 the two keeps are still written
+    ManyArgs m{};
+    m.count = std::max(0, std::min(kManyMax, count - base));
+    double *kin = (base == 0) ? keep_in : nullptr;
+    double *kout = (base + kManyMax >= count) ? keep_out : nullptr;
+    bool v2 = al16(z) && (!kin || al16(kin)) && (!kout || al16(kout));
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = xs[base + j];
+      m.a[j] = a[base + j];
+      v2 = v2 && al16(m.x[j]);
+      if (PAIRS) {
+        m.y[j] = ys[base + j];
+        m.b[j] = b[base + j];
+        v2 = v2 && al16(m.y[j]);
+      }
+    }
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, (PAIRS ? 2 : 1) * nv + 1);
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCH2
+#undef LAUNCH1
+    HIP_TRYV(hipGetLastError());
+    base += kManyMax;
+  } while (base < count);
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -413,12 +611,13 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
       m.x[j] = ys[base + j];
       v2 = v2 && al16(m.x[j]);
     }
-    const int g = grid_for(ws, n, v2 ? 2 : 1);
-    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
-#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_dot_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, m, ws->partials)
-    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
-    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
-#undef LAUNCH
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 1);
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_dot_many<NV, 2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, m, ws->partials)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_dot_many<NV, 1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, m, ws->partials)
+    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCH2
+#undef LAUNCH1
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, m.count, m.count, ws->results);
     HIP_TRYV(hipGetLastError());
     HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * m.count, hipMemcpyDeviceToHost, ws->stream));
@@ -452,12 +651,13 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
       m.x[j] = ys[base + j];
       v2 = v2 && al16(m.x[j]);
     }
-    const int g = grid_for(ws, n, v2 ? 2 : 1);
-    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
-#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_dot_pair_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, x0, x1, m, ws->partials)
-    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
-    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
-#undef LAUNCH
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 2);
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_dot_pair_many<NV, 2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x0, x1, m, ws->partials)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_dot_pair_many<NV, 1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x0, x1, m, ws->partials)
+    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCH2
+#undef LAUNCH1
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->results);
     HIP_TRYV(hipGetLastError());
     HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * (2 * nv + 1), hipMemcpyDeviceToHost, ws->stream));
@@ -495,12 +695,13 @@ int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const dou
       m.b[j] = b[base + j];
       v2 = v2 && al16(m.x[j]) && al16(m.y[j]);
     }
-    const int g = grid_for(ws, n, v2 ? 2 : 1);
-    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
-#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_update_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
-    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
-    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
-#undef LAUNCH
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, 2 * nv + 1);
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many<NV, 2>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many<NV, 1>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCH2
+#undef LAUNCH1
     HIP_TRYV(hipGetLastError());
   }
   return 0;
@@ -525,15 +726,110 @@ int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const doubl
       m.a[j] = a[base + j];
       v2 = v2 && al16(m.x[j]);
     }
-    const int g = grid_for(ws, n, v2 ? 2 : 1);
-    const int nv = m.count <= 4 ? 4 : (m.count <= 8 ? 8 : 16);
-#define LAUNCH(NV, VEC) hipLaunchKernelGGL((k_axpy_many<NV, VEC>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
-    if (v2) { if (nv == 4) LAUNCH(4, 2); else if (nv == 8) LAUNCH(8, 2); else LAUNCH(16, 2); }
-    else    { if (nv == 4) LAUNCH(4, 1); else if (nv == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
-#undef LAUNCH
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 1);
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_axpy_many<NV, 2>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_axpy_many<NV, 1>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m)
+    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCH2
+#undef LAUNCH1
     HIP_TRYV(hipGetLastError());
   }
   return 0;
+}
+
+// ---- fused stages (overrides of vector%update_norm2 / scale_dot_pair_many /
+// update_many_keep / axpy_many_keep, nka_amd/fortran/vector/vector_class.F90) ---------
+
+// z <- a*x + z ; *host_norm = ||z||_2 of the result.
+int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
+                             double *host_norm) {
+  if (!ws || !host_norm || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  *host_norm = 0.0;
+  if (n == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(z, n, "vec_update_norm2: z")) return rc;
+  if (int rc = nka_detail::check_device_span(x, n, "vec_update_norm2: x")) return rc;
+  const bool v2 = al16(z) && al16(x);
+  const int g = grid_for(ws, n, v2 ? 2 : 1);
+  if (v2)
+    hipLaunchKernelGGL((k_update_norm2<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+  else
+    hipLaunchKernelGGL((k_update_norm2<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->result);
+  HIP_TRYV(hipGetLastError());
+  HIP_TRYV(hipMemcpyAsync(ws->host_result, ws->result, sizeof(double), hipMemcpyDeviceToHost, ws->stream));
+  HIP_TRYV(hipStreamSynchronize(ws->stream));
+  *host_norm = std::sqrt(*ws->host_result);
+  return 0;
+}
+
+// w <- a*w ; v <- a*v (subtract != 0: then v <- (-1)*w + v) ; with the new w:
+// vals_w[j] = <w, ys[j]>, vals_f[j] = <f, ys[j]>, *cross = <f, w>.  One pass when
+// count <= 24; longer lists scale in the first launch and only add dots after it.
+int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
+                                    const double *f, const double *const *ys, int32_t count, double *host_vals_w,
+                                    double *host_vals_f, double *host_cross) {
+  if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals_w || !host_vals_f)))
+    return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  *host_cross = 0.0;
+  for (int j = 0; j < count; j++) host_vals_w[j] = host_vals_f[j] = 0.0;
+  if (n == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_detail::check_device_span(w, n, "vec_scale_dot_pair_many: w")) return rc;
+  if (int rc = nka_detail::check_device_span(v, n, "vec_scale_dot_pair_many: v")) return rc;
+  if (int rc = nka_detail::check_device_span(f, n, "vec_scale_dot_pair_many: f")) return rc;
+  for (int j = 0; j < count; j++)
+    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_scale_dot_pair_many: ys[j]")) return rc;
+  {
+    ManyArgs m{};
+    m.count = std::min(kManyMax, count);
+    bool v2 = al16(w) && al16(v) && al16(f);
+    for (int j = 0; j < m.count; j++) {
+      m.x[j] = ys[j];
+      v2 = v2 && al16(m.x[j]);
+    }
+    const int nv = width_for(m.count);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 3);
+#define LAUNCH2S(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
+#define LAUNCH2N(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
+#define LAUNCH1S(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
+#define LAUNCH1N(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
+    if (v2) { if (subtract) { NKA_DISPATCH_NV(nv, LAUNCH2S) } else { NKA_DISPATCH_NV(nv, LAUNCH2N) } }
+    else    { if (subtract) { NKA_DISPATCH_NV(nv, LAUNCH1S) } else { NKA_DISPATCH_NV(nv, LAUNCH1N) } }
+#undef LAUNCH2S
+#undef LAUNCH2N
+#undef LAUNCH1S
+#undef LAUNCH1N
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->results);
+    HIP_TRYV(hipGetLastError());
+    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * (2 * nv + 1), hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    for (int j = 0; j < m.count; j++) {
+      host_vals_w[j] = ws->host_results[j];
+      host_vals_f[j] = ws->host_results[nv + j];
+    }
+    *host_cross = ws->host_results[2 * nv];
+  }
+  if (count > kManyMax) {   // the rest of a long list: plain two-row dots against the already scaled w
+    double cross_again = 0.0;
+    return nka_hip_vec_dot_pair_many(ws, n, w, f, ys + kManyMax, count - kManyMax, host_vals_w + kManyMax,
+                                     host_vals_f + kManyMax, &cross_again);
+  }
+  return 0;
+}
+
+// keep_in <- z ; z <- (a[j]*xs[j] + b[j]*ys[j]) + z, j in order ; keep_out <- z.
+int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                                 const double *b, const double *const *ys, int32_t count, double *keep_in,
+                                 double *keep_out) {
+  return update_many_keep<true>(ws, n, z, a, xs, b, ys, count, keep_in, keep_out, "vec_update_many_keep");
+}
+
+// keep_in <- z ; z <- a[j]*xs[j] + z, j in order ; keep_out <- z.
+int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                               int32_t count, double *keep_in, double *keep_out) {
+  return update_many_keep<false>(ws, n, z, a, xs, nullptr, nullptr, count, keep_in, keep_out, "vec_axpy_many_keep");
 }
 
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host) {

@@ -215,6 +215,39 @@ module nka_hip_c
       type(c_ptr), intent(in) :: xs(*)
       integer(c_int32_t), value :: count
     end function
+    integer(c_int) function nka_hip_vec_update_norm2(ws, n, z, a, x, res) bind(C)
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a
+      real(c_double), intent(out) :: res
+    end function
+    integer(c_int) function nka_hip_vec_scale_dot_pair_many(ws, n, w, v, a, subtract, f, ys, count, vals_w, vals_f, &
+                                                            cross) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, w, v, f
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a
+      integer(c_int32_t), value :: subtract, count
+      type(c_ptr), intent(in) :: ys(*)
+      real(c_double), intent(out) :: vals_w(*), vals_f(*), cross
+    end function
+    integer(c_int) function nka_hip_vec_update_many_keep(ws, n, z, a, xs, b, ys, count, keep_in, keep_out) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, keep_in, keep_out
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*), b(*)
+      type(c_ptr), intent(in) :: xs(*), ys(*)
+      integer(c_int32_t), value :: count
+    end function
+    integer(c_int) function nka_hip_vec_axpy_many_keep(ws, n, z, a, xs, count, keep_in, keep_out) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, keep_in, keep_out
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*)
+      type(c_ptr), intent(in) :: xs(*)
+      integer(c_int32_t), value :: count
+    end function
     integer(c_int) function nka_hip_vec_h2d(ws, n, dst_dev, src_host) bind(C)
       import :: c_int, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, dst_dev

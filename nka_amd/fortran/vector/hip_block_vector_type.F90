@@ -43,6 +43,11 @@ module hip_block_vector_type
     procedure :: dot_pair_many => dot_pair_many_fused
     procedure :: update_many => update_many_fused
     procedure :: axpy_many => axpy_many_fused
+    !! fused stage hooks: each group of statements of an update as ONE kernel
+    procedure :: update_norm2 => update_norm2_fused
+    procedure :: scale_dot_pair_many => scale_dot_pair_many_fused
+    procedure :: update_many_keep => update_many_keep_fused
+    procedure :: axpy_many_keep => axpy_many_keep_fused
     !! specific to this type
     procedure :: init
     procedure :: release
@@ -312,6 +317,111 @@ contains
     end select
     call nka_hip_check(nka_hip_vec_axpy_many(this%ws, this%ntot, this%base, a, xp, size(idx, kind=c_int32_t)), &
                        'vec_axpy_many')
+  end subroutine
+
+  !! this <- a*x + this and ||this|| in one pass (R 2n, W n).
+  function update_norm2_fused(this, a, x) result(s)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    real(r8) :: s
+    s = 0.0_r8
+    select type (x)
+    class is (hip_block_vector)
+      call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%ntot, this%base, a, x%base, s), 'vec_update_norm2')
+    class default
+      error stop 'incompatible arguments to VECTOR%UPDATE_NORM2'
+    end select
+  end function
+
+  !! scale both members of the new pair and take both inner-product rows while the
+  !! stored vectors stream past once (R (3+L)n, W 2n).
+  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross)
+    class(hip_block_vector), intent(inout) :: this
+    class(vector), intent(inout) :: v
+    real(r8), intent(in) :: a
+    logical, intent(in) :: subtract
+    class(vector), intent(in) :: f
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_f(:), cross
+    type(c_ptr) :: ptrs(max(size(idx),1))
+    integer :: j
+    select type (v)
+    class is (hip_block_vector)
+      select type (f)
+      class is (hip_block_vector)
+        select type (ys)
+        class is (hip_block_vector)
+          do j = 1, size(idx)
+            ptrs(j) = ys(idx(j))%base
+          end do
+          call nka_hip_check(nka_hip_vec_scale_dot_pair_many(this%ws, this%ntot, this%base, v%base, a, &
+                             merge(1_c_int32_t, 0_c_int32_t, subtract), f%base, ptrs, size(idx, kind=c_int32_t), &
+                             vals_this, vals_f, cross), 'vec_scale_dot_pair_many')
+          return
+        end select
+      end select
+    end select
+    error stop 'incompatible arguments to VECTOR%SCALE_DOT_PAIR_MANY'
+  end subroutine
+
+  !! keep_in <- this ; combine ; keep_out <- this, `this` read once and written once
+  !! (R (1+2k)n, W 3n).
+  subroutine update_many_keep_fused(this, a, xs, b, ys, idx, keep_in, keep_out)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:), b(:)
+    class(vector), intent(in) :: xs(:), ys(:)
+    integer, intent(in) :: idx(:)
+    class(vector), intent(inout) :: keep_in, keep_out
+    type(c_ptr) :: xp(max(size(idx),1)), yp(max(size(idx),1))
+    integer :: j
+    select type (xs)
+    class is (hip_block_vector)
+      select type (ys)
+      class is (hip_block_vector)
+        select type (keep_in)
+        class is (hip_block_vector)
+          select type (keep_out)
+          class is (hip_block_vector)
+            do j = 1, size(idx)
+              xp(j) = xs(idx(j))%base
+              yp(j) = ys(idx(j))%base
+            end do
+            call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot, this%base, a, xp, b, yp, &
+                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_update_many_keep')
+            return
+          end select
+        end select
+      end select
+    end select
+    error stop 'incompatible arguments to VECTOR%UPDATE_MANY_KEEP'
+  end subroutine
+
+  subroutine axpy_many_keep_fused(this, a, xs, idx, keep_in, keep_out)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:)
+    class(vector), intent(in) :: xs(:)
+    integer, intent(in) :: idx(:)
+    class(vector), intent(inout) :: keep_in, keep_out
+    type(c_ptr) :: xp(max(size(idx),1))
+    integer :: j
+    select type (xs)
+    class is (hip_block_vector)
+      select type (keep_in)
+      class is (hip_block_vector)
+        select type (keep_out)
+        class is (hip_block_vector)
+          do j = 1, size(idx)
+            xp(j) = xs(idx(j))%base
+          end do
+          call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot, this%base, a, xp, &
+                             size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_axpy_many_keep')
+          return
+        end select
+      end select
+    end select
+    error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
   end subroutine
 
 end module hip_block_vector_type

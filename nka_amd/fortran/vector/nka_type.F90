@@ -9,10 +9,11 @@
 !! Cholesky matrix live on the host and every O(n) statement is a hook call:
 !!   update(-1,f) ; norm2 ; scale(1/s) x2 ; dot x L        (F08V:237-262)
 !!   copy ; dot x k ; update(-c,w,c,v) x k ; copy          (F08V:336-382)
-!! The L + k + 1 dots and the k updates are issued through the optional batched
-!! hooks dot_pair_many / dot_many / update_many of vector_class, whose default
-!! bodies are exactly those loops of dot() / update() calls -- a user type that
-!! does not override them sees only the reference's deferred hooks.
+!! These statements are issued through the optional STAGE hooks of vector_class
+!! (update_norm2, scale_dot_pair_many, update_many_keep / axpy_many_keep) and its
+!! batched hooks (dot_pair_many, dot_many, update_many), whose default bodies are
+!! exactly the calls listed above -- a user type that does not override them sees
+!! only the reference's deferred hooks, in the reference's order.
 !! With a device-resident concrete vector (hip_block_vector_type) each hook is a
 !! HIP kernel.  The hook sequence, and therefore every rounding of the stored
 !! vectors, is the reference's; the scalar step restates F08V:269-368 (see
@@ -220,6 +221,10 @@ contains
   end subroutine
 
   !! call a%accel_update(f)                                   F08V:219-397
+  !! The O(n) statements are issued as THREE stage hooks of class(vector), placed
+  !! where the algorithm needs a value reduced over the whole vector: the norm of
+  !! the new difference, the two inner-product rows, and nothing after the
+  !! combine.  Each stage's default body is the reference's own hook sequence.
   subroutine accel_update(this, f)
     class(nka), intent(inout) :: this
     class(vector), intent(inout) :: f
@@ -229,20 +234,16 @@ contains
 
     have_rows = .false.
     if (this%pending) then
-      call this%w(this%first)%update(-1.0_r8, f)             ! w1 <- w1 - f
-      s = this%w(this%first)%norm2()
+      s = this%w(this%first)%update_norm2(-1.0_r8, f)        ! w1 <- w1 - f ; s = ||w1||       F08V:237-238
       if (s == 0.0_r8) call this%relax                       ! nothing to learn from a zero difference
     end if
 
     if (this%pending) then
-      call this%v(this%first)%scale(1.0_r8/s)
-      call this%w(this%first)%scale(1.0_r8/s)
-      if (this%compact) call this%v(this%first)%update(-1.0_r8, this%w(this%first))   ! v1 <- v1 - w1
-      !! Both inner-product rows of this update in ONE batched hook call: the Gram
-      !! row <w1,w_k> (F08V:260-264) and the projection row <f,w_k> (F08V:347) for
-      !! every older entry, plus <f,w1>.  f is not modified in between, so the
-      !! values equal the reference's; rows of entries the factorisation then drops
-      !! are simply not used.  A plain user type gets the default loops of dot().
+      !! v1 <- v1/s, w1 <- w1/s (F08V:255-256; compact: then v1 <- v1 - w1) and both
+      !! inner-product rows of this update: the Gram row <w1,w_k> (F08V:260-264) and
+      !! the projection row <f,w_k> (F08V:347) for every older entry, plus <f,w1>.
+      !! f is not modified in between, so the values equal the reference's; rows of
+      !! entries the factorisation then drops are simply not used.
       nidx = 0
       k = this%next(this%first)
       do while (k /= 0)
@@ -250,7 +251,8 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
-      call this%w(this%first)%dot_pair_many(f, this%w, idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
+      call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
+                                                  idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
       c(this%first) = cross
       do j = 1, nidx
         this%h(this%first,idx(j)) = vals(j)
@@ -262,7 +264,6 @@ contains
 
     slot = this%free
     this%free = this%next(slot)
-    call this%w(slot)%copy(f)                                ! keep the raw f for the next call
 
     if (this%subspace) then
       nidx = 0
@@ -282,15 +283,18 @@ contains
       do j = 1, nidx
         vals(j) = c(idx(j))
       end do
-      !! f <- f - c w + c v for every k in list order (F08V:374), one batched call
-      if (this%compact) then
-        call f%axpy_many(vals(1:nidx), this%v, idx(1:nidx))    ! v slots hold v - w: f <- f + c*(v - w)
+      !! w_new <- f (F08V:336) ; f <- f - c w + c v for every k in list order (F08V:374) ;
+      !! v_new <- f (F08V:382): one stage
+      if (this%compact) then                                 ! v slots hold v - w: f <- f + c*(v - w)
+        call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
       else
-        call f%update_many(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx))
+        call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
       end if
+    else
+      call this%w(slot)%copy(f)                              ! no subspace yet: f is returned unchanged
+      call this%v(slot)%copy(f)
     end if
 
-    call this%v(slot)%copy(f)                                ! keep the returned update
     this%prev(slot) = 0
     this%next(slot) = this%first
     if (this%first == 0) then

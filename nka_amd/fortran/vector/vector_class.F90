@@ -15,6 +15,14 @@
 !! deferred hooks; a device vector may override them with fused kernels.
 !! dot_pair_many computes BOTH inner-product rows an update needs (the new
 !! difference against the stored w's, and f against them) in one pass.
+!!
+!! STAGE hooks, also NOT deferred: update_norm2, scale_dot_pair_many,
+!! update_many_keep, axpy_many_keep name the three groups of statements of
+!! accel_update between which a value reduced over the whole vector is needed
+!! (F08V:237-238 | 255-264 + 347 | 336 + 374 + 382).  Their default bodies ARE
+!! those statements, hook call by hook call, so the accelerator written against
+!! them performs exactly the reference's sequence on any user type; a device
+!! vector overrides each with ONE fused kernel (8n(12+3m) bytes per update).
 
 module vector_class
 
@@ -46,6 +54,11 @@ module vector_class
     procedure :: dot_pair_many
     procedure :: update_many
     procedure :: axpy_many
+    !! optional stage hooks (overridable, default = the reference's hook sequence)
+    procedure :: update_norm2
+    procedure :: scale_dot_pair_many
+    procedure :: update_many_keep
+    procedure :: axpy_many_keep
   end type
 
   abstract interface
@@ -239,6 +252,58 @@ contains
     do j = 1, size(idx)
       call this%update(a(j), xs(idx(j)))
     end do
+  end subroutine
+
+  !! this <- a*x + this, and the 2-norm of the result (F08V:237-238).
+  function update_norm2(this, a, x) result(s)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    real(r8) :: s
+    call this%update(a, x)
+    s = this%norm2()
+  end function
+
+  !! Normalise the new pair and take both inner-product rows (F08V:255-264, 347):
+  !!   v <- a*v ; this <- a*this ; [subtract: v <- v - this] ;
+  !!   vals_this(j) = <this, ys(idx(j))>, vals_f(j) = <f, ys(idx(j))>, cross = <f, this>.
+  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross)
+    class(vector), intent(inout) :: this, v
+    real(r8), intent(in) :: a
+    logical, intent(in) :: subtract
+    class(vector), intent(in) :: f
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_f(:), cross
+    call v%scale(a)
+    call this%scale(a)
+    if (subtract) call v%update(-1.0_r8, this)
+    call this%dot_pair_many(f, ys, idx, vals_this, vals_f, cross)
+  end subroutine
+
+  !! keep_in <- this ; this <- this + sum_j (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) in
+  !! order ; keep_out <- this  (F08V:336, 374, 382).
+  subroutine update_many_keep(this, a, xs, b, ys, idx, keep_in, keep_out)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:), b(:)
+    class(vector), intent(in) :: xs(:), ys(:)
+    integer, intent(in) :: idx(:)
+    class(vector), intent(inout) :: keep_in, keep_out
+    call keep_in%copy(this)
+    call this%update_many(a, xs, b, ys, idx)
+    call keep_out%copy(this)
+  end subroutine
+
+  !! keep_in <- this ; this <- this + sum_j a(j)*xs(idx(j)) in order ; keep_out <- this.
+  subroutine axpy_many_keep(this, a, xs, idx, keep_in, keep_out)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a(:)
+    class(vector), intent(in) :: xs(:)
+    integer, intent(in) :: idx(:)
+    class(vector), intent(inout) :: keep_in, keep_out
+    call keep_in%copy(this)
+    call this%axpy_many(a, xs, idx)
+    call keep_out%copy(this)
   end subroutine
 
 end module vector_class

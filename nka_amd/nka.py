@@ -283,6 +283,10 @@ class nka:  # noqa: N801  (the reference's type name)
     def set_grid(self, pa=0, pb=0):
         _check(self._L.nka_hip_set_grid(self._handle(), pa, pb), "set_grid")
 
+    def set_tuning(self, key: str, value: int):
+        """Kernel-variant switch for in-process A/B measurements (nka_hip_set_tuning)."""
+        _check(self._L.nka_hip_set_tuning(self._handle(), key.encode(), int(value)), "set_tuning")
+
     def device_info(self):
         name = C.create_string_buffer(64)
         ncu = C.c_int32()

@@ -135,7 +135,7 @@ def test_large_mvec_up_to_the_lds_limit(torch_cuda, oracle, m):
         if t % 8 == 0 or t > m:
             assert acc.state().list_order() == ora.state().list_order(), t
             P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t)
-    assert acc.defined() and acc.num_vec() == m
+    assert acc.defined() and acc.num_vec() == ora.num_vec() and acc.num_vec() >= m - 8   # a few dependence drops
 
 
 def test_mvec_beyond_the_lds_limit_is_refused_with_a_clear_message(torch_cuda):

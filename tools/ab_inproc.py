@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""In-process A/B of kernel variants: ONE accelerator (same allocations, same
+inputs, same thermal state), the variants alternated in blocks of K updates for
+R rounds; per-phase device times from the library's HIP events.
+
+  tools/ab_inproc.py --key pb_pipe --values 0 2 4 [--flavor f08] [--vlen 1e8] [--mvec 20] [--rounds 8] [--steps 10]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--key", default="pb_pipe")
+    ap.add_argument("--values", type=int, nargs="+", default=[0, 2, 4])
+    ap.add_argument("--flavor", default="f08", choices=["f08", "c", "f08vec"])
+    ap.add_argument("--vlen", type=float, default=1e8)
+    ap.add_argument("--mvec", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    import torch
+    import nka_amd
+    from nka_amd import synth
+    n, m = int(a.vlen), a.mvec
+    fl = {"f08": nka_amd.FLAVOR_F08, "c": nka_amd.FLAVOR_C, "f08vec": nka_amd.FLAVOR_F08_VECTOR}[a.flavor]
+    acc = nka_amd.nka().init(n, m, flavor=fl)
+    P = min(m + 6, 30)
+    pool = torch.empty((P, n + (n % 2)), dtype=torch.float64, device="cuda")
+    for j in range(P):
+        synth.fill_torch(pool[j, :n], 12345, j, 0, n)
+    t = 0
+    for _ in range(m + 3):
+        synth.fill_torch(pool[t % P, :n], 12345, t, 0, n)
+        acc.accel_update(pool[t % P, :n])
+        t += 1
+    assert acc.num_vec() == m
+    res = {v: {"PA": [], "PB": [], "all": []} for v in a.values}
+    acc.set_timing(a.steps)
+    for r in range(a.rounds):
+        order = a.values if r % 2 == 0 else list(reversed(a.values))
+        for v in order:
+            acc.set_tuning(a.key, v)
+            for _ in range(a.steps):
+                synth.fill_torch(pool[t % P, :n], 12345, t, 0, n)
+                acc.accel_update(pool[t % P, :n])
+                t += 1
+            ph = [acc.timing_ms(b) for b in range(a.steps)]
+            res[v]["PA"].append(statistics.mean(p[0] for p in ph))
+            res[v]["PB"].append(statistics.mean(p[2] for p in ph))
+            res[v]["all"].append(statistics.mean(p[3] for p in ph))
+    assert acc.num_vec() == m
+    print(f"in-process A/B  key={a.key}  flavor={a.flavor} n={n} m={m}  {a.rounds} rounds x {a.steps} updates per variant")
+    for v in a.values:
+        d = res[v]
+        print(f"  {a.key}={v}:  PB {statistics.mean(d['PB']):.3f} ms (min {min(d['PB']):.3f}, max {max(d['PB']):.3f}, "
+              f"sd {statistics.pstdev(d['PB']):.3f})   PA {statistics.mean(d['PA']):.3f}   update {statistics.mean(d['all']):.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
