@@ -202,7 +202,8 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
 
 /* Kernel-variant switches for A/B measurements inside one process (same
  * allocations, same thermal state): "pb_pipe" = 0 (k_combine), 2 or 4
- * (k_combine_pipe with that many load groups); "serial_solve" = 0/1.  Results are
+ * (k_combine_pipe with that many load groups), -1 automatic (the default; env
+ * NKA_HIP_PB_PIPE); "serial_solve" = 0/1.  Results are
  * bit-identical across variants. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 

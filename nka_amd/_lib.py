@@ -78,6 +78,16 @@ SIGNATURES = {
 }
 
 
+# include/nka_example_dev.h (device-resident example system)
+SIGNATURES.update({
+    "nka_ex_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p]),
+    "nka_ex_destroy": (C.c_int, [C.c_void_p]),
+    "nka_ex_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nka_ex_pc_ssor": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "nka_ex_update_solution": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+})
+
+
 def lib_path() -> str:
     # NKA_HIP_LIB: load another build of the same ABI (kernel tuning experiments)
     return os.environ.get("NKA_HIP_LIB") or os.path.join(HERE, "libnka_hip.so")

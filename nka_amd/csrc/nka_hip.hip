@@ -150,7 +150,8 @@ struct nka_hip_state {
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
-  int pb_pipe = 0;            // groups of the software-pipelined PB (0 = k_combine, 2 or 4 = k_combine_pipe)
+  int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
+                              // -1 = automatic (see enqueue_pb)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
@@ -510,8 +511,13 @@ static int enqueue_solve(nka_hip_t a, int mode) {
 static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
   const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
-  if (vec == 2 && npass == 1 && a->pb_pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
-    if (a->pb_pipe >= 4) launch_combine_pipe<4>(a->flavor, maxk, a, f);
+  // Measured in one process on MI355X (tools/ab_inproc.py, m = 20): the pipelined pass is 1.7 % faster
+  // than k_combine for the two-vectors-per-pair flavours at n = 1e8 (6.52 vs 6.63 ms), equal at
+  // 1.25e7, slower at 1e6, and 4 % slower for the compact flavour -- so: automatic = only there.
+  int pipe = a->pb_pipe;
+  if (pipe < 0) pipe = (a->flavor != NKA_HIP_FLAVOR_C && a->n >= 30000000) ? 4 : 0;
+  if (vec == 2 && npass == 1 && pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
+    if (pipe >= 4) launch_combine_pipe<4>(a->flavor, maxk, a, f);
     else launch_combine_pipe<2>(a->flavor, maxk, a, f);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -909,7 +915,7 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pb_pipe: 0, 2 or 4");
+    if (value != -1 && value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2 or 4");
     a->pb_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;

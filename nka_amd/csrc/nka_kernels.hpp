@@ -175,12 +175,14 @@ __device__ __forceinline__ void setc(d2 &x, int i, double val) { x[i] = val; }
 
 // ---- fixed-order final sum of per-block partials (vector hooks: dot, norm2) -------
 // out[c] = sum_b partials[c*G + b] for c < ncols ; 0 for ncols <= c < ncols_out.
-// One block; wave w takes columns w, w+4, ...; each lane sums its strided
-// share sequentially, then a butterfly: the order never depends on timing.
+// One wavefront per column (launch ceil(ncols_out / 4) blocks): each lane sums its
+// strided share sequentially, then a butterfly: the order never depends on timing.
+// `out` may be device-mapped pinned host memory: the host then reads the sums
+// right after synchronising the stream, with no copy in between.
 static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_finalize(
     const double *__restrict__ partials, int G, int ncols, int ncols_out, double *__restrict__ out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = wv; c < ncols_out; c += kWavesPerBlock) {
+  for (int c = blockIdx.x * kWavesPerBlock + wv; c < ncols_out; c += gridDim.x * kWavesPerBlock) {
     double r = 0.0;
     if (c < ncols) {
       for (int b = lane; b < G; b += 64) r += partials[(size_t)c * G + b];

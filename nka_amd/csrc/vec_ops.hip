@@ -30,10 +30,10 @@ struct nka_hip_vec_ws {
   hipStream_t stream = nullptr;
   int num_cu = 256;
   double *partials = nullptr;  // kMaxGrid
-  double *result = nullptr;    // 1 double, device
   double *host_result = nullptr;  // pinned
-  double *results = nullptr;      // kManyMax doubles, device
-  double *host_results = nullptr; // pinned
+  double *host_results = nullptr; // pinned, 2*kManyMax+1 doubles
+  double *host_result_dev = nullptr;   // device-side addresses of the two pinned buffers: the final-sum
+  double *host_results_dev = nullptr;  // kernel writes straight into host memory (no copy kernel, no staging)
 };
 
 namespace {
@@ -493,10 +493,10 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e == hipSuccess) ws->num_cu = prop.multiProcessorCount;
   if (e == hipSuccess) e = hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&ws->results, sizeof(double) * (2 * kManyMax + 1));
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc((void **)&ws->result, sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_result_dev, ws->host_result, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_results_dev, ws->host_results, 0);
   if (e != hipSuccess) {   // free whatever was obtained (hipFree / hipHostFree accept NULL)
     nka_hip_vec_workspace_destroy(ws);
     return nka_detail::set_error(e == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,
@@ -511,9 +511,7 @@ int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   hipSetDevice(ws->device);
   hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
-  hipFree(ws->result);
   hipHostFree(ws->host_result);
-  hipFree(ws->results);
   hipHostFree(ws->host_results);
   delete ws;
   return 0;
@@ -578,9 +576,8 @@ int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const doubl
     hipLaunchKernelGGL((k_dot<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
   else
     hipLaunchKernelGGL((k_dot<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->result);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->host_result_dev);
   HIP_TRYV(hipGetLastError());
-  HIP_TRYV(hipMemcpyAsync(ws->host_result, ws->result, sizeof(double), hipMemcpyDeviceToHost, ws->stream));
   HIP_TRYV(hipStreamSynchronize(ws->stream));
   *host_result = *ws->host_result;
   return 0;
@@ -618,9 +615,9 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, m.count, m.count, ws->results);
+    hipLaunchKernelGGL(k_finalize, dim3((m.count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
+                       ws->partials, g, m.count, m.count, ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * m.count, hipMemcpyDeviceToHost, ws->stream));
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
   }
@@ -658,9 +655,9 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->results);
+    hipLaunchKernelGGL(k_finalize, dim3((2 * nv + 1 + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
+                       ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * (2 * nv + 1), hipMemcpyDeviceToHost, ws->stream));
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) {
       host_vals0[base + j] = ws->host_results[j];
@@ -756,9 +753,8 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
     hipLaunchKernelGGL((k_update_norm2<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
   else
     hipLaunchKernelGGL((k_update_norm2<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->result);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->host_result_dev);
   HIP_TRYV(hipGetLastError());
-  HIP_TRYV(hipMemcpyAsync(ws->host_result, ws->result, sizeof(double), hipMemcpyDeviceToHost, ws->stream));
   HIP_TRYV(hipStreamSynchronize(ws->stream));
   *host_norm = std::sqrt(*ws->host_result);
   return 0;
@@ -801,9 +797,9 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef LAUNCH2N
 #undef LAUNCH1S
 #undef LAUNCH1N
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->results);
+    hipLaunchKernelGGL(k_finalize, dim3((2 * nv + 1 + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
+                       ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->results, sizeof(double) * (2 * nv + 1), hipMemcpyDeviceToHost, ws->stream));
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) {
       host_vals_w[j] = ws->host_results[j];

@@ -52,8 +52,9 @@ def test_c_abi_exports_every_declared_symbol():
     import re
     import nka_amd
     from nka_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "nka_hip.h")).read()
-    declared = set(re.findall(r"\b(nka_hip_[a-z0-9_]+)\s*\(", hdr)) - {"nka_hip_allreduce_fn"}
+    hdr = open(os.path.join(ROOT, "include", "nka_hip.h")).read() + \
+        open(os.path.join(ROOT, "include", "nka_example_dev.h")).read()
+    declared = set(re.findall(r"\b(nka_(?:hip|ex)_[a-z0-9_]+)\s*\(", hdr)) - {"nka_hip_allreduce_fn"}
     L = nka_amd.load()
     for name in sorted(declared):
         assert hasattr(L, name), f"libnka_hip.so lacks {name}"

@@ -124,3 +124,66 @@ def test_unaligned_operands_take_the_scalar_path(ws):
     assert x.data_ptr() % 16 == 8
     assert L.nka_hip_vec_update1(h, n, C.c_void_p(z.data_ptr()), 2.0, C.c_void_p(x.data_ptr())) == 0
     assert np.array_equal(z.cpu().numpy(), 2.0 * x.cpu().numpy() + z0)
+
+
+@pytest.mark.parametrize("n,count,subtract", [(1, 0, 0), (513, 3, 1), (4099, 5, 0), (100003, 20, 0), (100003, 20, 1),
+                                              (777, 37, 1)])
+def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, subtract):
+    """update_norm2, scale_dot_pair_many, update_many_keep, axpy_many_keep: stored
+    vectors BIT-EXACT against the sequences of deferred-hook expressions they
+    fuse (F08V:237-238, 255-264, 336+374+382), reductions within tolerance."""
+    L, h, torch = ws
+    rng = np.random.default_rng(7 * n + count)
+    dp = C.POINTER(C.c_double)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    f, w0, v0 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    Y = rng.standard_normal((max(count, 1), n))
+    Yd = [_dev(torch, Y[j]) for j in range(count)]
+    ys = (C.c_void_p * max(count, 1))(*[t.data_ptr() for t in Yd])
+
+    # stage 1: w <- (-1)*f + w ; s = ||w||
+    wd, fd, vd = _dev(torch, w0), _dev(torch, f), _dev(torch, v0)
+    s = C.c_double()
+    assert L.nka_hip_vec_update_norm2(h, n, P(wd), -1.0, P(fd), C.byref(s)) == 0
+    d = -1.0 * f + w0
+    assert np.array_equal(wd.cpu().numpy(), d)
+    assert s.value == pytest.approx(float(np.linalg.norm(d)), rel=1e-14)
+
+    # stage 2: scale both, optional subtract, both rows + cross with the NEW w
+    a = 1.0 / s.value
+    vw, vf, cross = np.zeros(max(count, 1)), np.zeros(max(count, 1)), C.c_double()
+    assert L.nka_hip_vec_scale_dot_pair_many(h, n, P(wd), P(vd), a, subtract, P(fd), ys, count,
+                                             vw.ctypes.data_as(dp), vf.ctypes.data_as(dp), C.byref(cross)) == 0
+    wn = a * d
+    vn = a * v0
+    if subtract:
+        vn = -1.0 * wn + vn
+    assert np.array_equal(wd.cpu().numpy(), wn)
+    assert np.array_equal(vd.cpu().numpy(), vn)
+    nf, nw = np.linalg.norm(f), np.linalg.norm(wn)
+    assert cross.value == pytest.approx(float(f @ wn), abs=1e-13 * nf * nw)
+    for j in range(count):
+        ny = np.linalg.norm(Y[j])
+        assert vw[j] == pytest.approx(float(wn @ Y[j]), abs=1e-13 * nw * ny)
+        assert vf[j] == pytest.approx(float(f @ Y[j]), abs=1e-13 * nf * ny)
+
+    # stage 3: keep_in <- z ; z <- combine ; keep_out <- z
+    X = rng.standard_normal((max(count, 1), n))
+    Xd = [_dev(torch, X[j]) for j in range(count)]
+    xs = (C.c_void_p * max(count, 1))(*[t.data_ptr() for t in Xd])
+    ca, cb = rng.standard_normal(max(count, 1)), rng.standard_normal(max(count, 1))
+    for pairs in (True, False):
+        zd = _dev(torch, f)
+        kin = torch.zeros(n, dtype=torch.float64, device="cuda")
+        kout = torch.zeros(n, dtype=torch.float64, device="cuda")
+        if pairs:
+            assert L.nka_hip_vec_update_many_keep(h, n, P(zd), ca.ctypes.data_as(dp), xs, cb.ctypes.data_as(dp), ys,
+                                                  count, P(kin), P(kout)) == 0
+        else:
+            assert L.nka_hip_vec_axpy_many_keep(h, n, P(zd), ca.ctypes.data_as(dp), xs, count, P(kin), P(kout)) == 0
+        ref = f.copy()
+        for j in range(count):
+            ref = (ca[j] * X[j] + cb[j] * Y[j]) + ref if pairs else ca[j] * X[j] + ref
+        assert np.array_equal(kin.cpu().numpy(), f)
+        assert np.array_equal(zd.cpu().numpy(), ref)
+        assert np.array_equal(kout.cpu().numpy(), ref)
