@@ -29,6 +29,10 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  combine with compact storage; both are checked
                  against the compiled src-F08 reference in tests/ (decisions exact,
                  values within the stated tolerance).
+  config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
+                 src-F08-vector abstract path through the Fortran vector flavour on
+                 the device block vector, measured by nka_vector_driver in a child
+                 process after the main measurement.
   replica_check (N > 1): digest of the replicated scalar state of every rank,
                  compared after warm-up and after the timed steps (outside the
                  timed region); a mismatch aborts the job.
@@ -58,6 +62,7 @@ def parse():
     ap.add_argument("--vlen", "--n", dest="n", type=float, default=1e8, help="GLOBAL vector length")
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the abstract-vector (BASELINE configs[4]) extra")
     ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")
     ap.add_argument("--flavor", choices=["c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "c"),
                     help="which reference rounding is mirrored; 'c' (src-C) uses compact storage")
@@ -102,6 +107,41 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6):
         "n": n, "s_per_update": per,
         "algorithmic_GBps": 8.0 * n * (11 + 3 * mvec) / per / 1e9,
     }
+
+
+def config5_abstract_vector(steps: int = 20):
+    """BASELINE configs[4]: the src-F08-vector abstract path (user dot/axpy hooks on a
+    4-field block vector, 4 x 1e7 per field, m = 20) through the Fortran vector
+    flavour and its device block vector (nka_amd/fortran/build/nka_vector_driver),
+    run as a child process after the main measurement has released its memory.
+    Reported as an extra key; never part of `value`."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "nka_amd", "fortran", "build", "nka_vector_driver")
+    if not os.path.exists(exe):
+        return {"value": None, "error": "nka_vector_driver not built"}
+    out = {"workload": "BASELINE configs[4]: abstract vector hooks, 4 fields x 1e7, mvec=20, fp64, 1 GPU",
+           "unit": "updates/s", "steps": steps}
+    n, m = 4 * 10**7, 20
+    for key, compact, words in (("reference_rounding", "0", 12 + 3 * m), ("compact_option", "1", 12 + 2 * m)):
+        try:
+            p = subprocess.run([exe, "bench", "4", "10000000", str(m), str(steps), compact], capture_output=True,
+                               text=True, timeout=600)
+            mt = re.search(r"updates/s\s+([0-9.]+)\s+ms/update\s+([0-9.]+)", p.stdout)
+            if p.returncode != 0 or not mt:
+                out[key] = {"value": None, "error": (p.stdout + p.stderr)[-300:]}
+                continue
+            ups, ms = float(mt.group(1)), float(mt.group(2))
+            moved = 8.0 * n * words
+            out[key] = {"value": ups, "ms_per_step": ms, "bytes_moved_per_update": moved,
+                        "achieved_GBps": moved / (ms * 1e-3) / 1e9, "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "contract_frac": 8.0 * n * (11 + 3 * m) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "byte_model": f"8n({words - (3 if compact == '0' else 2) * m}+{'3' if compact == '0' else '2'}m): "
+                                      "update_norm2 3, scale_dot_pair_many 5+m, update/axpy_many_keep "
+                                      + ("4+2m" if compact == "0" else "4+m")}
+        except Exception as exc:   # an extra, never the measured path
+            out[key] = {"value": None, "error": repr(exc)}
+    return out
 
 
 FLAVOR_TEXT = {"c": "src-C rounding f += c*(v-w), compact storage (v slot keeps v'-w'); checked against the "
@@ -375,12 +415,18 @@ def main():
                     out["cpu_baseline"]["value"] * int(args.cpu_n) / n_global
             except Exception as exc:  # the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        if world == 1 and not (args.no_config5 or args.no_cpu_baseline) and (n_global, m) == (10**8, 20):   # lean runs skip both extras
+            del pool, pool_store           # release HBM for the child process
+            acc.delete()
+            torch.cuda.empty_cache()
+            out["config5_abstract_vector"] = config5_abstract_vector()
+            pool = pool_store = None
         print(json.dumps(out), flush=True)
 
     # tear down in a fixed order on every rank: the library's RCCL communicator first,
     # then torch's process group
     del pool, pool_store
-    acc.delete()
+    acc.delete()                           # (idempotent)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,10 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_vec_ops_gpu.py tests/test_fortran_front_end.py -m gpu -q --tb=short -x 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -5
-nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 20 0
-nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 20 1
-for n in 1.25e7 1e6; do python tools/ab_inproc.py --flavor f08 --vlen $n --key pb_pipe --values 0 2 4 --rounds 8 --steps 20; done
-python tools/ab_inproc.py --flavor c --vlen 1.25e7 --key pb_pipe --values 0 2 4 --rounds 8 --steps 20
+timeout 900 python -m pytest tests/test_example_dev_gpu.py -m gpu -q --tb=short 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -8
+./tools/hbm_probe 1e8 0 w 2>&1 | tee gpurun_out/hbm_probe_write.txt | sort -k7 -n -r | head -12
+timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('value',d['value'],'roofline.frac',d['roofline']['frac'],'whole',d['roofline']['whole_update']['frac'])
+print('f08',d['also_f08_rounding']['value'],d['also_f08_rounding']['roofline']['frac'],d['also_f08_rounding']['roofline']['whole_update']['frac'])
+print(json.dumps(d.get('config5_abstract_vector'),indent=1))
+print(d['cpu_baseline'])"

@@ -205,6 +205,14 @@ int main(int argc, char **argv) {
 #define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
 #define RB(S, W, B, NTS, G) runb<S, W, B, NTS>("burst S=" #S " W=" #W " B=" #B " st=" #NTS, rd, wr, stride, n, out, G)
 #define RP(S, W, NTS, G) runp<S, W, NTS>("pipelined S=" #S " W=" #W " st=" #NTS, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 'w') {   // pure-write study: store policy x tiles per iteration x blocks per CU
+    for (int g : {cu * 1, cu * 2, cu * 4, cu * 8}) {
+      R(0, 4, 1, true, 0, 0, g); R(0, 4, 1, true, 1, 0, g); R(0, 4, 1, true, 2, 0, g); R(0, 4, 1, true, 3, 0, g); R(0, 4, 1, true, 4, 0, g);
+      R(0, 4, 4, true, 0, 0, g); R(0, 4, 4, true, 1, 0, g); R(0, 4, 4, true, 4, 0, g);
+      R(0, 1, 4, true, 1, 0, g); R(0, 1, 4, true, 1, 1, g);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; rep++)
   for (int g : {cu * 1, cu * 2}) {
     R(22, 5, 1, true, 1, 0, g);  RP(22, 5, 1, g); RP(22, 5, 0, g);
