@@ -123,6 +123,10 @@ int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t 
  * rows by s = sqrt(red[0]).  With these a CPU restatement of the scalar step
  * can be checked bit for bit. */
 int nka_hip_get_reductions(nka_hip_t a, double *red_out);
+/* Diagnostic builds of the library (-DNKA_SOLVE_STAMPS) stamp the phases of the
+ * one-wavefront scalar step with s_memtime; this returns the 16 stamps of the most
+ * recent update (zeros in a normal build).  tools/solve_phases.py prints them. */
+int nka_hip_get_stamps(nka_hip_t a, double *out16);
 /* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
 int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);
 int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);

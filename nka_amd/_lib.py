@@ -31,6 +31,7 @@ SIGNATURES = {
     "nka_hip_defined": (C.c_int, [C.c_void_p]),
     "nka_hip_get_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp, _dp]),
     "nka_hip_get_reductions": (C.c_int, [C.c_void_p, _dp]),
+    "nka_hip_get_stamps": (C.c_int, [C.c_void_p, _dp]),
     "nka_hip_get_w": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "nka_hip_get_v": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "nka_hip_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),

@@ -152,6 +152,7 @@ struct nka_hip_state {
   char devname[64] = {0};
   int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
                               // -1 = automatic (see enqueue_pb)
+  int solve_variant = 0;      // 0 = k_solve_wave2 (registers + masks), 1 = k_solve_wave (first version, LDS walks)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
@@ -353,6 +354,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
   a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
+  a->solve_variant = env_int("NKA_HIP_SOLVE_VARIANT", a->solve_variant);
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
@@ -490,7 +492,13 @@ static int enqueue_solve(nka_hip_t a, int mode) {
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int ns = solve_pairs_per_lane(a->mvec);
-#define SOLVE(NS) hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode)
+#define SOLVE(NS)                                                                                        \
+  do {                                                                                                   \
+    if (a->solve_variant == 1)                                                                           \
+      hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);         \
+    else                                                                                                 \
+      hipLaunchKernelGGL((k_solve_wave2<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);        \
+  } while (0)
     if (ns <= 1) SOLVE(1);
     else if (ns <= 2) SOLVE(2);
     else if (ns <= 4) SOLVE(4);
@@ -709,6 +717,15 @@ int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t 
   return 0;
 }
 
+// Diagnostic builds (-DNKA_SOLVE_STAMPS): the s_memtime stamps of the last scalar step.
+int nka_hip_get_stamps(nka_hip_t a, double *out16) {
+  if (!a || !out16) return fail(NKA_HIP_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(a->device));
+  HIP_TRY(hipMemcpyAsync(out16, a->ctl.stamps(), sizeof(double) * kStamps, hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
 int nka_hip_get_reductions(nka_hip_t a, double *red_out) {
   if (!a || !red_out) return fail(NKA_HIP_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(a->device));
@@ -919,6 +936,9 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
+  } else if (k == "solve_variant") {
+    if (value != 0 && value != 1) return fail(NKA_HIP_EINVAL, "solve_variant: 0 or 1");
+    a->solve_variant = value;
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);
   }

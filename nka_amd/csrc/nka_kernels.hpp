@@ -71,6 +71,13 @@ enum { DC_VTOL = 0, DC_S = 1, DC_HEADER = 2 };
 
 constexpr int kMaxPerPass = 32;  // largest MAXL / MAXK instantiated
 
+constexpr int kStamps = 16;      // s_memtime stamps of the scalar step, written only when NKA_SOLVE_STAMPS is defined
+#ifdef NKA_SOLVE_STAMPS
+#define NKA_STAMP(ctl, i) do { if (threadIdx.x == 0) (ctl).stamps()[i] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NKA_STAMP(ctl, i) do { } while (0)
+#endif
+
 struct Ctl {
   int32_t *ic;         // header, then next[M1+1], prev[M1+1], plan_slots[M1+pad], comb_slots[M1+pad]
   double *dc;          // header, then h[(M1+1)^2], c[M1+1], comb_c[M1+pad], red[2+2*mvec]
@@ -89,8 +96,9 @@ struct Ctl {
   __host__ __device__ double *comb_c() const { return c() + (m1() + 1); }
   __host__ __device__ double *red() const { return comb_c() + m1p(); }
   __host__ __device__ int red_count() const { return 2 + 2 * mvec; }
+  __host__ __device__ double *stamps() const { return red() + red_count(); }   // kStamps cycle stamps (diagnostic builds)
   __host__ __device__ int dc_count() const {
-    return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count();
+    return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count() + kStamps;
   }
 };
 // red[] layout (raw sums of PA, d = w1 - f NOT yet divided by s):
@@ -833,7 +841,9 @@ template <int NS>
 __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
+  NKA_STAMP(ctl, 0);
   lst_load(L, ctl, smem);
+  NKA_STAMP(ctl, 1);
   const int lane = threadIdx.x;
   const int NL = ctl.m1(), LDA = NL + 1, M = ctl.mvec;
   // A has NL+1 rows: row nl (one past the list) carries the right-hand side
@@ -873,6 +883,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
   int nl = 0;
   for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;
   __syncthreads();
+  NKA_STAMP(ctl, 2);
   int capdrop = -1;
   bool forward_done = false;
 
@@ -898,6 +909,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
       alive[p] = 1;
     }
     __syncthreads();
+    NKA_STAMP(ctl, 3);
     int kept = 0;
     for (int i = 0; i < nl; i++) {
       bool keep;
@@ -934,6 +946,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
       __syncthreads();
     }
     __syncthreads();
+    NKA_STAMP(ctl, 4);
     // ---- phase 2: scatter the factor back by slot, compact the forward-
     //      substituted right-hand side, replay the drops in list order
 #pragma unroll
@@ -971,6 +984,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
   }
 
   // ---- phase 3: new slot, then the substitutions on the current list
+  NKA_STAMP(ctl, 5);
   const int slot = L.free_;                    // F08:357-358
   L.free_ = L.next[slot];
   int nk = 0;
@@ -994,6 +1008,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
         __syncthreads();
       }
     }
+    NKA_STAMP(ctl, 6);
     for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
       const double ci = bb[i] / A[i * LDA + i];
       __syncthreads();
@@ -1001,6 +1016,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
       for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
       __syncthreads();
     }
+    NKA_STAMP(ctl, 7);
     for (int p = lane; p < nk; p += kSolveThreads) {
       ctl.comb_slots()[p] = ord[p];
       ctl.comb_c()[p] = bb[p];
@@ -1016,7 +1032,278 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode)
     ctl.ic[IC_NCOMB] = nk;
     ctl.ic[IC_NORMED] = normed;
   }
+  NKA_STAMP(ctl, 8);
   lst_store(L, ctl);
+  NKA_STAMP(ctl, 9);
+}
+
+// ---- the wavefront solve, second version: registers where the first one walks LDS ----
+// k_solve_wave spends most of its ~66 k cycles (m = 20, tools/solve_phases.py) not on
+// arithmetic but on SERIAL LDS round trips of ~130 cycles each: the list walks
+// (three per update), the per-column pivot read, the position loops over `alive`,
+// and two global round trips at entry.  Same algorithm, same operation order per
+// matrix entry (hence the same bits), with
+//   * ONE global round trip at entry (state, sums and plan loaded together);
+//   * lane k holding next[k]: the list is walked with v_readlane (~10 cycles a step);
+//   * lane p holding the running pivot, the accepted pivot and the right-hand side
+//     of list position p (pivot broadcast by v_readlane, no LDS);
+//   * `alive` as a 64-bit mask: drops are visited by count-trailing-zeros, compaction
+//     by population count, in parallel;
+//   * the back-substitution in POSITION space on the factor where it lies (no
+//     re-gather by slot); the plan of the next update written in parallel.
+// The rare path without a new pair (after relax / s == 0) keeps the first version's
+// gather-and-substitute code.
+__device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane_uniform);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane_uniform);
+  return u.d;
+}
+
+template <int NS>
+__global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
+  Lst L;
+  L.m1 = m1;
+  L.mvec = M;
+  L.h = reinterpret_cast<double *>(smem);
+  L.c = L.h + nh;
+  L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
+  L.prev = L.next + (m1 + 1);
+  double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
+  double *bb = A + (NL + 1) * LDA + 2 * NL;   // (same carve-up as k_solve_wave: dd and Ld slots unused here)
+  double *redL = bb + NL;
+  int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
+  int32_t *psL = ord + 2 * NL;
+  NKA_STAMP(ctl, 0);
+  // ---- one global round trip
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  for (int i = lane; i < nh; i += kSolveThreads) L.h[i] = ctl.h()[i];
+  for (int i = lane; i < m1 + 1; i += kSolveThreads) {
+    L.c[i] = ctl.c()[i];
+    L.next[i] = ctl.next()[i];
+    L.prev[i] = ctl.prev()[i];
+  }
+  for (int i = lane; i < 2 + 2 * M; i += kSolveThreads) redL[i] = ctl.red()[i];
+  for (int i = lane; i < nolder; i += kSolveThreads) psL[i] = ctl.plan_slots()[i];
+  L.subspace = ctl.ic[IC_SUBSPACE];
+  L.pending = ctl.ic[IC_PENDING];
+  L.first = ctl.ic[IC_FIRST];
+  L.last = ctl.ic[IC_LAST];
+  L.free_ = ctl.ic[IC_FREE];
+  L.vtol = ctl.dc[DC_VTOL];
+  const int entry_pending = L.pending;
+  __syncthreads();
+  NKA_STAMP(ctl, 1);
+  const double vtol2 = L.vtol * L.vtol;
+
+  // ---- phase 0: norm, s == 0 -> relax, Gram row of w1' = d/s, right-hand side
+  const int entry_first = L.first;
+  int normed = 0;
+  double s = 0.0;
+  if (L.pending) {
+    s = sqrt(redL[0]);                        // F08:267
+    if (s == 0.0) lst_relax(L);               // F08:275
+  }
+  if (L.pending) normed = 1;
+  {
+    const double rs = 1.0 / s;
+    for (int p = lane; p < nolder; p += kSolveThreads) {
+      if (normed) L.H(L.first, psL[p]) = solve_nrm(redL[2 + p], s, rs, mode);         // F08:286-290
+      L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
+    }
+    if (normed && lane == 0) L.c[entry_first] = solve_nrm(redL[1], s, rs, mode);     // <f,w1'> = <f,d>/s
+  }
+  __syncthreads();
+  // list position -> slot, walked through registers: lane k holds next[k]
+  const int nxt = (lane <= m1) ? L.next[lane] : 0;
+  int nl = 0, myord = 0;
+  for (int k = __builtin_amdgcn_readfirstlane(L.first); k != 0;) {
+    if (lane == nl) myord = k;
+    nl++;
+    k = __builtin_amdgcn_readlane(nxt, k);
+  }
+  if (lane < nl) ord[lane] = myord;
+  __syncthreads();
+  NKA_STAMP(ctl, 2);
+  const uint64_t listmask = (nl >= 64) ? ~0ull : ((1ull << nl) - 1);
+  uint64_t alive = listmask;
+  int capdrop = -1;
+  bool forward_done = false;
+  double ddr = 1.0;    // lane p: running pivot 1 - sum l^2 of list position p
+  double Ldr = 1.0;    // lane p: accepted pivot sqrt(hkk)
+  double yr = 0.0;     // lane p: right-hand side / solution of list position p
+  int nk = 0;
+
+  if (normed) {
+    // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
+    //      plus the right-hand side as row nl (lane p scales row p of each column).
+    int pp[NS], qq[NS];
+    const int npairs = (nl + 1) * nl / 2;
+#pragma unroll
+    for (int t = 0; t < NS; t++) {
+      const int idx = lane + kSolveThreads * t;
+      int p = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
+      while (p * (p - 1) / 2 > idx) p--;
+      while ((p + 1) * p / 2 <= idx) p++;
+      pp[t] = idx < npairs ? p : 0;
+      qq[t] = idx < npairs ? idx - p * (p - 1) / 2 : 0;
+      if (idx < npairs) A[p * LDA + qq[t]] = (p < nl) ? L.H(ord[qq[t]], ord[p])   // raw <w_q,w_p>, q newer
+                                                       : L.c[ord[qq[t]]];           // rhs <f,w_q>
+    }
+    __syncthreads();
+    NKA_STAMP(ctl, 3);
+    int kept = 0;
+    for (int i = 0; i < nl; i++) {
+      bool keep;
+      double Lii = 1.0;
+      if (i == 0) {
+        keep = true;                           // F08:295 h(first,first) = 1
+      } else if (kept + 1 > L.mvec) {
+        keep = false;                          // F08:301-308 capacity: i is the last entry
+        capdrop = i;
+      } else {
+        const double hkk = readlane_f64(ddr, i);
+        keep = hkk > vtol2;                    // F08:326
+        if (keep) Lii = sqrt(hkk);
+      }
+      if (!keep) {
+        alive &= ~(1ull << i);
+        if (capdrop >= 0) break;
+        continue;
+      }
+      kept++;
+      if (lane == i) Ldr = Lii;
+      if (lane > i && lane <= nl) {
+        const double l = A[lane * LDA + i] / Lii;  // F08:320 (row nl: F08:377)
+        A[lane * LDA + i] = l;
+        if (lane < nl) ddr = ddr - l * l;          // F08:321
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < NS; t++) {
+        const int p = pp[t], q = qq[t];
+        if (q > i && p > q)                      // trailing entry: F08:317 (row nl: F08:374)
+          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];
+      }
+      __syncthreads();
+    }
+    NKA_STAMP(ctl, 4);
+    // ---- phase 2: scatter the factor back by slot; replay the drops in list order
+#pragma unroll
+    for (int t = 0; t < NS; t++) {
+      const int p = pp[t], q = qq[t];
+      if (p > q && p < nl && ((alive >> p) & 1) && ((alive >> q) & 1)) L.H(ord[p], ord[q]) = A[p * LDA + q];
+    }
+    if (lane < nl && ((alive >> lane) & 1)) L.H(myord, myord) = Ldr;
+    if (lane < nl) yr = A[nl * LDA + lane];    // forward-substituted right-hand side of position p
+    forward_done = true;
+    for (uint64_t dm = ~alive & listmask & ~1ull; dm != 0; dm &= dm - 1) {
+      const int p = __builtin_ctzll(dm);
+      const int k = __builtin_amdgcn_readlane(myord, p);
+      if (p == capdrop) {                      // F08:303-307
+        L.next[L.last] = L.free_;
+        L.free_ = k;
+        L.last = L.prev[k];
+        L.next[L.last] = 0;
+      } else {                                 // F08:331-340
+        const int pv = L.prev[k], nx = L.next[k];
+        L.next[pv] = nx;
+        if (nx == 0) L.last = pv; else L.prev[nx] = pv;
+        L.next[k] = L.free_;
+        L.free_ = k;
+      }
+    }
+    L.subspace = 1;
+    L.pending = 0;
+    __syncthreads();
+  }
+
+  // ---- phase 3: new slot, then the substitutions on the current list
+  NKA_STAMP(ctl, 5);
+  const int slot = L.free_;                    // F08:357-358
+  L.free_ = L.next[slot];
+  if (forward_done) {
+    // back-substitution F08:382-392 in position space: the factor lies in A, its
+    // diagonal in Ldr, the forward-substituted right-hand side in yr
+    NKA_STAMP(ctl, 6);
+    for (int i = nl - 1; i >= 0; i--) {
+      if (!((alive >> i) & 1)) continue;
+      const double ci = readlane_f64(yr, i) / readlane_f64(Ldr, i);
+      if (lane == i) yr = ci;
+      if (lane < i && ((alive >> lane) & 1)) yr = yr - A[i * LDA + lane] * ci;
+    }
+    NKA_STAMP(ctl, 7);
+    nk = __builtin_popcountll(alive & listmask);
+    if (lane < nl && ((alive >> lane) & 1)) {
+      const int r = __builtin_popcountll(alive & ((1ull << lane) - 1));   // position among the kept entries
+      ctl.comb_slots()[r] = myord;
+      ctl.comb_c()[r] = yr;
+      ctl.plan_slots()[r] = myord;             // the next update's older entries: this list, in order
+      L.c[myord] = yr;
+    }
+  } else if (L.subspace) {
+    // no new pair this call (after relax / s == 0): substitute on the stored factor
+    for (int k = L.first; k != 0; k = L.next[k]) ord[nk++] = k;
+    __syncthreads();
+    for (int p = lane; p < nk; p += kSolveThreads) bb[p] = L.c[ord[p]];
+    for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
+      const int p = idx / nk, q = idx - p * nk;
+      if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
+    }
+    __syncthreads();
+    for (int i = 0; i < nk; i++) {             // forward, F08:369-379
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
+      __syncthreads();
+    }
+    for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
+      __syncthreads();
+    }
+    for (int p = lane; p < nk; p += kSolveThreads) {
+      ctl.comb_slots()[p] = ord[p];
+      ctl.comb_c()[p] = bb[p];
+      ctl.plan_slots()[p] = ord[p];
+      L.c[ord[p]] = bb[p];
+    }
+  }
+  __syncthreads();
+  lst_prepend(L, slot);                        // F08:406-417 (every lane, same values)
+  NKA_STAMP(ctl, 8);
+  // ---- state back to global memory (the plan was written above: without a subspace
+  //      the list was empty before the prepend, so the next update has no older entry)
+  __syncthreads();
+  for (int i = lane; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
+  for (int i = lane; i < m1 + 1; i += kSolveThreads) {
+    ctl.c()[i] = L.c[i];
+    ctl.next()[i] = L.next[i];
+    ctl.prev()[i] = L.prev[i];
+  }
+  if (lane == 0) {
+    ctl.dc[DC_S] = s;
+    if (entry_first != 0 && !normed && entry_pending) ctl.ic[IC_NRELAX] += 1;
+    ctl.ic[IC_NEW] = slot;
+    ctl.ic[IC_NCOMB] = nk;
+    ctl.ic[IC_NORMED] = normed;
+    ctl.ic[IC_SUBSPACE] = L.subspace;
+    ctl.ic[IC_PENDING] = L.pending;
+    ctl.ic[IC_FIRST] = L.first;
+    ctl.ic[IC_LAST] = L.last;
+    ctl.ic[IC_FREE] = L.free_;
+    ctl.ic[IC_PLAN_PENDING] = L.pending;
+    ctl.ic[IC_PLAN_FIRST] = L.first;
+    ctl.ic[IC_PLAN_NOLDER] = nk;
+  }
+  NKA_STAMP(ctl, 9);
 }
 
 }  // namespace nka

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where does the one-wavefront scalar step spend its time?  Needs a diagnostic
+build of the library with s_memtime stamps:
+
+  make -C nka_amd/csrc stamps
+  NKA_HIP_LIB=$PWD/nka_amd/libnka_hip_stamps.so python tools/solve_phases.py [--mvec 20] [--vlen 1e5]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NAMES = ["lst_load", "red/plan staging + list walk", "pair setup + gather A", "factorisation loop", "scatter + drop replay",
+         "new slot + ord + gather (phase 3 head)", "backward substitution", "comb plan stores", "lst_store"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mvec", type=int, default=20)
+    ap.add_argument("--vlen", type=float, default=1e5)
+    ap.add_argument("--variant", type=int, default=0, help="0 = k_solve_wave2, 1 = k_solve_wave")
+    a = ap.parse_args()
+    import torch
+    import nka_amd
+    n, m = int(a.vlen), a.mvec
+    acc = nka_amd.nka().init(n, m)
+    acc.set_tuning("solve_variant", a.variant)
+    L = nka_amd.load()
+    rng = np.random.default_rng(0)
+    rows = []
+    for t in range(m + 12):
+        f = torch.from_numpy(rng.standard_normal(n)).cuda()
+        acc.accel_update(f)
+        st = np.zeros(16)
+        L.nka_hip_get_stamps(acc._handle(), st.ctypes.data_as(C.POINTER(C.c_double)))
+        if t >= m + 2:
+            rows.append(np.diff(st[:10]))
+    d = np.median(np.array(rows), axis=0)
+    tot = d.sum()
+    print(f"{'k_solve_wave' if a.variant else 'k_solve_wave2'} phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (100 MHz => 10 ns):")
+    for nm, v in zip(NAMES, d):
+        print(f"  {nm:<42s} {v:8.0f} ticks  {v * 0.01:7.2f} us  {100 * v / tot:5.1f} %")
+    print(f"  {'total inside the kernel':<42s} {tot:8.0f} ticks  {tot * 0.01:7.2f} us")
+
+
+if __name__ == "__main__":
+    main()
