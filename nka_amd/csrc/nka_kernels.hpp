@@ -1141,7 +1141,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
   if (normed) {
     // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
     //      plus the right-hand side as row nl (lane p scales row p of each column).
-    int pp[NS], qq[NS];
+    // Every LDS access of a lane's NS pairs is issued as a batch (all reads of a
+    // stage, then all uses): a lone wavefront cannot hide a ~130-cycle LDS round
+    // trip behind anything else, so NS serial read -> use chains cost NS round trips.
+    int pp[NS], qq[NS], op[NS], oq[NS];
     const int npairs = (nl + 1) * nl / 2;
 #pragma unroll
     for (int t = 0; t < NS; t++) {
@@ -1149,10 +1152,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
       int p = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
       while (p * (p - 1) / 2 > idx) p--;
       while ((p + 1) * p / 2 <= idx) p++;
-      pp[t] = idx < npairs ? p : 0;
+      pp[t] = idx < npairs ? p : 0;                // unused pairs sit on (0,0): every address below stays valid
       qq[t] = idx < npairs ? idx - p * (p - 1) / 2 : 0;
-      if (idx < npairs) A[p * LDA + qq[t]] = (p < nl) ? L.H(ord[qq[t]], ord[p])   // raw <w_q,w_p>, q newer
-                                                       : L.c[ord[qq[t]]];           // rhs <f,w_q>
+    }
+#pragma unroll
+    for (int t = 0; t < NS; t++) {                 // slots of the pair's two list positions (row nl: the rhs)
+      op[t] = ord[pp[t] < nl ? pp[t] : 0];
+      oq[t] = ord[qq[t]];
+    }
+    {
+      double g[NS];
+#pragma unroll
+      for (int t = 0; t < NS; t++)
+        g[t] = (pp[t] < nl) ? L.H(oq[t], op[t])    // raw <w_q,w_p>, q newer
+                            : L.c[oq[t]];          // rhs <f,w_q>
+#pragma unroll
+      for (int t = 0; t < NS; t++)
+        if (pp[t] > qq[t]) A[pp[t] * LDA + qq[t]] = g[t];
     }
     __syncthreads();
     NKA_STAMP(ctl, 3);
@@ -1183,20 +1199,32 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
         if (lane < nl) ddr = ddr - l * l;          // F08:321
       }
       __syncthreads();
+      {
+        double ap[NS], aq[NS], apq[NS];
 #pragma unroll
-      for (int t = 0; t < NS; t++) {
-        const int p = pp[t], q = qq[t];
-        if (q > i && p > q)                      // trailing entry: F08:317 (row nl: F08:374)
-          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];
+        for (int t = 0; t < NS; t++) {
+          ap[t] = A[pp[t] * LDA + i];
+          aq[t] = A[qq[t] * LDA + i];
+          apq[t] = A[pp[t] * LDA + qq[t]];
+        }
+#pragma unroll
+        for (int t = 0; t < NS; t++)
+          if (qq[t] > i && pp[t] > qq[t])        // trailing entry: F08:317 (row nl: F08:374)
+            A[pp[t] * LDA + qq[t]] = apq[t] - ap[t] * aq[t];
       }
       __syncthreads();
     }
     NKA_STAMP(ctl, 4);
     // ---- phase 2: scatter the factor back by slot; replay the drops in list order
+    {
+      double g[NS];
 #pragma unroll
-    for (int t = 0; t < NS; t++) {
-      const int p = pp[t], q = qq[t];
-      if (p > q && p < nl && ((alive >> p) & 1) && ((alive >> q) & 1)) L.H(ord[p], ord[q]) = A[p * LDA + q];
+      for (int t = 0; t < NS; t++) g[t] = A[pp[t] * LDA + qq[t]];
+#pragma unroll
+      for (int t = 0; t < NS; t++) {
+        const int p = pp[t], q = qq[t];
+        if (p > q && p < nl && ((alive >> p) & 1) && ((alive >> q) & 1)) L.H(op[t], oq[t]) = g[t];
+      }
     }
     if (lane < nl && ((alive >> lane) & 1)) L.H(myord, myord) = Ldr;
     if (lane < nl) yr = A[nl * LDA + lane];    // forward-substituted right-hand side of position p
