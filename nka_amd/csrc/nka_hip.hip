@@ -143,6 +143,7 @@ struct nka_hip_state {
   Ctl ctl{};
   double *partials = nullptr;
   double *f_stage = nullptr;  // device staging for the host-array entry point
+  double *hd_scratch = nullptr;  // device vector for the operands of a user host dot product (set_host_dot)
   // what the host knows without reading the device back
   bool pending = false;
   int list_ub = 0;            // upper bound on the list length
@@ -447,6 +448,7 @@ int nka_hip_destroy(nka_hip_t a) {
   hipFree(a->ctl.dc);
   hipFree(a->partials);
   hipFree(a->f_stage);
+  hipFree(a->hd_scratch);
   for (auto &e : a->ev)
     if (e) hipEventDestroy(e);
   a->ev.clear();
@@ -550,17 +552,31 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   return 0;
 }
 
+// Operands of the user's dot product, formed ON THE DEVICE with the rounding of the
+// stored vectors: out = w1 - f (F08:266), then out = out/s or (1/s)*out (F08:283 / F08V:256).
+static __global__ __launch_bounds__(kBlock) void k_hostdot_diff(int64_t n, const double *__restrict__ w1,
+                                                                const double *__restrict__ f, double *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = w1[i] - f[i];
+}
+static __global__ __launch_bounds__(kBlock) void k_hostdot_normalise(int64_t n, double *__restrict__ d, double s, int rcp) {
+  const double rs = 1.0 / s;
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    d[i] = rcp ? rs * d[i] : d[i] / s;
+}
+
 // The inner products of an update through the USER's host dot product
 // (nka_hip_set_host_dot): the reference's own sequence of dp calls on host copies
 // of the operands -- dp(d,d) with d = w1 - f (F08:266-267), then on the
 // normalised w1' = d/s the Gram row dp(w1', w_k) (F08:288) and the projections
 // dp(f, w_j) (F08:371) -- written to red[] for the device scalar step (mode
-// kSolvePrenorm).  Synchronous and PCIe-bound by construction: a compatibility
-// path, never the measured one.
+// kSolvePrenorm).  d and w1' are formed by device kernels (the host only copies,
+// calls dp and takes one square root to know whether s == 0).  Synchronous and
+// PCIe-bound by construction: a compatibility path, never the measured one.
 static int host_dot_sums(nka_hip_t a, const double *f) {
   const int64_t n = a->n;
   const int mvec = a->mvec;
-  const bool rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR);
+  const int rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? 1 : 0;
   HIP_TRY(hipStreamSynchronize(a->stream));
   std::vector<int32_t> ic(a->ctl.ic_count());
   HIP_TRY(hipMemcpy(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost));
@@ -569,19 +585,26 @@ static int host_dot_sums(nka_hip_t a, const double *f) {
   if (nolder < 0 || nolder > mvec + 1 || (pending && (first < 1 || first > mvec + 1)))
     return fail(NKA_HIP_ESTATE, "host dot path: corrupt dot plan on the device");
   const size_t nb = sizeof(double) * (size_t)n;
+  if (pending && !a->hd_scratch) HIP_TRY(hipMalloc((void **)&a->hd_scratch, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)a->num_cu * 8));
   std::vector<double> hf((size_t)n), hw1(pending ? (size_t)n : 0), hk((size_t)n);
   std::vector<double> red((size_t)a->ctl.red_count(), 0.0);
   if (n > 0) HIP_TRY(hipMemcpy(hf.data(), f, nb, hipMemcpyDeviceToHost));
   bool normed = false;
   if (pending) {
-    if (n > 0) HIP_TRY(hipMemcpy(hw1.data(), a->vs.w + (size_t)(first - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) hw1[i] = hw1[i] - hf[i];                     // F08:266
-    red[0] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hw1.data());           // F08:267 (s = sqrt of it on the device)
+    hipLaunchKernelGGL(k_hostdot_diff, dim3(g), dim3(kBlock), 0, a->stream, n,
+                       a->vs.w + (size_t)(first - 1) * a->vs.stride, f, a->hd_scratch);
+    HIP_TRY(hipGetLastError());
+    if (n > 0) HIP_TRY(hipMemcpyAsync(hw1.data(), a->hd_scratch, nb, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    red[0] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hw1.data());           // F08:267 (the device takes the sqrt again)
     const double s = std::sqrt(red[0]);
     if (s != 0.0) {                                                               // F08:275, else relax
       normed = true;
-      const double rs = 1.0 / s;
-      for (int64_t i = 0; i < n; i++) hw1[i] = rcp ? rs * hw1[i] : hw1[i] / s;   // F08:283 / F08V:256
+      hipLaunchKernelGGL(k_hostdot_normalise, dim3(g), dim3(kBlock), 0, a->stream, n, a->hd_scratch, s, rcp);
+      HIP_TRY(hipGetLastError());
+      if (n > 0) HIP_TRY(hipMemcpyAsync(hw1.data(), a->hd_scratch, nb, hipMemcpyDeviceToHost, a->stream));
+      HIP_TRY(hipStreamSynchronize(a->stream));
       red[1] = a->host_dot(a->host_dot_ctx, n, hf.data(), hw1.data());          // F08:371, j = first
     }
   }
