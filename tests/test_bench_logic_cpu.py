@@ -1,0 +1,66 @@
+"""Host logic of bench.py that needs no GPU: the byte model, the physical
+roofline block (every `frac` = bytes moved / time / 8 TB/s), and the contract
+ratio kept apart from it."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_byte_model_matches_the_schedule(bench):
+    # PA reads w1, f and the L stored w; PB reads f + pairs and writes 5 streams
+    assert bench.words_moved("f08", 20, 20) == {"PA_k_dots": 22, "PB_k_combine": 46}
+    assert bench.words_moved("c", 20, 20) == {"PA_k_dots": 22, "PB_k_combine": 27}      # compact: one vector per pair
+    assert bench.words_moved("f08vec", 10, 10) == {"PA_k_dots": 12, "PB_k_combine": 26}
+    # whole update: 8n(8+L+2k) for F08, 8n(9+L+k) compact
+    for L in (5, 10, 20):
+        assert sum(bench.words_moved("f08", L, L).values()) == 8 + 3 * L
+        assert sum(bench.words_moved("c", L, L).values()) == 9 + 2 * L
+
+
+@pytest.mark.parametrize("flavor,pa_ms,pb_ms", [("c", 2.7, 3.6), ("f08", 2.7, 6.5), ("c", 1.0, 1.2)])
+def test_roofline_block_is_physical(bench, flavor, pa_ms, pb_ms):
+    n, m = 10**8, 20
+    mean = [pa_ms, 0.03, pb_ms, pa_ms + 0.03 + pb_ms + 0.01]
+    r = bench.roofline_block(flavor, n, m, mean, 5000.0)
+    w = bench.words_moved(flavor, m, m)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    dom = "PB_k_combine" if pb_ms >= pa_ms else "PA_k_dots"
+    assert r["kernel"] == dom
+    # achieved = bytes the launch moves / its duration; frac = achieved / peak
+    want = 8.0 * n * w[dom] / (mean[2 if dom == "PB_k_combine" else 0] * 1e-3) / 1e9
+    assert r["achieved"] == pytest.approx(want)
+    assert r["frac"] == pytest.approx(want / 8000.0)
+    moved = 8.0 * n * sum(w.values())
+    assert r["whole_update"]["bytes_moved"] == moved
+    assert r["whole_update"]["frac"] == pytest.approx(moved / (mean[3] * 1e-3) / 1e9 / 8000.0)
+    # the contract's B_alg never enters a fraction: it is a ratio and a work rate
+    assert r["contract_bytes_per_update"] == 8.0 * n * (11 + 3 * m)
+    assert r["contract_bytes_ratio"] == pytest.approx(8.0 * n * (11 + 3 * m) / moved)
+    assert r["contract_GBps"] == pytest.approx(r["whole_update"]["achieved"] * r["contract_bytes_ratio"])
+    if pb_ms > 2.0:                          # realistic timings: below the peak
+        assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["whole_update"]["frac"] <= 1.0
+        for k in ("PA_k_dots", "PB_k_combine"):
+            assert 0.0 < r["kernels"][k]["frac"] <= 1.0
+
+
+def test_committed_pmc_traffic_agrees_with_the_byte_model(bench):
+    """profiles/r*/pmc_traffic_*.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) vs 8n x words."""
+    n, m = 10**8, 20
+    for flavor in ("c", "f08"):
+        pm, src = bench.pmc_traffic(flavor, n, m)
+        assert pm is not None, "no committed PMC summary for the headline workload"
+        w = bench.words_moved(flavor, m, m)
+        for key, name in (("k_dots", "PA_k_dots"), ("k_combine", "PB_k_combine")):
+            k = pm["kernels"][key]
+            assert (k["read_bytes"] + k["write_bytes"]) == pytest.approx(8.0 * n * w[name], rel=2e-3), (src, key)
