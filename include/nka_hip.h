@@ -259,20 +259,22 @@ int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const doubl
  * vector%update_norm2 / scale_dot_pair_many / update_many_keep / axpy_many_keep;
  * each default body is the reference's own hook sequence, F08V:237-238, 255-264 +
  * 347, 336 + 374 + 382).  Elementwise results are rounded like those hook calls.
- *   update_norm2:        z <- a*x + z ; *host_norm = ||z||_2
- *   scale_dot_pair_many: w <- a*w ; v <- a*v (subtract: v <- (-1)*w + v) ; then with
- *                        the new w: vals_w[j] = <w,ys[j]>, vals_f[j] = <f,ys[j]>,
- *                        *cross = <f,w>
+ *   update_norm2:        *host_norm = ||a*x + z||_2 ; store != 0: z <- a*x + z, store == 0:
+ *                        z untouched -- the update is then applied by the next stage
+ *   scale_dot_pair_many: [pre != 0: w <- pre_a*f + w ;] w <- a*w ; v <- a*v (subtract:
+ *                        v <- (-1)*w + v) ; then with the new w: vals_w[j] = <w,ys[j]>,
+ *                        vals_f[j] = <f,ys[j]>, *cross = <f,w>
  *   update_many_keep:    keep_in <- z ; z <- (a[j]*xs[j] + b[j]*ys[j]) + z in order ;
  *                        keep_out <- z          (keep_in / keep_out may be NULL)
  *   axpy_many_keep:      the same with z <- a[j]*xs[j] + z
- * With them an update of the abstract path moves 8n(12+3m) bytes in 3 passes. */
+ * With the norm stage deferring its store an update of the abstract path moves
+ * 8n(11+3m) bytes in 3 passes: exactly the contract's figure. */
 int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
-                             double *host_norm);
+                             int32_t store, double *host_norm);
 int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a,
-                                    int32_t subtract, const double *f, const double *const *ys,
-                                    int32_t count, double *host_vals_w, double *host_vals_f,
-                                    double *host_cross);
+                                    int32_t subtract, int32_t pre, double pre_a, const double *f,
+                                    const double *const *ys, int32_t count, double *host_vals_w,
+                                    double *host_vals_f, double *host_cross);
 int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                                  const double *const *xs, const double *b, const double *const *ys,
                                  int32_t count, double *keep_in, double *keep_out);

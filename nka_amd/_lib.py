@@ -67,9 +67,10 @@ SIGNATURES = {
     "nka_hip_vec_update_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                           C.POINTER(C.c_void_p), C.c_int32]),
     "nka_hip_vec_axpy_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32]),
-    "nka_hip_vec_update_norm2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, _dp]),
+    "nka_hip_vec_update_norm2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, _dp]),
     "nka_hip_vec_scale_dot_pair_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
-                                                  C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp]),
+                                                  C.c_int32, C.c_double, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32,
+                                                  _dp, _dp, _dp]),
     "nka_hip_vec_update_many_keep": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                                C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p]),
     "nka_hip_vec_axpy_many_keep": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32,

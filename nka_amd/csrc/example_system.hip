@@ -14,6 +14,7 @@
 namespace nka_detail {
 int set_error(int code, const std::string &msg);
 int check_device_span(const void *p, int64_t n, const char *what);
+void invalidate_span_cache();
 }
 
 struct nka_ex_system {
@@ -171,6 +172,7 @@ int nka_ex_create(nka_ex_t *out, int32_t nx, int32_t ny, double a, int32_t devic
 
 int nka_ex_destroy(nka_ex_t s) {
   if (!s) return 0;
+  nka_detail::invalidate_span_cache();
   hipSetDevice(s->device);
   hipStreamSynchronize(s->stream);
   hipFree(s->ax);

@@ -23,6 +23,7 @@ extern "C" const char *nka_hip_last_error(void);
 namespace nka_detail {
 int set_error(int code, const std::string &msg);
 int check_device_span(const void *p, int64_t n, const char *what);
+void invalidate_span_cache();
 }
 
 struct nka_hip_vec_ws {
@@ -252,9 +253,10 @@ __global__ __launch_bounds__(kBlock) void k_axpy_many(int64_t n, double *z, Many
 // ---- fused stages of the vector-flavour update (vector_class: update_norm2,
 // scale_dot_pair_many, update_many_keep, axpy_many_keep) ------------------------------
 
-// z <- a*x + z (update1_, grid_vector_type.F90:127) and the partial sum of z^2 of
-// the RESULT (norm2, :185-197) in the same pass: F08V:237-238 as one kernel.
-template <int VEC>
+// r = a*x + z (update1_, grid_vector_type.F90:127) and the partial sum of r^2 (norm2,
+// :185-197) in the same pass: F08V:237-238 as one kernel.  STORE: z <- r; otherwise z
+// is left untouched and the next stage applies the same update before scaling.
+template <int VEC, bool STORE>
 __global__ __launch_bounds__(kBlock) void k_update_norm2(int64_t n, double *z, const double *__restrict__ x, double a,
                                                          double *__restrict__ partials) {
   using V = typename VecT<VEC>::type;
@@ -271,22 +273,23 @@ __global__ __launch_bounds__(kBlock) void k_update_norm2(int64_t n, double *z, c
       setc(zv, q, r);
       acc[0] = fma(r, r, acc[0]);
     }
-    st(z + e, zv);
+    if (STORE) st(z + e, zv);
   }
   if (blockIdx.x == G - 1)
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
       const double r = a * x[i] + z[i];
-      z[i] = r;
+      if (STORE) z[i] = r;
       acc[0] = fma(r, r, acc[0]);
     }
   block_reduce_store<1>(acc, partials, G);
 }
 
-// F08V:255-264 + :347 in one pass: w <- a*w, v <- a*v (scale, grid_vector_type.F90:
+// F08V:255-264 + :347 in one pass: [PRE: first w <- pre_a*f + w, the update1_ of F08V:237
+// when the norm stage left it undone,] w <- a*w, v <- a*v (scale, grid_vector_type.F90:
 // 117) [SUB: then v <- (-1)*w + v, the compact option's update1_], both stored, and
 // with the NEW w: partials[j] = <w, y_j>, partials[NV+j] = <f, y_j>, partials[2NV] = <f, w>.
-template <int NV, int VEC, bool SUB>
-__global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, double *w, double *v, double a,
+template <int NV, int VEC, bool SUB, bool PRE>
+__global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, double *w, double *v, double a, double pre_a,
                                                                 const double *__restrict__ f, ManyArgs m,
                                                                 double *__restrict__ partials) {
   using V = typename VecT<VEC>::type;
@@ -305,12 +308,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < VEC; q++) {
-      const double wn = a * ex(wv, q);
+      const double fq = ex(fv, q);
+      const double w0 = PRE ? pre_a * fq + ex(wv, q) : ex(wv, q);
+      const double wn = a * w0;
       double vn = a * ex(vv, q);
       if (SUB) vn = (-1.0) * wn + vn;
       setc(wv, q, wn);
       setc(vv, q, vn);
-      const double fq = ex(fv, q);
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
@@ -323,12 +327,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
   }
   if (blockIdx.x == G - 1)
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
-      const double wn = a * w[i];
+      const double fq = f[i];
+      const double w0 = PRE ? pre_a * fq + w[i] : w[i];
+      const double wn = a * w0;
       double vn = a * v[i];
       if (SUB) vn = (-1.0) * wn + vn;
       w[i] = wn;
       v[i] = vn;
-      const double fq = f[i];
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
@@ -508,6 +513,7 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
 
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   if (!ws) return 0;
+  nka_detail::invalidate_span_cache();
   hipSetDevice(ws->device);
   hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
@@ -528,6 +534,7 @@ int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev) {
   if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
   HIP_TRYV(hipSetDevice(ws->device));
   HIP_TRYV(hipStreamSynchronize(ws->stream));
+  nka_detail::invalidate_span_cache();
   HIP_TRYV(hipFree(dev));
   return 0;
 }
@@ -615,8 +622,8 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3((m.count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
-                       ws->partials, g, m.count, m.count, ws->host_results_dev);
+    hipLaunchKernelGGL(k_finalize, dim3(m.count), dim3(kBlock), 0, ws->stream, ws->partials, g, m.count, m.count,
+                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
@@ -655,8 +662,8 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3((2 * nv + 1 + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
-                       ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->host_results_dev);
+    hipLaunchKernelGGL(k_finalize, dim3(2 * nv + 1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1,
+                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) {
@@ -738,8 +745,9 @@ int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const doubl
 // ---- fused stages (overrides of vector%update_norm2 / scale_dot_pair_many /
 // update_many_keep / axpy_many_keep, nka_amd/fortran/vector/vector_class.F90) ---------
 
-// z <- a*x + z ; *host_norm = ||z||_2 of the result.
-int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
+// *host_norm = ||a*x + z||_2 ; store != 0: z <- a*x + z, else z is left as it is (the
+// caller applies the update in the next stage, nka_hip_vec_scale_dot_pair_many with pre).
+int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, int32_t store,
                              double *host_norm) {
   if (!ws || !host_norm || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_norm = 0.0;
@@ -749,10 +757,14 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
   if (int rc = nka_detail::check_device_span(x, n, "vec_update_norm2: x")) return rc;
   const bool v2 = al16(z) && al16(x);
   const int g = grid_for(ws, n, v2 ? 2 : 1);
-  if (v2)
-    hipLaunchKernelGGL((k_update_norm2<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+  if (v2 && store)
+    hipLaunchKernelGGL((k_update_norm2<2, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+  else if (v2)
+    hipLaunchKernelGGL((k_update_norm2<2, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+  else if (store)
+    hipLaunchKernelGGL((k_update_norm2<1, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
   else
-    hipLaunchKernelGGL((k_update_norm2<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
+    hipLaunchKernelGGL((k_update_norm2<1, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->host_result_dev);
   HIP_TRYV(hipGetLastError());
   HIP_TRYV(hipStreamSynchronize(ws->stream));
@@ -760,12 +772,12 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
   return 0;
 }
 
-// w <- a*w ; v <- a*v (subtract != 0: then v <- (-1)*w + v) ; with the new w:
-// vals_w[j] = <w, ys[j]>, vals_f[j] = <f, ys[j]>, *cross = <f, w>.  One pass when
-// count <= 24; longer lists scale in the first launch and only add dots after it.
+// [pre != 0: w <- pre_a*f + w ;] w <- a*w ; v <- a*v (subtract != 0: then v <- (-1)*w + v) ;
+// with the new w: vals_w[j] = <w, ys[j]>, vals_f[j] = <f, ys[j]>, *cross = <f, w>.  One pass
+// when count <= 24; longer lists scale in the first launch and only add dots after it.
 int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
-                                    const double *f, const double *const *ys, int32_t count, double *host_vals_w,
-                                    double *host_vals_f, double *host_cross) {
+                                    int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
+                                    double *host_vals_w, double *host_vals_f, double *host_cross) {
   if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals_w || !host_vals_f)))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_cross = 0.0;
@@ -787,18 +799,35 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
     }
     const int nv = width_for(m.count);
     const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 3);
-#define LAUNCH2S(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
-#define LAUNCH2N(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
-#define LAUNCH1S(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
-#define LAUNCH1N(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, f, m, ws->partials)
-    if (v2) { if (subtract) { NKA_DISPATCH_NV(nv, LAUNCH2S) } else { NKA_DISPATCH_NV(nv, LAUNCH2N) } }
-    else    { if (subtract) { NKA_DISPATCH_NV(nv, LAUNCH1S) } else { NKA_DISPATCH_NV(nv, LAUNCH1N) } }
-#undef LAUNCH2S
-#undef LAUNCH2N
-#undef LAUNCH1S
-#undef LAUNCH1N
-    hipLaunchKernelGGL(k_finalize, dim3((2 * nv + 1 + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ws->stream,
-                       ws->partials, g, 2 * nv + 1, 2 * nv + 1, ws->host_results_dev);
+#define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
+  hipLaunchKernelGGL((k_scale_dot_pair_many<NV, VEC, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
+                     ws->partials)
+#define L2SP(NV) NKA_SDPM(NV, 2, true, true)
+#define L2SN(NV) NKA_SDPM(NV, 2, true, false)
+#define L2NP(NV) NKA_SDPM(NV, 2, false, true)
+#define L2NN(NV) NKA_SDPM(NV, 2, false, false)
+#define L1SP(NV) NKA_SDPM(NV, 1, true, true)
+#define L1SN(NV) NKA_SDPM(NV, 1, true, false)
+#define L1NP(NV) NKA_SDPM(NV, 1, false, true)
+#define L1NN(NV) NKA_SDPM(NV, 1, false, false)
+    if (v2) {
+      if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L2SP) } else { NKA_DISPATCH_NV(nv, L2SN) } }
+      else          { if (pre) { NKA_DISPATCH_NV(nv, L2NP) } else { NKA_DISPATCH_NV(nv, L2NN) } }
+    } else {
+      if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L1SP) } else { NKA_DISPATCH_NV(nv, L1SN) } }
+      else          { if (pre) { NKA_DISPATCH_NV(nv, L1NP) } else { NKA_DISPATCH_NV(nv, L1NN) } }
+    }
+#undef L2SP
+#undef L2SN
+#undef L2NP
+#undef L2NN
+#undef L1SP
+#undef L1SN
+#undef L1NP
+#undef L1NN
+#undef NKA_SDPM
+    hipLaunchKernelGGL(k_finalize, dim3(2 * nv + 1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1,
+                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
     HIP_TRYV(hipStreamSynchronize(ws->stream));
     for (int j = 0; j < m.count; j++) {

@@ -215,20 +215,21 @@ module nka_hip_c
       type(c_ptr), intent(in) :: xs(*)
       integer(c_int32_t), value :: count
     end function
-    integer(c_int) function nka_hip_vec_update_norm2(ws, n, z, a, x, res) bind(C)
-      import :: c_int, c_int64_t, c_ptr, c_double
+    integer(c_int) function nka_hip_vec_update_norm2(ws, n, z, a, x, store, res) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, z, x
       integer(c_int64_t), value :: n
       real(c_double), value :: a
+      integer(c_int32_t), value :: store
       real(c_double), intent(out) :: res
     end function
-    integer(c_int) function nka_hip_vec_scale_dot_pair_many(ws, n, w, v, a, subtract, f, ys, count, vals_w, vals_f, &
-                                                            cross) bind(C)
+    integer(c_int) function nka_hip_vec_scale_dot_pair_many(ws, n, w, v, a, subtract, pre, pre_a, f, ys, count, &
+                                                            vals_w, vals_f, cross) bind(C)
       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, w, v, f
       integer(c_int64_t), value :: n
-      real(c_double), value :: a
-      integer(c_int32_t), value :: subtract, count
+      real(c_double), value :: a, pre_a
+      integer(c_int32_t), value :: subtract, pre, count
       type(c_ptr), intent(in) :: ys(*)
       real(c_double), intent(out) :: vals_w(*), vals_f(*), cross
     end function

@@ -319,24 +319,28 @@ contains
                        'vec_axpy_many')
   end subroutine
 
-  !! this <- a*x + this and ||this|| in one pass (R 2n, W n).
-  function update_norm2_fused(this, a, x) result(s)
+  !! || a*x + this || in one pure-read pass (R 2n); the update itself is left to the
+  !! next stage (stored = .false.), which reads `this` and x = f anyway.
+  function update_norm2_fused(this, a, x, stored) result(s)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a
     class(vector), intent(in) :: x
+    logical, intent(out) :: stored
     real(r8) :: s
     s = 0.0_r8
+    stored = .false.
     select type (x)
     class is (hip_block_vector)
-      call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%ntot, this%base, a, x%base, s), 'vec_update_norm2')
+      call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%ntot, this%base, a, x%base, 0_c_int32_t, s), &
+                         'vec_update_norm2')
     class default
       error stop 'incompatible arguments to VECTOR%UPDATE_NORM2'
     end select
   end function
 
-  !! scale both members of the new pair and take both inner-product rows while the
-  !! stored vectors stream past once (R (3+L)n, W 2n).
-  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross)
+  !! [apply the deferred update,] scale both members of the new pair and take both
+  !! inner-product rows while the stored vectors stream past once (R (3+L)n, W 2n).
+  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a)
     class(hip_block_vector), intent(inout) :: this
     class(vector), intent(inout) :: v
     real(r8), intent(in) :: a
@@ -345,8 +349,17 @@ contains
     class(vector), intent(in) :: ys(:)
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
+    real(r8), intent(in), optional :: pre_a
     type(c_ptr) :: ptrs(max(size(idx),1))
     integer :: j
+    integer(c_int32_t) :: pre
+    real(r8) :: pa
+    pre = 0
+    pa = 0.0_r8
+    if (present(pre_a)) then
+      pre = 1
+      pa = pre_a
+    end if
     select type (v)
     class is (hip_block_vector)
       select type (f)
@@ -357,8 +370,8 @@ contains
             ptrs(j) = ys(idx(j))%base
           end do
           call nka_hip_check(nka_hip_vec_scale_dot_pair_many(this%ws, this%ntot, this%base, v%base, a, &
-                             merge(1_c_int32_t, 0_c_int32_t, subtract), f%base, ptrs, size(idx, kind=c_int32_t), &
-                             vals_this, vals_f, cross), 'vec_scale_dot_pair_many')
+                             merge(1_c_int32_t, 0_c_int32_t, subtract), pre, pa, f%base, ptrs, &
+                             size(idx, kind=c_int32_t), vals_this, vals_f, cross), 'vec_scale_dot_pair_many')
           return
         end select
       end select

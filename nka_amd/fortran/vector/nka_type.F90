@@ -230,11 +230,12 @@ contains
     class(vector), intent(inout) :: f
     real(r8) :: s, c(this%mvec+1), vals(this%mvec+1), bvals(this%mvec+1), cross
     integer :: k, slot, idx(this%mvec+1), nidx, j
-    logical :: have_rows
+    logical :: have_rows, stored
 
     have_rows = .false.
+    stored = .true.
     if (this%pending) then
-      s = this%w(this%first)%update_norm2(-1.0_r8, f)        ! w1 <- w1 - f ; s = ||w1||       F08V:237-238
+      s = this%w(this%first)%update_norm2(-1.0_r8, f, stored)   ! s = ||w1 - f|| ; w1 <- w1 - f now or in the next stage   F08V:237-238
       if (s == 0.0_r8) call this%relax                       ! nothing to learn from a zero difference
     end if
 
@@ -251,8 +252,13 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
-      call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
-                                                  idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
+      if (stored) then
+        call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
+                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
+      else                                                   ! the norm stage left w1 <- w1 - f to this one
+        call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
+                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, pre_a=-1.0_r8)
+      end if
       c(this%first) = cross
       do j = 1, nidx
         this%h(this%first,idx(j)) = vals(j)

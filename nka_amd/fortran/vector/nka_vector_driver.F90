@@ -213,11 +213,15 @@ contains
     write(*,'(a,i0,a,i0,a,i0,a,l1)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec, &
                                      ' compact=', compact
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
-    !! bytes the hooks move per update: hook by hook 8n(12+8m); with the batched
-    !! hooks of hip_block_vector 8n(16+3m); contract figure 8n(11+3m)
-    write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, batched hooks (8n(16+3m)) ', 8.0_r8*n*(16+3*mvec)/per/1e9_r8, &
-                                 '   algorithmic GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
-    write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by algorithmic bytes ', &
+    !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector
+    !! 8n(11+3m) = the contract figure (compact option: 8n(11+2m))
+    if (compact) then
+      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks compact (8n(11+2m)) ', 8.0_r8*n*(11+2*mvec)/per/1e9_r8, &
+                                   '   contract GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
+    else
+      write(*,'(a,f10.1)') 'moved GB/s, stage hooks = contract bytes (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
+    end if
+    write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by contract bytes 8n(11+3m) ', &
                         8.0_r8*n*(11+3*mvec)/per/8.0e12_r8
   end subroutine
 

@@ -254,20 +254,27 @@ contains
     end do
   end subroutine
 
-  !! this <- a*x + this, and the 2-norm of the result (F08V:237-238).
-  function update_norm2(this, a, x) result(s)
+  !! s = || a*x + this ||_2 (F08V:237-238).  `stored` tells the caller whether `this`
+  !! now HOLDS a*x + this (.true.: this default, the reference's update + norm2) or was
+  !! left untouched (.false.: an override may leave the update to the next stage,
+  !! scale_dot_pair_many, which is then called with pre_a = a and applies it there --
+  !! one pass over `this` instead of two).
+  function update_norm2(this, a, x, stored) result(s)
     class(vector), intent(inout) :: this
     real(r8), intent(in) :: a
     class(vector), intent(in) :: x
+    logical, intent(out) :: stored
     real(r8) :: s
     call this%update(a, x)
     s = this%norm2()
+    stored = .true.
   end function
 
   !! Normalise the new pair and take both inner-product rows (F08V:255-264, 347):
+  !!   [pre_a present: this <- pre_a*f + this, the update update_norm2 did not store ;]
   !!   v <- a*v ; this <- a*this ; [subtract: v <- v - this] ;
   !!   vals_this(j) = <this, ys(idx(j))>, vals_f(j) = <f, ys(idx(j))>, cross = <f, this>.
-  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross)
+  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a)
     class(vector), intent(inout) :: this, v
     real(r8), intent(in) :: a
     logical, intent(in) :: subtract
@@ -275,6 +282,8 @@ contains
     class(vector), intent(in) :: ys(:)
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
+    real(r8), intent(in), optional :: pre_a
+    if (present(pre_a)) call this%update(pre_a, f)
     call v%scale(a)
     call this%scale(a)
     if (subtract) call v%update(-1.0_r8, this)

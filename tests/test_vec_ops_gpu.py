@@ -141,31 +141,38 @@ def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, s
     Yd = [_dev(torch, Y[j]) for j in range(count)]
     ys = (C.c_void_p * max(count, 1))(*[t.data_ptr() for t in Yd])
 
-    # stage 1: w <- (-1)*f + w ; s = ||w||
+    # stage 1, storing form: w <- (-1)*f + w ; s = ||w||
     wd, fd, vd = _dev(torch, w0), _dev(torch, f), _dev(torch, v0)
     s = C.c_double()
-    assert L.nka_hip_vec_update_norm2(h, n, P(wd), -1.0, P(fd), C.byref(s)) == 0
+    assert L.nka_hip_vec_update_norm2(h, n, P(wd), -1.0, P(fd), 1, C.byref(s)) == 0
     d = -1.0 * f + w0
     assert np.array_equal(wd.cpu().numpy(), d)
     assert s.value == pytest.approx(float(np.linalg.norm(d)), rel=1e-14)
+    # stage 1, deferring form: same norm (same bits), w untouched
+    wd2, s2 = _dev(torch, w0), C.c_double()
+    assert L.nka_hip_vec_update_norm2(h, n, P(wd2), -1.0, P(fd), 0, C.byref(s2)) == 0
+    assert np.array_equal(wd2.cpu().numpy(), w0) and s2.value == s.value
 
-    # stage 2: scale both, optional subtract, both rows + cross with the NEW w
+    # stage 2: scale both, optional subtract, both rows + cross with the NEW w --
+    # once on the stored difference, once applying the deferred update itself
     a = 1.0 / s.value
-    vw, vf, cross = np.zeros(max(count, 1)), np.zeros(max(count, 1)), C.c_double()
-    assert L.nka_hip_vec_scale_dot_pair_many(h, n, P(wd), P(vd), a, subtract, P(fd), ys, count,
-                                             vw.ctypes.data_as(dp), vf.ctypes.data_as(dp), C.byref(cross)) == 0
     wn = a * d
     vn = a * v0
     if subtract:
         vn = -1.0 * wn + vn
-    assert np.array_equal(wd.cpu().numpy(), wn)
-    assert np.array_equal(vd.cpu().numpy(), vn)
     nf, nw = np.linalg.norm(f), np.linalg.norm(wn)
-    assert cross.value == pytest.approx(float(f @ wn), abs=1e-13 * nf * nw)
-    for j in range(count):
-        ny = np.linalg.norm(Y[j])
-        assert vw[j] == pytest.approx(float(wn @ Y[j]), abs=1e-13 * nw * ny)
-        assert vf[j] == pytest.approx(float(f @ Y[j]), abs=1e-13 * nf * ny)
+    for pre, wdev in ((0, wd), (1, wd2)):
+        vdev = _dev(torch, v0)
+        vw, vf, cross = np.zeros(max(count, 1)), np.zeros(max(count, 1)), C.c_double()
+        assert L.nka_hip_vec_scale_dot_pair_many(h, n, P(wdev), P(vdev), a, subtract, pre, -1.0, P(fd), ys, count,
+                                                 vw.ctypes.data_as(dp), vf.ctypes.data_as(dp), C.byref(cross)) == 0
+        assert np.array_equal(wdev.cpu().numpy(), wn), pre
+        assert np.array_equal(vdev.cpu().numpy(), vn), pre
+        assert cross.value == pytest.approx(float(f @ wn), abs=1e-13 * nf * nw)
+        for j in range(count):
+            ny = np.linalg.norm(Y[j])
+            assert vw[j] == pytest.approx(float(wn @ Y[j]), abs=1e-13 * nw * ny)
+            assert vf[j] == pytest.approx(float(f @ Y[j]), abs=1e-13 * nf * ny)
 
     # stage 3: keep_in <- z ; z <- combine ; keep_out <- z
     X = rng.standard_normal((max(count, 1), n))

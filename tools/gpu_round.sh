@@ -1,3 +1,6 @@
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2; grep -E "^FAILED|^ERROR|^E  " gpurun_out/pytest_gpu.log | head -20
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_vec_ops_gpu.py tests/test_hip_parity.py tests/test_example_dev_gpu.py -m gpu -q --tb=short 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -4
+for r in 1 2 3; do
+  echo "checks on (cached): $(nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)"
+  echo "checks off        : $(NKA_HIP_CHECK_POINTERS=0 nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)"
+done

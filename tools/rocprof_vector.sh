@@ -11,22 +11,25 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "$ROOT/nka_amd/fortran/build/nka_vector_driver" bench 4 10000000 20 20 $CP > "$OUT/bench.log" 2>&1
 echo "trace rc=$?"; cat "$OUT/bench.log"
 S=$(ls "$OUT"/trace/*/*_kernel_stats.csv | head -1)
-{ head -1 "$S"; grep -E "nka::" "$S"; } > "$ROOT/gpurun_out/profiles_$TAG/kernel_stats_vector_compact$CP.csv"
+{ head -1 "$S"; grep -E "k_[a-z_0-9]+<|nka::" "$S"; } > "$ROOT/gpurun_out/profiles_$TAG/kernel_stats_vector_compact$CP.csv"
 cp "$OUT/bench.log" "$ROOT/gpurun_out/profiles_$TAG/vector_bench_under_trace_compact$CP.log"
 cat "$ROOT/gpurun_out/profiles_$TAG/kernel_stats_vector_compact$CP.csv"
 # timeline of two steady-state updates: kernel starts/ends relative to the first
 python3 - "$OUT" <<'PY'
-import csv, glob, sys
+import csv, glob, re, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/trace/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")))
+        m = re.search(r"(k_\w+(<[^>]*>)?|__amd\w+)", r["Kernel_Name"])
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:60]))
 rows.sort()
 # last 2 updates = last 2 occurrences of k_update_norm2
 idx = [i for i, r in enumerate(rows) if "k_update_norm2" in r[2]]
 if len(idx) >= 3:
     a = idx[-3]
     t0 = rows[a][0]
+    prev = None
     for s, e, k in rows[a:idx[-1]]:
-        print(f"{(s - t0) / 1e3:10.1f} us  +{(e - s) / 1e3:9.1f} us  {k[:70]}")
+        print(f"{(s - t0) / 1e3:10.1f} us  gap {((s - prev) / 1e3 if prev else 0):6.1f}  +{(e - s) / 1e3:9.1f} us  {k[:70]}")
+        prev = e
 PY
