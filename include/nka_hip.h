@@ -205,7 +205,8 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
 /* Kernel-variant switches for A/B measurements inside one process (same
- * allocations, same thermal state): "pb_pipe" = 0 (k_combine), 2 or 4
+ * allocations, same thermal state): "pa_pipe" = 0 (k_dots), 2 or 4 (k_dots_pipe), -1
+ * automatic (env NKA_HIP_PA_PIPE); "pb_pipe" = 0 (k_combine), 2 or 4
  * (k_combine_pipe with that many load groups), -1 automatic (the default; env
  * NKA_HIP_PB_PIPE); "serial_solve" = 0/1.  Results are
  * bit-identical across variants. */

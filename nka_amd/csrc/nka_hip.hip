@@ -172,6 +172,7 @@ struct nka_hip_state {
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
+  int pa_pipe = -1;           // groups of the software-pipelined PA: 0 = k_dots, 2 or 4 = k_dots_pipe, -1 = automatic
   int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
                               // -1 = automatic (see enqueue_pb)
   int solve_variant = 0;      // 0 = k_solve_wave2 (registers + masks), 1 = k_solve_wave (first version, LDS walks)
@@ -233,6 +234,27 @@ int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) 
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
                      a->partials, g, pass, npass * MAXL);
   return g;
+}
+
+template <int MAXL, int NG>
+int launch_dots_pipe_1(const nka_hip_state *a, const double *f) {
+  static const int occ = occupancy_of(k_dots_pipe<MAXL, NG>);
+  const int g = grid_for(a, 0, 2, occ, MAXL + 2);
+  hipLaunchKernelGGL((k_dots_pipe<MAXL, NG>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
+                     a->partials, g, 0, MAXL);
+  return g;
+}
+
+template <int NG>
+int launch_dots_pipe(int maxl, const nka_hip_state *a, const double *f) {
+#define CASE(L) \
+  case L: return launch_dots_pipe_1<L, NG>(a, f);
+  switch (maxl) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
 }
 
 int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass, int npass) {
@@ -375,6 +397,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
+  a->pa_pipe = env_int("NKA_HIP_PA_PIPE", a->pa_pipe);
   a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
   a->solve_variant = env_int("NKA_HIP_SOLVE_VARIANT", a->solve_variant);
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
@@ -668,9 +691,18 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
     RoctxRange range("nka:PA dots + all-reduce");
     const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
     const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
-    for (int p = 0; p < npass; p++) {
-      if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
-      else launch_dots_1<4, 1>(a, f, p, npass);
+    // in-process A/B (tools/ab_inproc.py, m = 20): k_dots_pipe 2.734 vs k_dots 2.786 ms at n = 1e8
+    // (-1.9 %), equal at 1.25e7: automatic = large vectors only
+    int pa_pipe = a->pa_pipe;
+    if (pa_pipe < 0) pa_pipe = (a->n >= 30000000) ? 4 : 0;
+    if (vec == 2 && npass == 1 && pa_pipe > 0) {         // software-pipelined single pass (k_dots_pipe)
+      if (pa_pipe >= 4) launch_dots_pipe<4>(maxl, a, f);
+      else launch_dots_pipe<2>(maxl, a, f);
+    } else {
+      for (int p = 0; p < npass; p++) {
+        if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
+        else launch_dots_1<4, 1>(a, f, p, npass);
+      }
     }
     HIP_TRY(hipGetLastError());
     // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
@@ -979,6 +1011,9 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (k == "pb_pipe") {
     if (value != -1 && value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2 or 4");
     a->pb_pipe = value;
+  } else if (k == "pa_pipe") {
+    if (value != -1 && value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2 or 4");
+    a->pa_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
   } else if (k == "solve_variant") {

@@ -278,6 +278,93 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
   block_reduce_store<NACC>(acc, partials, G);
 }
 
+// PA, software-pipelined over NG groups of stored vectors (single pass, VEC = 2):
+// as soon as group g of a tile has been accumulated, group g of the block's next
+// tile is requested into the same registers (cf. k_combine_pipe).  Same products,
+// same per-thread accumulation order => same bits as k_dots.
+template <int MAXL, int NG>
+__global__ __launch_bounds__(kBlock) void k_dots_pipe(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                      double *__restrict__ partials) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  constexpr int NACC = 2 * MAXL + 2;
+  constexpr int GP = MAXL / NG;
+  static_assert(MAXL % NG == 0, "groups must divide the unroll width");
+  const int G = gridDim.x;
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const int32_t *slots = ctl.plan_slots();
+  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
+  const double *wk[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? vs.w + (size_t)(slots[j] - 1) * vs.stride : f;
+  double acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  V fv, w1v, wkv[MAXL];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    fv = ld<VEC>(f + e);
+    w1v = ld<VEC>(w1 + e);
+#pragma unroll
+    for (int j = 0; j < MAXL; j++) wkv[j] = ld<VEC>(wk[j] + e);
+  }
+  for (; t < ntile; t += G) {
+    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    double dq[VEC], fq[VEC];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          fq[q] = ex(fv, q);
+          dq[q] = ex(w1v, q) - fq[q];                  // F08:266
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        if (g == 0) {
+          acc[0] = fma(dq[q], dq[q], acc[0]);
+          acc[1] = fma(fq[q], dq[q], acc[1]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < GP; jj++) {
+          const int j = g * GP + jj;
+          acc[2 + j] = fma(dq[q], ex(wkv[j], q), acc[2 + j]);
+          acc[2 + MAXL + j] = fma(fq[q], ex(wkv[j], q), acc[2 + MAXL + j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 0) {
+        fv = ld<VEC>(f + en);
+        w1v = ld<VEC>(w1 + en);
+      }
+#pragma unroll
+      for (int jj = 0; jj < GP; jj++) wkv[g * GP + jj] = ld<VEC>(wk[g * GP + jj] + en);
+    }
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+      const double fq = f[i];
+      const double d = w1[i] - fq;
+      acc[0] = fma(d, d, acc[0]);
+      acc[1] = fma(fq, d, acc[1]);
+#pragma unroll
+      for (int j = 0; j < MAXL; j++) {
+        const double x = wk[j][i];
+        acc[2 + j] = fma(d, x, acc[2 + j]);
+        acc[2 + MAXL + j] = fma(fq, x, acc[2 + MAXL + j]);
+      }
+    }
+  }
+  block_reduce_store<NACC>(acc, partials, G);
+}
+
 // Final sums of one PA pass scattered into red[] (layout above).  One wavefront
 // per column (grid = 2*MAXL+2 blocks of 64): each lane sums its strided share in
 // order, then a butterfly -- the same bits on every run.

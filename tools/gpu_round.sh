@@ -1,6 +1,4 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_vec_ops_gpu.py tests/test_hip_parity.py tests/test_example_dev_gpu.py -m gpu -q --tb=short 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -4
-for r in 1 2 3; do
-  echo "checks on (cached): $(nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)"
-  echo "checks off        : $(NKA_HIP_CHECK_POINTERS=0 nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)"
-done
+for p in 2 4; do NKA_HIP_PA_PIPE=$p timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x --tb=short 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -3; done
+python tools/ab_inproc.py --flavor c --key pa_pipe --values 0 2 4 --rounds 8 --steps 10
+python tools/ab_inproc.py --flavor c --vlen 1.25e7 --key pa_pipe --values 0 2 4 --rounds 8 --steps 20
