@@ -236,20 +236,31 @@ int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) 
   return g;
 }
 
-template <int MAXL, int NG>
+template <int MAXL, int GP>
 int launch_dots_pipe_1(const nka_hip_state *a, const double *f) {
-  static const int occ = occupancy_of(k_dots_pipe<MAXL, NG>);
+  static const int occ = occupancy_of(k_dots_pipe<MAXL, GP>);
   const int g = grid_for(a, 0, 2, occ, MAXL + 2);
-  hipLaunchKernelGGL((k_dots_pipe<MAXL, NG>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  hipLaunchKernelGGL((k_dots_pipe<MAXL, GP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
                      a->partials, g, 0, MAXL);
   return g;
 }
 
-template <int NG>
-int launch_dots_pipe(int maxl, const nka_hip_state *a, const double *f) {
+// `pipe` = 2 or 4 groups per tile, or the group size itself: 101 = one vector per group
+// (a rolling window: every consumed load is re-issued at once), 102 = two per group
+template <int MAXL>
+int launch_dots_pipe_g(int pipe, const nka_hip_state *a, const double *f) {
+  switch (pipe) {
+    case 101: return launch_dots_pipe_1<MAXL, 1>(a, f);
+    case 102: return launch_dots_pipe_1<MAXL, 2>(a, f);
+    case 4: return launch_dots_pipe_1<MAXL, MAXL / 4>(a, f);
+    default: return launch_dots_pipe_1<MAXL, MAXL / 2>(a, f);
+  }
+}
+
+int launch_dots_pipe(int pipe, int maxl, const nka_hip_state *a, const double *f) {
 #define CASE(L) \
-  case L: return launch_dots_pipe_1<L, NG>(a, f);
+  case L: return launch_dots_pipe_g<L>(pipe, a, f);
   switch (maxl) {
     CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
   }
@@ -286,18 +297,28 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
   return 0;
 }
 
-template <int MAXK, int COMB, int NG>
+template <int MAXK, int COMB, int GP>
 int launch_combine_pipe_1(const nka_hip_state *a, double *f) {
-  static const int occ = occupancy_of(k_combine_pipe<MAXK, COMB, NG>);
+  static const int occ = occupancy_of(k_combine_pipe<MAXK, COMB, GP>);
   const int g = grid_for(a, 1, 2, occ, (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1));
-  hipLaunchKernelGGL((k_combine_pipe<MAXK, COMB, NG>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
+  hipLaunchKernelGGL((k_combine_pipe<MAXK, COMB, GP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
   return g;
 }
 
-template <int COMB, int NG>
-int launch_combine_pipe_w(int maxk, const nka_hip_state *a, double *f) {
+template <int MAXK, int COMB>
+int launch_combine_pipe_g(int pipe, const nka_hip_state *a, double *f) {
+  switch (pipe) {
+    case 101: return launch_combine_pipe_1<MAXK, COMB, 1>(a, f);
+    case 102: return launch_combine_pipe_1<MAXK, COMB, 2>(a, f);
+    case 4: return launch_combine_pipe_1<MAXK, COMB, MAXK / 4>(a, f);
+    default: return launch_combine_pipe_1<MAXK, COMB, MAXK / 2>(a, f);
+  }
+}
+
+template <int COMB>
+int launch_combine_pipe_w(int pipe, int maxk, const nka_hip_state *a, double *f) {
 #define CASE(K) \
-  case K: return launch_combine_pipe_1<K, COMB, NG>(a, f);
+  case K: return launch_combine_pipe_g<K, COMB>(pipe, a, f);
   switch (maxk) {
     CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
   }
@@ -305,12 +326,11 @@ int launch_combine_pipe_w(int maxk, const nka_hip_state *a, double *f) {
   return 0;
 }
 
-template <int NG>
-int launch_combine_pipe(int flavor, int maxk, const nka_hip_state *a, double *f) {
+int launch_combine_pipe(int pipe, int flavor, int maxk, const nka_hip_state *a, double *f) {
   switch (flavor) {
-    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_pipe_w<1, NG>(maxk, a, f);
-    case NKA_HIP_FLAVOR_C: return launch_combine_pipe_w<2, NG>(maxk, a, f);
-    default: return launch_combine_pipe_w<0, NG>(maxk, a, f);
+    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_pipe_w<1>(pipe, maxk, a, f);
+    case NKA_HIP_FLAVOR_C: return launch_combine_pipe_w<2>(pipe, maxk, a, f);
+    default: return launch_combine_pipe_w<0>(pipe, maxk, a, f);
   }
 }
 
@@ -572,8 +592,7 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   int pipe = a->pb_pipe;
   if (pipe < 0) pipe = (a->flavor != NKA_HIP_FLAVOR_C && a->n >= 30000000) ? 4 : 0;
   if (vec == 2 && npass == 1 && pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
-    if (pipe >= 4) launch_combine_pipe<4>(a->flavor, maxk, a, f);
-    else launch_combine_pipe<2>(a->flavor, maxk, a, f);
+    launch_combine_pipe(pipe, a->flavor, maxk, a, f);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -696,8 +715,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
     int pa_pipe = a->pa_pipe;
     if (pa_pipe < 0) pa_pipe = (a->n >= 30000000) ? 4 : 0;
     if (vec == 2 && npass == 1 && pa_pipe > 0) {         // software-pipelined single pass (k_dots_pipe)
-      if (pa_pipe >= 4) launch_dots_pipe<4>(maxl, a, f);
-      else launch_dots_pipe<2>(maxl, a, f);
+      launch_dots_pipe(pa_pipe, maxl, a, f);
     } else {
       for (int p = 0; p < npass; p++) {
         if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
@@ -1009,10 +1027,12 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2 or 4");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102)
+      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (pairs per group)");
     a->pb_pipe = value;
   } else if (k == "pa_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4) return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2 or 4");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102)
+      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (vectors per group)");
     a->pa_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;

@@ -282,14 +282,14 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 // as soon as group g of a tile has been accumulated, group g of the block's next
 // tile is requested into the same registers (cf. k_combine_pipe).  Same products,
 // same per-thread accumulation order => same bits as k_dots.
-template <int MAXL, int NG>
+template <int MAXL, int GP>
 __global__ __launch_bounds__(kBlock) void k_dots_pipe(Ctl ctl, Vecs vs, const double *__restrict__ f,
                                                       double *__restrict__ partials) {
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr int NACC = 2 * MAXL + 2;
-  constexpr int GP = MAXL / NG;
-  static_assert(MAXL % NG == 0, "groups must divide the unroll width");
+  constexpr int NG = MAXL / GP;          // GP stored vectors per group
+  static_assert(MAXL % GP == 0, "groups must divide the unroll width");
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
@@ -540,15 +540,15 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
 // Single pass only (MAXK covers the list: mvec <= 32), VEC = 2.  The block's last
 // iteration prefetches its own tile again (cache hits) so that the loop body has
 // no load under a branch: the compiler's s_waitcnt vmcnt(N) counts stay exact.
-template <int MAXK, int COMB, int NG>
+template <int MAXK, int COMB, int GP>
 __global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, double *f) {
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr bool RCP = (COMB == 1);
   constexpr bool COMPACT = (COMB == 2);
   constexpr int NW = COMPACT ? 1 : MAXK;
-  constexpr int GP = MAXK / NG;
-  static_assert(MAXK % NG == 0, "groups must divide the unroll width");
+  constexpr int NG = MAXK / GP;          // GP pairs per group
+  static_assert(MAXK % GP == 0, "groups must divide the unroll width");
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
   const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;

@@ -188,6 +188,18 @@ void run(const char *name, const double *base, double *wbase, size_t stride, siz
   fflush(stdout);
 }
 
+// fill with pseudo-random doubles in (-1,1): all-zero buffers flatter a bandwidth probe
+// (no data toggling on the HBM interface)
+__global__ void k_fill_random(double *p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    p[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? (size_t)atof(argv[1]) : 100000000;
   const size_t stride = ((n + 31) / 32) * 32 + (argc > 2 ? atoi(argv[2]) / 8 : 0);
@@ -198,10 +210,16 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&out, 64));
   CK(hipMemset(rd, 0, stride * 8 * NS));
   CK(hipMemset(wr, 0, stride * 8 * NW));
+  const bool random_data = argc > 3 && (argv[3][0] == 'r' || (argv[3][0] && argv[3][1] == 'r'));   // "r" or "wr"
+  if (random_data) {
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, rd, stride * NS);
+    CK(hipDeviceSynchronize());
+  }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int cu = prop.multiProcessorCount;
-  printf("device %s, %d CUs, n=%zu, slot stride %zu B\n", prop.gcnArchName, cu, n, stride * 8);
+  printf("device %s, %d CUs, n=%zu, slot stride %zu B, read data %s\n", prop.gcnArchName, cu, n, stride * 8,
+         random_data ? "random" : "zeros");
 #define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
 #define RB(S, W, B, NTS, G) runb<S, W, B, NTS>("burst S=" #S " W=" #W " B=" #B " st=" #NTS, rd, wr, stride, n, out, G)
 #define RP(S, W, NTS, G) runp<S, W, NTS>("pipelined S=" #S " W=" #W " st=" #NTS, rd, wr, stride, n, out, G)
