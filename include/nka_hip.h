@@ -212,6 +212,10 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * bit-identical across variants. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
+/* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,
+ * launched `reps` times back to back (it only writes scratch: state unchanged). */
+int nka_hip_debug_time_pa(nka_hip_t a, const double *f_dev, int32_t reps, float *ms_mean);
+
 const char *nka_hip_last_error(void);
 /* "gfx950"-style name of the device the handle runs on, CU count. */
 int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);

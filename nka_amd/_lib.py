@@ -46,6 +46,7 @@ SIGNATURES = {
     "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "nka_hip_debug_time_pa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_last_error": (C.c_char_p, []),
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),

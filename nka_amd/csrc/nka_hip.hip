@@ -258,6 +258,41 @@ int launch_dots_pipe_g(int pipe, const nka_hip_state *a, const double *f) {
   }
 }
 
+// rolling-window PA: ring of W registers (W = 4 divides every unroll width; 2, MAXL/4 and
+// MAXL/2 also offered), `bpc` blocks per CU
+template <int MAXL, int W>
+int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
+  static const int occ = occupancy_of(k_dots_win<MAXL, W>);
+  const int64_t ntile = a->n / (kBlock * 2);
+  int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
+  g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
+  hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
+                     a->partials, (int)g, 0, MAXL);
+  return (int)g;
+}
+
+// wsel: 0 -> W = 4, 1 -> W = 2, 2 -> W = MAXL/4, 3 -> W = MAXL/2
+template <int MAXL>
+int launch_dots_win_g(int wsel, const nka_hip_state *a, const double *f, int bpc) {
+  switch (wsel) {
+    case 1: return launch_dots_win_1<MAXL, 2>(a, f, bpc);
+    case 2: return launch_dots_win_1<MAXL, (MAXL / 4 > 0 ? MAXL / 4 : 1)>(a, f, bpc);
+    case 3: return launch_dots_win_1<MAXL, MAXL / 2>(a, f, bpc);
+    default: return launch_dots_win_1<MAXL, 4>(a, f, bpc);
+  }
+}
+
+int launch_dots_win(int maxl, int wsel, const nka_hip_state *a, const double *f, int bpc) {
+#define CASE(L) \
+  case L: return launch_dots_win_g<L>(wsel, a, f, bpc);
+  switch (maxl) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
+}
+
 int launch_dots_pipe(int pipe, int maxl, const nka_hip_state *a, const double *f) {
 #define CASE(L) \
   case L: return launch_dots_pipe_g<L>(pipe, a, f);
@@ -331,6 +366,46 @@ int launch_combine_pipe(int pipe, int flavor, int maxk, const nka_hip_state *a, 
     case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_pipe_w<1>(pipe, maxk, a, f);
     case NKA_HIP_FLAVOR_C: return launch_combine_pipe_w<2>(pipe, maxk, a, f);
     default: return launch_combine_pipe_w<0>(pipe, maxk, a, f);
+  }
+}
+
+// rolling-window PB: ring of W pairs (wsel 0 -> 4, 1 -> 2, 2 -> MAXK/4, 3 -> MAXK/2), `bpc` blocks per CU
+template <int MAXK, int COMB, int W>
+int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
+  static const int occ = occupancy_of(k_combine_win<MAXK, COMB, W>);
+  const int64_t ntile = a->n / (kBlock * 2);
+  int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
+  g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
+  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
+  return (int)g;
+}
+
+template <int MAXK, int COMB>
+int launch_combine_win_g(int wsel, const nka_hip_state *a, double *f, int bpc) {
+  switch (wsel) {
+    case 1: return launch_combine_win_1<MAXK, COMB, 2>(a, f, bpc);
+    case 2: return launch_combine_win_1<MAXK, COMB, (MAXK / 4 > 0 ? MAXK / 4 : 1)>(a, f, bpc);
+    case 3: return launch_combine_win_1<MAXK, COMB, MAXK / 2>(a, f, bpc);
+    default: return launch_combine_win_1<MAXK, COMB, 4>(a, f, bpc);
+  }
+}
+
+template <int COMB>
+int launch_combine_win_w(int maxk, int wsel, const nka_hip_state *a, double *f, int bpc) {
+#define CASE(K) \
+  case K: return launch_combine_win_g<K, COMB>(wsel, a, f, bpc);
+  switch (maxk) {
+    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  }
+#undef CASE
+  return 0;
+}
+
+int launch_combine_win(int flavor, int maxk, int wsel, const nka_hip_state *a, double *f, int bpc) {
+  switch (flavor) {
+    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_win_w<1>(maxk, wsel, a, f, bpc);
+    case NKA_HIP_FLAVOR_C: return launch_combine_win_w<2>(maxk, wsel, a, f, bpc);
+    default: return launch_combine_win_w<0>(maxk, wsel, a, f, bpc);
   }
 }
 
@@ -581,16 +656,46 @@ static int enqueue_solve(nka_hip_t a, int mode) {
   return 0;
 }
 
+// PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371).
+// Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
+static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
+  const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
+  const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
+  // Automatic choice, from in-process A/B runs (tools/ab_inproc.py, profiles/r02/ab_inproc_*.txt):
+  // the rolling-window kernel (ring of 4, one block per CU) wins by 5-8 % whenever the unroll width
+  // carries no padding (m = 20: 2.58 vs 2.75 ms at n = 1e8, 0.374 vs 0.394 at 1.25e7, 44 vs 48 us
+  // at 1e6) -- padded entries are cache hits that occupy ring slots and starve the window (m = 5 at
+  // n = 1e8: +20 %); otherwise the 4-group pipeline for large vectors (-1.9 %), else k_dots.
+  int pa_pipe = a->pa_pipe;
+  if (pa_pipe < 0) pa_pipe = (older_ub == maxl) ? 201 : ((a->n >= 30000000) ? 4 : 0);
+  if (vec == 2 && npass == 1 && pa_pipe >= 200 && pa_pipe < 300) {    // rolling window: 2WB, W selector, B blocks per CU
+    launch_dots_win(maxl, (pa_pipe - 200) / 10, a, f, std::max(1, (pa_pipe - 200) % 10));
+  } else if (vec == 2 && npass == 1 && pa_pipe > 0) {  // software-pipelined single pass (k_dots_pipe)
+    launch_dots_pipe(pa_pipe, maxl, a, f);
+  } else {
+    for (int p = 0; p < npass; p++) {
+      if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
+      else launch_dots_1<4, 1>(a, f, p, npass);
+    }
+  }
+}
+
 // PB: normalise + combine + ring stores (F08:282-283, 361, 395-404).
 // After the subspace update the list holds at most min(list_ub, mvec) vectors.
 static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
   const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
-  // Measured in one process on MI355X (tools/ab_inproc.py, m = 20): the pipelined pass is 1.7 % faster
-  // than k_combine for the two-vectors-per-pair flavours at n = 1e8 (6.52 vs 6.63 ms), equal at
-  // 1.25e7, slower at 1e6, and 4 % slower for the compact flavour -- so: automatic = only there.
+  // Automatic choice (in-process A/B, profiles/r02/ab_inproc_window_matrix.txt): the rolling-window
+  // kernel (ring of 4 pairs, one block per CU) is as fast or faster than k_combine over n = 1e6..1e8,
+  // m = 5..20 (-2 % at n = 1e8 m = 20, -4 % at m = 5/10, -5 % at 1e7, -17 % at 1e6 m = 20; +2 % at
+  // 1e7 m = 20) and equals the 4-group pipeline for the two-vectors-per-pair flavours.
   int pipe = a->pb_pipe;
-  if (pipe < 0) pipe = (a->flavor != NKA_HIP_FLAVOR_C && a->n >= 30000000) ? 4 : 0;
+  if (pipe < 0) pipe = 201;
+  if (vec == 2 && npass == 1 && pipe >= 200 && pipe < 300) {   // rolling window: 2WB, W selector, B blocks per CU
+    launch_combine_win(a->flavor, maxk, (pipe - 200) / 10, a, f, std::max(1, (pipe - 200) % 10));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (vec == 2 && npass == 1 && pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
     launch_combine_pipe(pipe, a->flavor, maxk, a, f);
     HIP_TRY(hipGetLastError());
@@ -708,20 +813,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
     mode |= kSolvePrenorm;
   } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
-    const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
-    const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
-    // in-process A/B (tools/ab_inproc.py, m = 20): k_dots_pipe 2.734 vs k_dots 2.786 ms at n = 1e8
-    // (-1.9 %), equal at 1.25e7: automatic = large vectors only
-    int pa_pipe = a->pa_pipe;
-    if (pa_pipe < 0) pa_pipe = (a->n >= 30000000) ? 4 : 0;
-    if (vec == 2 && npass == 1 && pa_pipe > 0) {         // software-pipelined single pass (k_dots_pipe)
-      launch_dots_pipe(pa_pipe, maxl, a, f);
-    } else {
-      for (int p = 0; p < npass; p++) {
-        if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
-        else launch_dots_1<4, 1>(a, f, p, npass);
-      }
-    }
+    enqueue_pa(a, f, vec, older_ub);
     HIP_TRY(hipGetLastError());
     // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
     if (a->allreduce)
@@ -1023,16 +1115,45 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   return 0;
 }
 
+// Measurement aid: the PA launches of the NEXT update, `reps` times back to back on the
+// handle's stream, timed with HIP events (mean ms per repetition).  PA only writes
+// scratch (partials, red[]), so the state is unchanged.
+int nka_hip_debug_time_pa(nka_hip_t a, const double *f, int32_t reps, float *ms_mean) {
+  if (!a || !f || !ms_mean || reps < 1) return fail(NKA_HIP_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(a->device));
+  if (int rc = nka_detail::check_device_span(f, a->n, "debug_time_pa: f")) return rc;
+  const int vec = (reinterpret_cast<uintptr_t>(f) % 16) == 0 ? 2 : 1;
+  const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  enqueue_pa(a, f, vec, older_ub);   // warm
+  HIP_TRY(hipEventRecord(e0, a->stream));
+  for (int r = 0; r < reps; r++) enqueue_pa(a, f, vec, older_ub);
+  HIP_TRY(hipEventRecord(e1, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_mean = ms / reps;
+  return 0;
+}
+
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102)
-      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (pairs per group)");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102 &&
+        !(value >= 200 && value < 240))
+      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (pairs per group), "
+                                  "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXK/4, MAXK/2; B blocks per CU)");
     a->pb_pipe = value;
   } else if (k == "pa_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102)
-      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (vectors per group)");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102 &&
+        !(value >= 200 && value < 240))
+      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (vectors per group), "
+                                  "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXL/4, MAXL/2; B blocks per CU)");
     a->pa_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;

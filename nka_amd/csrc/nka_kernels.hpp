@@ -365,6 +365,91 @@ __global__ __launch_bounds__(kBlock) void k_dots_pipe(Ctl ctl, Vecs vs, const do
   block_reduce_store<NACC>(acc, partials, G);
 }
 
+// PA with a SMALL ROLLING WINDOW of loads.  tools/hbm_probe (mode f) showed that a
+// pure-read kernel with the arithmetic of this pass runs at 7.15 TB/s when each wave
+// keeps only ~6 loads in flight and re-issues one as soon as one has been consumed,
+// against 6.4-6.7 TB/s for k_dots with all 22 loads of a tile in flight: fewer streams
+// are open at any moment (DRAM page locality) and the fp64 FMAs interleave with the
+// load issue.  Here the MAXL stored vectors of a tile go through a ring of W registers
+// (slot j mod W holds vector j; when vector j has been accumulated its slot is re-loaded
+// with vector j+W of this tile or vector j+W-MAXL of the block's next tile), and f, w1
+// of the next tile are requested as soon as this tile's copies are in d / fq.  Same
+// products, same per-thread accumulation order => same bits as k_dots.  Single pass, VEC = 2.
+template <int MAXL, int W>
+__global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                     double *__restrict__ partials) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  constexpr int NACC = 2 * MAXL + 2;
+  static_assert(MAXL % W == 0, "the ring must divide the stored vectors of a tile");
+  const int G = gridDim.x;
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const int32_t *slots = ctl.plan_slots();
+  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
+  const double *wk[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? vs.w + (size_t)(slots[j] - 1) * vs.stride : f;
+  double acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  V fv, w1v, ring[W];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    fv = ld<VEC>(f + e);
+    w1v = ld<VEC>(w1 + e);
+#pragma unroll
+    for (int j = 0; j < W; j++) ring[j] = ld<VEC>(wk[j] + e);
+  }
+  for (; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    double dq[VEC], fq[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      fq[q] = ex(fv, q);
+      dq[q] = ex(w1v, q) - fq[q];                      // F08:266
+      acc[0] = fma(dq[q], dq[q], acc[0]);
+      acc[1] = fma(fq[q], dq[q], acc[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fv = ld<VEC>(f + en);
+    w1v = ld<VEC>(w1 + en);
+#pragma unroll
+    for (int j = 0; j < MAXL; j++) {
+      const V x = ring[j % W];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + W < MAXL) ring[j % W] = ld<VEC>(wk[j + W] + e);
+      else ring[j % W] = ld<VEC>(wk[j + W - MAXL] + en);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        acc[2 + j] = fma(dq[q], ex(x, q), acc[2 + j]);
+        acc[2 + MAXL + j] = fma(fq[q], ex(x, q), acc[2 + MAXL + j]);
+      }
+    }
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+      const double fq = f[i];
+      const double d = w1[i] - fq;
+      acc[0] = fma(d, d, acc[0]);
+      acc[1] = fma(fq, d, acc[1]);
+#pragma unroll
+      for (int j = 0; j < MAXL; j++) {
+        const double x = wk[j][i];
+        acc[2 + j] = fma(d, x, acc[2 + j]);
+        acc[2 + MAXL + j] = fma(fq, x, acc[2 + MAXL + j]);
+      }
+    }
+  }
+  block_reduce_store<NACC>(acc, partials, G);
+}
+
 // Final sums of one PA pass scattered into red[] (layout above).  One wavefront
 // per column (grid = 2*MAXL+2 blocks of 64): each lane sums its strided share in
 // order, then a butterfly -- the same bits on every run.
@@ -637,6 +722,133 @@ __global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, doubl
         vv[j] = ld<VEC>(vk[j] + en);
       }
     }
+  }
+  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+      const double fin = f[i];
+      double x = fin;
+#pragma unroll
+      for (int j = 0; j < MAXK; j++) {
+        if (j < ncomb) {
+          double v = vk[j][i];
+          double w = (!COMPACT || (j == 0 && norm0)) ? wk[j][i] : 0.0;
+          if (j == 0 && norm0) {
+            const double d = w - fin;
+            w = RCP ? rs * d : d / s;
+            v = RCP ? rs * v : v / s;
+            if (COMPACT) v = v - w;
+            wk[0][i] = w;
+            vk[0][i] = v;
+          }
+          x = COMPACT ? x + ck[j] * v : comb1<COMB>(x, ck[j], w, v);
+        }
+      }
+      wnew[i] = fin;
+      vnew[i] = x;
+      f[i] = x;
+    }
+  }
+}
+
+// ---- PB with a SMALL ROLLING WINDOW of loads ---------------------------------------
+// tools/hbm_probe (mode m): a kernel reading 22 streams and writing 5 moves 5.5 TB/s with
+// every load of a tile in flight, 5.7 software-pipelined, 5.9 when each wave keeps only a
+// ring of FOUR loads in flight and re-issues a slot the moment it has been consumed
+// (pure reads: 7.25 against 7.0 TB/s) -- fewer streams are open in the DRAMs at any
+// moment, and the load issue never stops for the arithmetic or the stores.  Here the MAXK
+// pairs of a tile go through a ring of W (pair j in slot j mod W; a consumed slot is
+// re-loaded with pair j+W of this tile or pair j+W-MAXK of the block's next tile); f
+// and, with compact storage, the raw w of the pending pair are requested one tile ahead.
+// Same arithmetic in the same order => same bits as k_combine.  Single pass, VEC = 2.
+template <int MAXK, int COMB, int W>
+__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  constexpr bool RCP = (COMB == 1);
+  constexpr bool COMPACT = (COMB == 2);
+  static_assert(MAXK % W == 0, "the ring must divide the pairs of a tile");
+  const int G = gridDim.x;
+  const int ncomb = ctl.ic[IC_NCOMB];
+  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
+  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
+  const int32_t *cs = ctl.comb_slots();
+  const double *cc = ctl.comb_c();
+  const bool norm0 = ctl.ic[IC_NORMED] != 0;
+  const double s = ctl.dc[DC_S];
+  const double rs = 1.0 / s;
+
+  double *wk[MAXK], *vk[MAXK];
+  double ck[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; j++) {
+    const bool live = j < ncomb;
+    const size_t off = live ? (size_t)(cs[j] - 1) * vs.stride : 0;
+    wk[j] = live ? vs.w + off : f;
+    vk[j] = live ? vs.v + off : f;
+    ck[j] = cc[j];
+  }
+  // compact storage reads w only for the pending pair that is normalised now
+  const double *w0src = norm0 ? wk[0] : f;
+
+  const int64_t ntile = vs.n / (kBlock * VEC);
+  V finv, w0v, rw[COMPACT ? 1 : W], rv[W];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    finv = ld<VEC>(f + e);
+    if (COMPACT) w0v = ld<VEC>(w0src + e);
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      if (!COMPACT) rw[j] = ld<VEC>(wk[j] + e);
+      rv[j] = ld<VEC>(vk[j] + e);
+    }
+  }
+  for (; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    const V fin = finv;
+    V w0 = COMPACT ? w0v : fin;
+    V x = fin;
+    st(wnew + e, fin);
+    __builtin_amdgcn_sched_barrier(0);
+    finv = ld<VEC>(f + en);
+    if (COMPACT) w0v = ld<VEC>(w0src + en);
+#pragma unroll
+    for (int j = 0; j < MAXK; j++) {
+      V wj = COMPACT ? w0 : rw[COMPACT ? 0 : j % W];
+      V vj = rv[j % W];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + W < MAXK) {
+        if (!COMPACT) rw[COMPACT ? 0 : j % W] = ld<VEC>(wk[j + W] + e);
+        rv[j % W] = ld<VEC>(vk[j + W] + e);
+      } else {
+        if (!COMPACT) rw[COMPACT ? 0 : j % W] = ld<VEC>(wk[j + W - MAXK] + en);
+        rv[j % W] = ld<VEC>(vk[j + W - MAXK] + en);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == 0 && norm0) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          const double d = ex(wj, q) - ex(fin, q);
+          const double wn = RCP ? rs * d : d / s;
+          const double vn = RCP ? rs * ex(vj, q) : ex(vj, q) / s;
+          setc(wj, q, wn);
+          setc(vj, q, COMPACT ? vn - wn : vn);
+        }
+        st(wk[0] + e, wj);
+        st(vk[0] + e, vj);
+      }
+      if (j < ncomb) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          if (COMPACT) setc(x, q, ex(x, q) + ck[j] * ex(vj, q));
+          else setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wj, q), ex(vj, q)));
+        }
+      }
+    }
+    st(vnew + e, x);
+    st(f + e, x);
   }
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {

@@ -68,6 +68,94 @@ __global__ __launch_bounds__(256) void k_stream(const double *base, double *wbas
   if (S > 0 && acc == 12345.678) out[0] = acc;  // keep the loads alive
 }
 
+// Pure-read variant with the arithmetic of the NKA dot pass: per element, stream 0 (f) and
+// stream 1 (w1) give fq and d = w1 - f, every other stream x adds TWO fp64 FMAs
+// (acc_d += d*x, acc_f += fq*x) into its own pair of accumulators, as k_dots does.
+template <int S>
+__global__ __launch_bounds__(256) void k_stream_fma(const double *base, size_t stride, size_t n, double *out) {
+  const size_t ntile = n / 512;
+  double acc[2 * S];
+#pragma unroll
+  for (int a = 0; a < 2 * S; a++) acc[a] = 0.0;
+  for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    double2 v[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) v[s] = ld2<true>(base + s * stride + t * 512 + threadIdx.x * 2);
+    const double fx = v[0].x, fy = v[0].y, dx = v[1].x - fx, dy = v[1].y - fy;
+    acc[0] = fma(dx, dx, acc[0]); acc[0] = fma(dy, dy, acc[0]);
+    acc[1] = fma(fx, dx, acc[1]); acc[1] = fma(fy, dy, acc[1]);
+#pragma unroll
+    for (int s = 2; s < S; s++) {
+      acc[2 * s] = fma(dx, v[s].x, acc[2 * s]);     acc[2 * s] = fma(dy, v[s].y, acc[2 * s]);
+      acc[2 * s + 1] = fma(fx, v[s].x, acc[2 * s + 1]); acc[2 * s + 1] = fma(fy, v[s].y, acc[2 * s + 1]);
+    }
+  }
+  double tot = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2 * S; a++) tot += acc[a];
+  if (tot == 12345.678) out[0] = tot;
+}
+
+// Mixed read/write with a SMALL ROLLING WINDOW of loads: streams 0,1 are loaded a tile ahead,
+// streams 2..S-1 go through a ring of WIN registers (a consumed slot is re-loaded at once, across
+// the tile boundary), then W streams are stored per tile -- the shape of the NKA combine pass.
+template <int S, int W, int WIN, int NTS>
+__global__ __launch_bounds__(256) void k_stream_win(const double *base, double *wbase, size_t stride, size_t n, double *out) {
+  constexpr int R = S - 2;
+  static_assert(R % WIN == 0, "ring must divide the ringed streams");
+  const size_t ntile = n / 512;
+  double acc = 0.0;
+  double2 a0, a1, ring[WIN];
+  size_t t = blockIdx.x;
+  if (t < ntile) {
+    a0 = ld2<true>(base + t * 512 + threadIdx.x * 2);
+    a1 = ld2<true>(base + stride + t * 512 + threadIdx.x * 2);
+#pragma unroll
+    for (int j = 0; j < WIN; j++) ring[j] = ld2<true>(base + (2 + j) * stride + t * 512 + threadIdx.x * 2);
+  }
+  for (; t < ntile; t += gridDim.x) {
+    const size_t tn = (t + gridDim.x < ntile) ? t + gridDim.x : t;
+    double2 sum = {a0.x + a1.x, a0.y + a1.y};
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = ld2<true>(base + tn * 512 + threadIdx.x * 2);
+    a1 = ld2<true>(base + stride + tn * 512 + threadIdx.x * 2);
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const double2 x = ring[j % WIN];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + WIN < R) ring[j % WIN] = ld2<true>(base + (2 + j + WIN) * stride + t * 512 + threadIdx.x * 2);
+      else ring[j % WIN] = ld2<true>(base + (2 + j + WIN - R) * stride + tn * 512 + threadIdx.x * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      sum.x += x.x; sum.y += x.y;
+    }
+    acc += sum.x + sum.y;
+#pragma unroll
+    for (int w = 0; w < W; w++) st2<NTS>(wbase + w * stride + t * 512 + threadIdx.x * 2, sum);
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int S, int W, int WIN, int NTS>
+void runw(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 3;
+  hipLaunchKernelGGL((k_stream_win<S, W, WIN, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream_win<S, W, WIN, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+}
+
 // Burst variant: each block reads B tiles of S streams, THEN writes B tiles of W streams.
 template <int S, int W, int B, int NTS>
 __global__ __launch_bounds__(256) void k_burst(const double *base, double *wbase, size_t stride, size_t n, double *out) {
@@ -223,6 +311,38 @@ int main(int argc, char **argv) {
 #define R(S, W, T, NTL, NTS, MAP, G) run<S, W, T, NTL, NTS, MAP>("S=" #S " W=" #W " T=" #T " ntl=" #NTL " st=" #NTS " map=" #MAP, rd, wr, stride, n, out, G)
 #define RB(S, W, B, NTS, G) runb<S, W, B, NTS>("burst S=" #S " W=" #W " B=" #B " st=" #NTS, rd, wr, stride, n, out, G)
 #define RP(S, W, NTS, G) runp<S, W, NTS>("pipelined S=" #S " W=" #W " st=" #NTS, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 'f') {   // does the fp64 arithmetic of the dot pass cost bandwidth?  ("f" zeros, "fr" random)
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+      R(22, 0, 1, true, 0, 0, cu);
+      hipLaunchKernelGGL((k_stream_fma<22>), dim3(cu), dim3(256), 0, 0, rd, stride, n, out);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < 3; r++) hipLaunchKernelGGL((k_stream_fma<22>), dim3(cu), dim3(256), 0, 0, rd, stride, n, out);
+      CK(hipEventRecord(e1));
+      CK(hipDeviceSynchronize());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", "S=22 pure read + 84 fp64 FMAs per tile-thread", cu,
+             22.0 * n * 8.0 * 3 / (ms * 1e-3) / 1e9, ms / 3);
+    }
+    return 0;
+  }
+#define RW(S, W, WIN, NTS, G) runw<S, W, WIN, NTS>("window S=" #S " W=" #W " WIN=" #WIN " st=" #NTS, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 'm') {   // mixed read/write: all loads in flight vs a small rolling window ("m" zeros, "mr" random)
+    for (int rep = 0; rep < 2; rep++)
+      for (int g : {cu * 1, cu * 2}) {
+        R(22, 5, 1, true, 1, 0, g);
+        RP(22, 5, 1, g);
+        RW(22, 5, 2, 1, g); RW(22, 5, 4, 1, g); RW(22, 5, 5, 1, g); RW(22, 5, 10, 1, g); RW(22, 5, 4, 2, g);
+        R(42, 5, 1, true, 1, 0, g);
+        RW(42, 5, 4, 1, g); RW(42, 5, 8, 1, g); RW(42, 5, 10, 1, g);
+        RW(22, 0, 4, 1, g);
+      }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'w') {   // pure-write study: store policy x tiles per iteration x blocks per CU
     for (int g : {cu * 1, cu * 2, cu * 4, cu * 8}) {
       R(0, 4, 1, true, 0, 0, g); R(0, 4, 1, true, 1, 0, g); R(0, 4, 1, true, 2, 0, g); R(0, 4, 1, true, 3, 0, g); R(0, 4, 1, true, 4, 0, g);
