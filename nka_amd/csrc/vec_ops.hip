@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 
 using namespace nka;
@@ -389,6 +390,169 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *
     }
 }
 
+// ---- the two heavy stages with a ROLLING WINDOW of loads (16-byte path) -----------------
+// Same idea as k_dots_win / k_combine_win of the array flavour (nka_kernels.hpp): the NV
+// streamed vectors (pairs) of a tile go through a ring of WIN registers -- slot j mod WIN
+// holds vector j, a consumed slot is re-loaded at once with vector j+WIN of this tile or
+// j+WIN-NV of the block's next tile -- and the tile's own operands (w, v, f / z) are
+// requested one tile ahead.  4-6 loads in flight per wave move more bytes per second
+// than all of a tile's loads at once (profiles/r02/hbm_probe_rolling_window.txt).  Same
+// arithmetic in the same order => same bits as the kernels above.
+constexpr int kWin = 4;
+
+template <int NV, bool SUB, bool PRE>
+__global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, double *w, double *v, double a,
+                                                                    double pre_a, const double *__restrict__ f,
+                                                                    ManyArgs m, double *__restrict__ partials) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  static_assert(NV % kWin == 0, "the ring must divide the unroll width");
+  const int G = gridDim.x;
+  double acc[2 * NV + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * NV + 1; j++) acc[j] = 0.0;
+  const double *ys[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) ys[j] = (j < m.count) ? m.x[j] : f;
+  const int64_t ntile = n / (kBlock * VEC);
+  V wv, vv, fv, ring[kWin];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    wv = ld<VEC>(w + e);
+    vv = ld<VEC>(v + e);
+    fv = ld<VEC>(f + e);
+#pragma unroll
+    for (int j = 0; j < kWin; j++) ring[j] = ld<VEC>(ys[j] + e);
+  }
+  for (; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    double wn[VEC], fq[VEC];
+    V wout = wv, vout = vv;
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      fq[q] = ex(fv, q);
+      const double w0 = PRE ? pre_a * fq[q] + ex(wv, q) : ex(wv, q);
+      wn[q] = a * w0;
+      double vn = a * ex(vv, q);
+      if (SUB) vn = (-1.0) * wn[q] + vn;
+      setc(wout, q, wn[q]);
+      setc(vout, q, vn);
+      acc[2 * NV] = fma(fq[q], wn[q], acc[2 * NV]);
+    }
+    st(w + e, wout);
+    st(v + e, vout);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tn != t) {                       // (on the last iteration w, v of this tile were just rewritten)
+      wv = ld<VEC>(w + en);
+      vv = ld<VEC>(v + en);
+    }
+    fv = ld<VEC>(f + en);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const V y = ring[j % kWin];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + kWin < NV) ring[j % kWin] = ld<VEC>(ys[j + kWin] + e);
+      else ring[j % kWin] = ld<VEC>(ys[j + kWin - NV] + en);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        acc[j] = fma(wn[q], ex(y, q), acc[j]);
+        acc[NV + j] = fma(fq[q], ex(y, q), acc[NV + j]);
+      }
+    }
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      const double fq = f[i];
+      const double w0 = PRE ? pre_a * fq + w[i] : w[i];
+      const double wn = a * w0;
+      double vn = a * v[i];
+      if (SUB) vn = (-1.0) * wn + vn;
+      w[i] = wn;
+      v[i] = vn;
+      acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const double y = ys[j][i];
+        acc[j] = fma(wn, y, acc[j]);
+        acc[NV + j] = fma(fq, y, acc[NV + j]);
+      }
+    }
+  block_reduce_store<2 * NV + 1>(acc, partials, G);
+}
+
+template <int NV, bool PAIRS>
+__global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, double *z, ManyArgs m, double *keep_in,
+                                                                 double *keep_out) {
+  constexpr int VEC = 2;
+  using V = typename VecT<VEC>::type;
+  static_assert(NV % kWin == 0, "the ring must divide the unroll width");
+  const int G = gridDim.x;
+  const double *xs[NV], *ys[PAIRS ? NV : 1];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    xs[j] = (j < m.count) ? m.x[j] : z;
+    if (PAIRS) ys[j] = (j < m.count) ? m.y[j] : z;
+  }
+  const int64_t ntile = n / (kBlock * VEC);
+  V znext, rx[kWin], ry[PAIRS ? kWin : 1];
+  int64_t t = blockIdx.x;
+  if (t < ntile) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    znext = ld<VEC>(z + e);
+#pragma unroll
+    for (int j = 0; j < kWin; j++) {
+      rx[j] = ld<VEC>(xs[j] + e);
+      if (PAIRS) ry[j] = ld<VEC>(ys[j] + e);
+    }
+  }
+  for (; t < ntile; t += G) {
+    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
+    V zv = znext;
+    if (keep_in) st(keep_in + e, zv);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tn != t) znext = ld<VEC>(z + en);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const V xj = rx[j % kWin];
+      const V yj = ry[PAIRS ? j % kWin : 0];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + kWin < NV) {
+        rx[j % kWin] = ld<VEC>(xs[j + kWin] + e);
+        if (PAIRS) ry[j % kWin] = ld<VEC>(ys[j + kWin] + e);
+      } else {
+        rx[j % kWin] = ld<VEC>(xs[j + kWin - NV] + en);
+        if (PAIRS) ry[j % kWin] = ld<VEC>(ys[j + kWin - NV] + en);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < m.count) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          if (PAIRS) setc(zv, q, (m.a[j] * ex(xj, q) + m.b[j] * ex(yj, q)) + ex(zv, q));
+          else setc(zv, q, m.a[j] * ex(xj, q) + ex(zv, q));
+        }
+      }
+    }
+    if (keep_out) st(keep_out + e, zv);
+    st(z + e, zv);
+  }
+  if (blockIdx.x == G - 1)
+    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
+      double zi = z[i];
+      if (keep_in) keep_in[i] = zi;
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+        if (j < m.count) zi = PAIRS ? (m.a[j] * m.x[j][i] + m.b[j] * m.y[j][i]) + zi : m.a[j] * m.x[j][i] + zi;
+      if (keep_out) keep_out[i] = zi;
+      z[i] = zi;
+    }
+}
+
 // Persistent grid.  Light kernels (a few loads per thread) fill the chip with 8
 // blocks per CU; the fused many-vector kernels keep `nloads` 16-byte loads per
 // thread in flight and follow the rule measured for the array flavour (ONE block
@@ -398,6 +562,15 @@ int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec, int nloads = 2) {
   int64_t g = (int64_t)ws->num_cu * per_cu;
   g = std::min<int64_t>(g, std::max<int64_t>(n / (kBlock * vec), 1));
   return (int)std::min<int64_t>(g, kMaxGrid);
+}
+
+// NKA_HIP_VEC_WIN=0: the all-loads-in-flight forms of the two heavy stage kernels (A/B aid)
+bool use_win() {
+  static const bool on = [] {
+    const char *e = getenv("NKA_HIP_VEC_WIN");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 int width_for(int count) { return std::max(4, ((count + 3) / 4) * 4); }   // unroll width 4, 8, ..., kManyMax
@@ -469,8 +642,14 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
       }
     }
     const int nv = width_for(m.count);
-    const int g = grid_for(ws, n, v2 ? 2 : 1, (PAIRS ? 2 : 1) * nv + 1);
-#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+    const int g = grid_for(ws, n, v2 ? 2 : 1, (v2 && use_win()) ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
+#define LAUNCH2(NV)                                                                                                  \
+  do {                                                                                                               \
+    if (use_win())                                                                                                   \
+      hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout);  \
+  } while (0)
 #define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
@@ -798,14 +977,17 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
       v2 = v2 && al16(m.x[j]);
     }
     const int nv = width_for(m.count);
-    const int g = grid_for(ws, n, v2 ? 2 : 1, nv + 3);
+    const int g = grid_for(ws, n, v2 ? 2 : 1, (v2 && use_win()) ? 22 : nv + 3);   // rolling-window kernel: one block per CU
 #define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
   hipLaunchKernelGGL((k_scale_dot_pair_many<NV, VEC, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
                      ws->partials)
-#define L2SP(NV) NKA_SDPM(NV, 2, true, true)
-#define L2SN(NV) NKA_SDPM(NV, 2, true, false)
-#define L2NP(NV) NKA_SDPM(NV, 2, false, true)
-#define L2NN(NV) NKA_SDPM(NV, 2, false, false)
+#define NKA_SDPMW(NV, SUB, PRE)                                                                                  \
+  hipLaunchKernelGGL((k_scale_dot_pair_many_win<NV, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
+                     ws->partials)
+#define L2SP(NV) do { if (use_win()) NKA_SDPMW(NV, true, true); else NKA_SDPM(NV, 2, true, true); } while (0)
+#define L2SN(NV) do { if (use_win()) NKA_SDPMW(NV, true, false); else NKA_SDPM(NV, 2, true, false); } while (0)
+#define L2NP(NV) do { if (use_win()) NKA_SDPMW(NV, false, true); else NKA_SDPM(NV, 2, false, true); } while (0)
+#define L2NN(NV) do { if (use_win()) NKA_SDPMW(NV, false, false); else NKA_SDPM(NV, 2, false, false); } while (0)
 #define L1SP(NV) NKA_SDPM(NV, 1, true, true)
 #define L1SN(NV) NKA_SDPM(NV, 1, true, false)
 #define L1NP(NV) NKA_SDPM(NV, 1, false, true)
@@ -826,6 +1008,7 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef L1NP
 #undef L1NN
 #undef NKA_SDPM
+#undef NKA_SDPMW
     hipLaunchKernelGGL(k_finalize, dim3(2 * nv + 1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1,
                        ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
