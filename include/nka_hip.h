@@ -205,11 +205,13 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
 /* Kernel-variant switches for A/B measurements inside one process (same
- * allocations, same thermal state): "pa_pipe" = 0 (k_dots), 2 or 4 (k_dots_pipe), -1
- * automatic (env NKA_HIP_PA_PIPE); "pb_pipe" = 0 (k_combine), 2 or 4
- * (k_combine_pipe with that many load groups), -1 automatic (the default; env
- * NKA_HIP_PB_PIPE); "serial_solve" = 0/1.  Results are
- * bit-identical across variants. */
+ * allocations, same thermal state).  "pa_pipe" / "pb_pipe" (env NKA_HIP_PA_PIPE /
+ * NKA_HIP_PB_PIPE): -1 automatic (default); 0 = every load of a tile in flight
+ * (k_dots / k_combine); 2, 4 = software-pipelined over that many load groups per
+ * tile (k_dots_pipe / k_combine_pipe); 200 + 10*w + b = rolling window (k_dots_win /
+ * k_combine_win) with a ring of 4, 2, MAXL/4 or MAXL/2 registers (w = 0..3) and b
+ * blocks per CU, e.g. 201.  "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave;
+ * "serial_solve" = 0/1.  Results are bit-identical across variants. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,

@@ -246,13 +246,10 @@ int launch_dots_pipe_1(const nka_hip_state *a, const double *f) {
   return g;
 }
 
-// `pipe` = 2 or 4 groups per tile, or the group size itself: 101 = one vector per group
-// (a rolling window: every consumed load is re-issued at once), 102 = two per group
+// `pipe` = 2 or 4 load groups per tile (finer groups measured no better: profiles/r02/ab_inproc_pipelined_passes.txt)
 template <int MAXL>
 int launch_dots_pipe_g(int pipe, const nka_hip_state *a, const double *f) {
   switch (pipe) {
-    case 101: return launch_dots_pipe_1<MAXL, 1>(a, f);
-    case 102: return launch_dots_pipe_1<MAXL, 2>(a, f);
     case 4: return launch_dots_pipe_1<MAXL, MAXL / 4>(a, f);
     default: return launch_dots_pipe_1<MAXL, MAXL / 2>(a, f);
   }
@@ -343,8 +340,6 @@ int launch_combine_pipe_1(const nka_hip_state *a, double *f) {
 template <int MAXK, int COMB>
 int launch_combine_pipe_g(int pipe, const nka_hip_state *a, double *f) {
   switch (pipe) {
-    case 101: return launch_combine_pipe_1<MAXK, COMB, 1>(a, f);
-    case 102: return launch_combine_pipe_1<MAXK, COMB, 2>(a, f);
     case 4: return launch_combine_pipe_1<MAXK, COMB, MAXK / 4>(a, f);
     default: return launch_combine_pipe_1<MAXK, COMB, MAXK / 2>(a, f);
   }
@@ -1144,15 +1139,13 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102 &&
-        !(value >= 200 && value < 240))
-      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (pairs per group), "
+    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value >= 200 && value < 240))
+      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (load groups per tile), "
                                   "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXK/4, MAXK/2; B blocks per CU)");
     a->pb_pipe = value;
   } else if (k == "pa_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && value != 101 && value != 102 &&
-        !(value >= 200 && value < 240))
-      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (groups per tile), 101, 102 (vectors per group), "
+    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value >= 200 && value < 240))
+      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), "
                                   "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXL/4, MAXL/2; B blocks per CU)");
     a->pa_pipe = value;
   } else if (k == "serial_solve") {
