@@ -1,4 +1,4 @@
-for r in 1 2 3; do
-  echo "win   : $(nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)   compact $(nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 1 | sed -n 2p)"
-  echo "no win: $(NKA_HIP_VEC_WIN=0 nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p)   compact $(NKA_HIP_VEC_WIN=0 nka_amd/fortran/build/nka_vector_driver bench 4 10000000 20 30 1 | sed -n 2p)"
-done
+bash tools/rocprof_bench.sh r02 c > gpurun_out/rocprof_c.log 2>&1; tail -4 gpurun_out/rocprof_c.log
+bash tools/rocprof_bench.sh r02 f08 > gpurun_out/rocprof_f08.log 2>&1; tail -4 gpurun_out/rocprof_f08.log
+bash tools/pmc_memsys.sh r02 f08 > gpurun_out/memsys_f08.log 2>&1; tail -5 gpurun_out/memsys_f08.log
+bash tools/pmc_memsys.sh r02 c > gpurun_out/memsys_c.log 2>&1; tail -5 gpurun_out/memsys_c.log

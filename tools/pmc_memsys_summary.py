@@ -24,22 +24,23 @@ def main():
         for f in glob.glob(os.path.join(pdir, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "nka::k_dots<" not in k and "nka::k_combine<" not in k:
+                if not re.search(r"nka::k_(dots|combine)(_win|_pipe)?<", k):
                     continue
                 name = k.split("(")[0].replace("void ", "")
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for f in glob.glob(os.path.join(pdir, "**", "*_kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "nka::k_dots<" in k or "nka::k_combine<" in k:
+                if re.search(r"nka::k_(dots|combine)(_win|_pipe)?<", k):
                     name = k.split("(")[0].replace("void ", "")
                     dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
         for stem in ("k_dots", "k_combine"):
-            best, bw = None, -1
+            best, key = None, (-1, -1)
             for name in agg:
-                m = re.match(rf"nka::{stem}<(\d+)", name)
-                if m and int(m.group(1)) > bw:
-                    best, bw = name, int(m.group(1))
+                m = re.match(rf"nka::{stem}(?:_win|_pipe)?<(\d+)", name)
+                nlaunch = max(len(v) for v in agg[name].values())
+                if m and (int(m.group(1)), nlaunch) > key:      # widest instance, then the most launched variant
+                    best, key = name, (int(m.group(1)), nlaunch)
             if best is None:
                 continue
             for ctr, vals in agg[best].items():

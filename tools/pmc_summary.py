@@ -10,7 +10,8 @@ Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes, are in KiB, and on
 gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane)
 coalesced streaming read -> doubled here; WRITE_SIZE is exact for 16-B stores.
-Only steady-state launches (the widest template instance) are averaged.
+Only steady-state launches (the widest template instance of k_dots* / k_combine*,
+whichever variant the library chose) are averaged.
 """
 import argparse
 import collections
@@ -31,11 +32,13 @@ def load_counter(path, counter):
 
 
 def widest(agg, stem):
-    best, bw = None, -1
+    """Steady-state kernel of a pass: the widest template instance; among equal widths (the
+    library switches variants while the list fills) the one launched most often."""
+    best, key = None, (-1, -1)
     for k in agg:
-        m = re.match(rf"nka::{stem}<(\d+)", k)
-        if m and int(m.group(1)) > bw:
-            best, bw = k, int(m.group(1))
+        m = re.match(rf"nka::{stem}(?:_win|_pipe)?<(\d+)", k)     # k_dots / k_dots_pipe / k_dots_win: the same pass
+        if m and (int(m.group(1)), len(agg[k])) > key:
+            best, key = k, (int(m.group(1)), len(agg[k]))
     return best
 
 
