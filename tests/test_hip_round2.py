@@ -218,3 +218,56 @@ def test_bench_two_gpus(torch_cuda):
     assert d["n_gpus"] == 2 and d["config"]["steady_state"]
     assert all(c["identical"] for c in d["replica_check"])
     assert 0.0 < d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+@pytest.mark.parametrize("n,m", [(40961, 8), (100003, 20), (5003, 5)])
+def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
+    """The streaming passes exist in three forms (every load of a tile in flight,
+    software-pipelined over load groups, rolling window) and the scalar step in two;
+    nka_hip_set_tuning switches between them.  All of them restate the same
+    arithmetic in the same order: outputs, stored vectors and the replicated state
+    must agree BIT FOR BIT with the automatic choice, through list growth, capacity
+    and dependence drops, a repeated input, relax and restart."""
+    import nka_amd
+    rng = np.random.default_rng(100 * m + flavor)
+    basis = rng.standard_normal((3, n))
+    X = []
+    for t in range(m + 9):
+        X.append(rng.standard_normal(3) @ basis if t % 6 == 4 else rng.standard_normal(n))
+    X[m + 3] = X[m + 2].copy()                      # s == 0 -> relax inside the update
+
+    def run(settings):
+        acc = nka_amd.nka().init(n, m, flavor=flavor)
+        for k, v in settings.items():
+            acc.set_tuning(k, v)
+        outs = []
+        for t, x in enumerate(X):
+            ft = torch_cuda.from_numpy(x.copy()).cuda()
+            acc.accel_update(ft)
+            outs.append(ft.cpu().numpy())
+            if t == m + 5:
+                acc.relax()
+            if t == m + 7:
+                acc.restart()
+        st = acc.state()
+        live = st.list_order()
+        ix = np.ix_([k - 1 for k in live[1:]], [k - 1 for k in live[1:]])
+        return (outs, acc.state_digest(), acc.w(st.first), acc.v(st.first),
+                (live, st.free_order(), st.subspace, st.pending, st.h[ix].tobytes(), st.c[[k - 1 for k in live[1:]]].tobytes()))
+
+    ref = run({})
+    variants = [{"pa_pipe": 0, "pb_pipe": 0}, {"pa_pipe": 2, "pb_pipe": 2}, {"pa_pipe": 4, "pb_pipe": 4},
+                {"pa_pipe": 201, "pb_pipe": 201}, {"pa_pipe": 211, "pb_pipe": 211}, {"pa_pipe": 221, "pb_pipe": 221},
+                {"pa_pipe": 231, "pb_pipe": 231}, {"pa_pipe": 202, "pb_pipe": 202}, {"solve_variant": 1},
+                {"serial_solve": 1}]
+    for settings in variants:
+        got = run(settings)
+        for t, (a, b) in enumerate(zip(ref[0], got[0])):
+            assert np.array_equal(a, b), (settings, t, np.abs(a - b).max())
+        assert got[4] == ref[4], settings            # lists, free list, flags, factor and coefficients of the live entries
+        if "serial_solve" not in settings:           # (the one-lane solve leaves other bits in entries nobody reads)
+            assert got[1] == ref[1], settings        # digest of the whole control blocks incl. the reduced sums
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), settings
+    with pytest.raises(nka_amd.NKAError):
+        nka_amd.nka().init(16, 2).set_tuning("pa_pipe", 7)

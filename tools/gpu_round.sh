@@ -1,4 +1,1 @@
-bash tools/rocprof_bench.sh r02 c > gpurun_out/rocprof_c.log 2>&1; tail -4 gpurun_out/rocprof_c.log
-bash tools/rocprof_bench.sh r02 f08 > gpurun_out/rocprof_f08.log 2>&1; tail -4 gpurun_out/rocprof_f08.log
-bash tools/pmc_memsys.sh r02 f08 > gpurun_out/memsys_f08.log 2>&1; tail -5 gpurun_out/memsys_f08.log
-bash tools/pmc_memsys.sh r02 c > gpurun_out/memsys_c.log 2>&1; tail -5 gpurun_out/memsys_c.log
+timeout 900 python -m pytest tests/test_hip_round2.py -m gpu -q --tb=short -k "variant" 2>&1 | grep -E "passed|failed|^FAILED|^E  " | tail -12
