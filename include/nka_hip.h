@@ -208,9 +208,8 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * allocations, same thermal state).  "pa_pipe" / "pb_pipe" (env NKA_HIP_PA_PIPE /
  * NKA_HIP_PB_PIPE): -1 automatic (default); 0 = every load of a tile in flight
  * (k_dots / k_combine); 2, 4 = software-pipelined over that many load groups per
- * tile (k_dots_pipe / k_combine_pipe); 200 + 10*w + b = rolling window (k_dots_win /
- * k_combine_win) with a ring of 4, 2, MAXL/4 or MAXL/2 registers (w = 0..3) and b
- * blocks per CU, e.g. 201.  "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave;
+ * tile (k_dots_pipe / k_combine_pipe); 201..204 = rolling window (k_dots_win /
+ * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.  "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave;
  * "serial_solve" = 0/1.  Results are bit-identical across variants. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 

@@ -255,8 +255,7 @@ int launch_dots_pipe_g(int pipe, const nka_hip_state *a, const double *f) {
   }
 }
 
-// rolling-window PA: ring of W registers (W = 4 divides every unroll width; 2, MAXL/4 and
-// MAXL/2 also offered), `bpc` blocks per CU
+// rolling-window PA: ring of W registers, `bpc` blocks per CU
 template <int MAXL, int W>
 int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
   static const int occ = occupancy_of(k_dots_win<MAXL, W>);
@@ -269,22 +268,23 @@ int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
   return (int)g;
 }
 
-// wsel: 0 -> W = 4, 1 -> W = 2, 2 -> W = MAXL/4, 3 -> W = MAXL/2
+// The ring size: a small divisor of the width (4, 5, 6, 3 or 7), or the width itself when it
+// is prime (then every load of a tile is in flight and each is re-issued for the next tile
+// as soon as it has been consumed).  Rings of 2, MAXL/4 and MAXL/2 measured slower than 4
+// (profiles/r02/ab_inproc_pipelined_passes.txt).
 template <int MAXL>
-int launch_dots_win_g(int wsel, const nka_hip_state *a, const double *f, int bpc) {
-  switch (wsel) {
-    case 1: return launch_dots_win_1<MAXL, 2>(a, f, bpc);
-    case 2: return launch_dots_win_1<MAXL, (MAXL / 4 > 0 ? MAXL / 4 : 1)>(a, f, bpc);
-    case 3: return launch_dots_win_1<MAXL, MAXL / 2>(a, f, bpc);
-    default: return launch_dots_win_1<MAXL, 4>(a, f, bpc);
-  }
+constexpr int win_ring() {
+  return MAXL % 4 == 0 ? 4 : MAXL % 5 == 0 ? 5 : MAXL % 6 == 0 ? 6 : MAXL % 3 == 0 ? 3 : MAXL % 7 == 0 ? 7 : MAXL;
 }
 
-int launch_dots_win(int maxl, int wsel, const nka_hip_state *a, const double *f, int bpc) {
+// instantiated for EVERY width 1..32 so that no list length needs padding
+int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc) {
 #define CASE(L) \
-  case L: return launch_dots_win_g<L>(wsel, a, f, bpc);
-  switch (maxl) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  case L: return launch_dots_win_1<L, win_ring<L>()>(a, f, bpc);
+  switch (width) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+    CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
+    CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
   }
 #undef CASE
   return 0;
@@ -364,7 +364,7 @@ int launch_combine_pipe(int pipe, int flavor, int maxk, const nka_hip_state *a, 
   }
 }
 
-// rolling-window PB: ring of W pairs (wsel 0 -> 4, 1 -> 2, 2 -> MAXK/4, 3 -> MAXK/2), `bpc` blocks per CU
+// rolling-window PB: ring of W pairs, `bpc` blocks per CU; every width 1..32 (no padding)
 template <int MAXK, int COMB, int W>
 int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   static const int occ = occupancy_of(k_combine_win<MAXK, COMB, W>);
@@ -375,32 +375,24 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   return (int)g;
 }
 
-template <int MAXK, int COMB>
-int launch_combine_win_g(int wsel, const nka_hip_state *a, double *f, int bpc) {
-  switch (wsel) {
-    case 1: return launch_combine_win_1<MAXK, COMB, 2>(a, f, bpc);
-    case 2: return launch_combine_win_1<MAXK, COMB, (MAXK / 4 > 0 ? MAXK / 4 : 1)>(a, f, bpc);
-    case 3: return launch_combine_win_1<MAXK, COMB, MAXK / 2>(a, f, bpc);
-    default: return launch_combine_win_1<MAXK, COMB, 4>(a, f, bpc);
-  }
-}
-
 template <int COMB>
-int launch_combine_win_w(int maxk, int wsel, const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) {
 #define CASE(K) \
-  case K: return launch_combine_win_g<K, COMB>(wsel, a, f, bpc);
-  switch (maxk) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+  case K: return launch_combine_win_1<K, COMB, win_ring<K>()>(a, f, bpc);
+  switch (width) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+    CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
+    CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
   }
 #undef CASE
   return 0;
 }
 
-int launch_combine_win(int flavor, int maxk, int wsel, const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f, int bpc) {
   switch (flavor) {
-    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_win_w<1>(maxk, wsel, a, f, bpc);
-    case NKA_HIP_FLAVOR_C: return launch_combine_win_w<2>(maxk, wsel, a, f, bpc);
-    default: return launch_combine_win_w<0>(maxk, wsel, a, f, bpc);
+    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_win_w<1>(width, a, f, bpc);
+    case NKA_HIP_FLAVOR_C: return launch_combine_win_w<2>(width, a, f, bpc);
+    default: return launch_combine_win_w<0>(width, a, f, bpc);
   }
 }
 
@@ -657,14 +649,18 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
   const int maxl = (vec == 1) ? 4 : (older_ub > kMaxPerPass ? kMaxPerPass : round_up4(older_ub));
   const int npass = std::max(1, (older_ub + maxl - 1) / maxl);
   // Automatic choice, from in-process A/B runs (tools/ab_inproc.py, profiles/r02/ab_inproc_*.txt):
-  // the rolling-window kernel (ring of 4, one block per CU) wins by 5-8 % whenever the unroll width
+  // the rolling-window kernel (small ring, one block per CU) wins by 4-11 % whenever the unroll width
   // carries no padding (m = 20: 2.58 vs 2.75 ms at n = 1e8, 0.374 vs 0.394 at 1.25e7, 44 vs 48 us
-  // at 1e6) -- padded entries are cache hits that occupy ring slots and starve the window (m = 5 at
-  // n = 1e8: +20 %); otherwise the 4-group pipeline for large vectors (-1.9 %), else k_dots.
+  // at 1e6; m = 10: 1.43 vs 1.60 ms at n = 1e8) -- padded entries are cache hits that occupy ring
+  // slots and starve the window (m = 5 padded to 8 at n = 1e8: +20 %), which is why it is instantiated
+  // for EVERY width 1..32; the fallbacks (k_dots_pipe for large vectors, k_dots) serve mvec > 32 and
+  // unaligned f.
   int pa_pipe = a->pa_pipe;
-  if (pa_pipe < 0) pa_pipe = (older_ub == maxl) ? 201 : ((a->n >= 30000000) ? 4 : 0);
-  if (vec == 2 && npass == 1 && pa_pipe >= 200 && pa_pipe < 300) {    // rolling window: 2WB, W selector, B blocks per CU
-    launch_dots_win(maxl, (pa_pipe - 200) / 10, a, f, std::max(1, (pa_pipe - 200) % 10));
+  // the rolling-window kernel exists for every width 1..32, so the list needs no padding
+  const bool exact = vec == 2 && older_ub >= 1 && older_ub <= kMaxPerPass;
+  if (pa_pipe < 0) pa_pipe = exact ? 201 : ((a->n >= 30000000) ? 4 : 0);
+  if (vec == 2 && npass == 1 && pa_pipe > 200 && pa_pipe < 210) {     // rolling window, 200 + blocks per CU
+    launch_dots_win(exact ? older_ub : maxl, a, f, std::max(1, pa_pipe - 200));
   } else if (vec == 2 && npass == 1 && pa_pipe > 0) {  // software-pipelined single pass (k_dots_pipe)
     launch_dots_pipe(pa_pipe, maxl, a, f);
   } else {
@@ -686,8 +682,8 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   // 1e7 m = 20) and equals the 4-group pipeline for the two-vectors-per-pair flavours.
   int pipe = a->pb_pipe;
   if (pipe < 0) pipe = 201;
-  if (vec == 2 && npass == 1 && pipe >= 200 && pipe < 300) {   // rolling window: 2WB, W selector, B blocks per CU
-    launch_combine_win(a->flavor, maxk, (pipe - 200) / 10, a, f, std::max(1, (pipe - 200) % 10));
+  if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
+    launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1139,14 +1135,12 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value >= 200 && value < 240))
-      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (load groups per tile), "
-                                  "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXK/4, MAXK/2; B blocks per CU)");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
+      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pb_pipe = value;
   } else if (k == "pa_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value >= 200 && value < 240))
-      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), "
-                                  "2WB (rolling window: W selector 0..3 = ring of 4, 2, MAXL/4, MAXL/2; B blocks per CU)");
+    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
+      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pa_pipe = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;

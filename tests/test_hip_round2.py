@@ -258,8 +258,8 @@ def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
 
     ref = run({})
     variants = [{"pa_pipe": 0, "pb_pipe": 0}, {"pa_pipe": 2, "pb_pipe": 2}, {"pa_pipe": 4, "pb_pipe": 4},
-                {"pa_pipe": 201, "pb_pipe": 201}, {"pa_pipe": 211, "pb_pipe": 211}, {"pa_pipe": 221, "pb_pipe": 221},
-                {"pa_pipe": 231, "pb_pipe": 231}, {"pa_pipe": 202, "pb_pipe": 202}, {"solve_variant": 1},
+                {"pa_pipe": 201, "pb_pipe": 201}, {"pa_pipe": 202, "pb_pipe": 202}, {"pa_pipe": 201, "pb_pipe": 0},
+                {"pa_pipe": 4, "pb_pipe": 201}, {"solve_variant": 1},
                 {"serial_solve": 1}]
     for settings in variants:
         got = run(settings)
