@@ -1,3 +1,4 @@
-mkdir -p gpurun_out
-bash tools/sweep.sh > gpurun_out/sweep_n_mvec.txt 2>&1; cat gpurun_out/sweep_n_mvec.txt
-bash tools/sweep.sh f08 > gpurun_out/sweep_n_mvec_f08.txt 2>&1; tail -6 gpurun_out/sweep_n_mvec_f08.txt
+python tools/ab_pad.py --pads 0 256 2048 2304 --vlen 1e8 2>&1 | tail -5
+python tools/ab_pad.py --pads 0 256 2304 --vlen 134217728 2>&1 | tail -4
+python tools/ab_pad.py --pads 0 256 2304 --vlen 67108864 2>&1 | tail -4
+python tools/ab_pad.py --pads 0 256 2048 2304 --vlen 1.25e7 2>&1 | tail -5
