@@ -40,6 +40,19 @@ int nka_ex_pc_ssor(nka_ex_t s, int32_t nsweep, double omega, double *r_dev);
 /* u = u - r on the interior of uext  (:248). */
 int nka_ex_update_solution(nka_ex_t s, double *uext_dev, const double *r_dev);
 
+/* The same system on DEVICE GRID VECTORS (the abstract-vector flavour of the example,
+ * /root/reference/src-F08-vector/nka_example.F90:103-120, 147-179, whose u and r are
+ * grid_vector objects: (nx+2) x (ny+2) values, elementwise operations cover the ghost
+ * ring, reductions do not -- grid_vector_type.F90:104-195).  Layout of a device grid
+ * vector (nka_amd/fortran/vector/hip_grid_vector_type.F90): the nx*ny interior values
+ * first, x(j,k) at [(j-1) + (k-1)*nx], then the ring -- row k = 0 (j = 0..nx+1), row
+ * k = ny+1, column j = 0 (k = 1..ny), column j = nx+1 -- so every reduction of the
+ * vector hooks runs over a dense, aligned prefix.
+ *   residual_grid: r(1:nx,1:ny) <- residual(u); the ring of r is left alone (:112-118)
+ *   pc_ssor_grid : r(:,:) <- z, i.e. the preconditioned interior and a ZERO ring (:178) */
+int nka_ex_residual_grid(nka_ex_t s, const double *u_grid_dev, double *r_grid_dev);
+int nka_ex_pc_ssor_grid(nka_ex_t s, int32_t nsweep, double omega, double *r_grid_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,8 @@ SIGNATURES.update({
     "nka_ex_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nka_ex_pc_ssor": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "nka_ex_update_solution": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nka_ex_residual_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nka_ex_pc_ssor_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
 })
 
 

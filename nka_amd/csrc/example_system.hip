@@ -40,45 +40,64 @@ namespace {
 
 constexpr int kT = 256;
 
+// Two layouts of a cell-centred field with its boundary ring:
+//   GRID = false: the natural (nx+2) x (ny+2) array, u(j,k) at [j + k*(nx+2)]
+//   GRID = true : the device grid vector of nka_amd/fortran/vector/hip_grid_vector_type.F90 --
+//                 the nx*ny interior values packed first, u(j,k) at [(j-1) + (k-1)*nx], then the
+//                 ring: row k = 0 (j = 0..nx+1), row k = ny+1, column j = 0 (k = 1..ny), column
+//                 j = nx+1.  Reductions of the vector hooks then run over a dense prefix.
+template <bool GRID>
+__device__ __forceinline__ double u_at(const double *__restrict__ u, int nx, int ny, int j, int k) {
+  if (!GRID) return u[j + (int64_t)k * (nx + 2)];
+  if (j >= 1 && j <= nx && k >= 1 && k <= ny) return u[(j - 1) + (int64_t)(k - 1) * nx];
+  const double *ring = u + (int64_t)nx * ny;
+  if (k == 0) return ring[j];
+  if (k == ny + 1) return ring[(nx + 2) + j];
+  if (j == 0) return ring[2 * (nx + 2) + (k - 1)];
+  return ring[2 * (nx + 2) + ny + (k - 1)];
+}
+
 // nka_example.F90:122-142.  The reference accumulates t*h^2 of the two cells next to
 // a face into a zeroed array (k outer, j inner: the lower-index cell first) and then
 // takes 2/sum: one thread per face does the same two additions in the same order.
+template <bool GRID>
 __global__ __launch_bounds__(kT) void k_ex_faces(int nx, int ny, double a, double hx2, double hy2,
                                                  const double *__restrict__ uext, double *__restrict__ ax,
                                                  double *__restrict__ ay) {
   const int64_t nax = (int64_t)(nx + 1) * ny, nay = (int64_t)nx * (ny + 1);
-  const int64_t ldu = nx + 2;
   for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < nax + nay; i += (int64_t)gridDim.x * kT) {
     if (i < nax) {
       const int j = (int)(i % (nx + 1)) + 1, k = (int)(i / (nx + 1)) + 1;   // face between cells (j-1,k) and (j,k)
       double sum = 0.0;
-      if (j - 1 >= 1) sum = sum + ((1.0 / (a + uext[(j - 1) + k * ldu])) * hx2);
-      if (j <= nx) sum = sum + ((1.0 / (a + uext[j + k * ldu])) * hx2);
+      if (j - 1 >= 1) sum = sum + ((1.0 / (a + u_at<GRID>(uext, nx, ny, j - 1, k))) * hx2);
+      if (j <= nx) sum = sum + ((1.0 / (a + u_at<GRID>(uext, nx, ny, j, k))) * hx2);
       ax[i] = 2.0 / sum;
     } else {
       const int64_t q = i - nax;
       const int j = (int)(q % nx) + 1, k = (int)(q / nx) + 1;               // face between cells (j,k-1) and (j,k)
       double sum = 0.0;
-      if (k - 1 >= 1) sum = sum + ((1.0 / (a + uext[j + (int64_t)(k - 1) * ldu])) * hy2);
-      if (k <= ny) sum = sum + ((1.0 / (a + uext[j + (int64_t)k * ldu])) * hy2);
+      if (k - 1 >= 1) sum = sum + ((1.0 / (a + u_at<GRID>(uext, nx, ny, j, k - 1))) * hy2);
+      if (k <= ny) sum = sum + ((1.0 / (a + u_at<GRID>(uext, nx, ny, j, k))) * hy2);
       ay[q] = 2.0 / sum;
     }
   }
 }
 
 // nka_example.F90:143-145 (ac) and :112-118 (the residual), q = 1 (:100)
+template <bool GRID>
 __global__ __launch_bounds__(kT) void k_ex_residual(int nx, int ny, const double *__restrict__ uext,
                                                     const double *__restrict__ ax, const double *__restrict__ ay,
                                                     double *__restrict__ ac, double *__restrict__ r) {
-  const int64_t n = (int64_t)nx * ny, ldu = nx + 2, ldx = nx + 1;
+  const int64_t n = (int64_t)nx * ny, ldx = nx + 1;
   for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
     const int j = (int)(i % nx) + 1, k = (int)(i / nx) + 1;
     const double axl = ax[(j - 1) + (k - 1) * ldx], axr = ax[j + (k - 1) * ldx];
     const double ayl = ay[(j - 1) + (int64_t)(k - 1) * nx], ayr = ay[(j - 1) + (int64_t)k * nx];
     const double c = axl + axr + ayl + ayr;
     ac[i] = c;
-    r[i] = c * uext[j + k * ldu] - axl * uext[(j - 1) + k * ldu] - axr * uext[(j + 1) + k * ldu] -
-           ayl * uext[j + (k - 1) * ldu] - ayr * uext[j + (k + 1) * ldu] - 1.0;
+    r[i] = c * u_at<GRID>(uext, nx, ny, j, k) - axl * u_at<GRID>(uext, nx, ny, j - 1, k) -
+           axr * u_at<GRID>(uext, nx, ny, j + 1, k) - ayl * u_at<GRID>(uext, nx, ny, j, k - 1) -
+           ayr * u_at<GRID>(uext, nx, ny, j, k + 1) - 1.0;
   }
 }
 
@@ -139,6 +158,23 @@ int grid_of(int64_t n) {
 
 }  // namespace
 
+namespace {
+template <bool GRID>
+int residual_impl(nka_ex_t s, const double *u, double *r, const char *who) {
+  if (!s) return nka_detail::set_error(NKA_HIP_EINVAL, "null system");
+  EX_TRY(hipSetDevice(s->device));
+  const int64_t n = (int64_t)s->nx * s->ny, next = (int64_t)(s->nx + 2) * (s->ny + 2);
+  if (int rc = nka_detail::check_device_span(u, next, who)) return rc;
+  if (int rc = nka_detail::check_device_span(r, GRID ? next : n, who)) return rc;
+  const int64_t nfaces = (int64_t)(s->nx + 1) * s->ny + (int64_t)s->nx * (s->ny + 1);
+  hipLaunchKernelGGL(k_ex_faces<GRID>, dim3(grid_of(nfaces)), dim3(kT), 0, s->stream, s->nx, s->ny, s->a, s->hx * s->hx,
+                     s->hy * s->hy, u, s->ax, s->ay);
+  hipLaunchKernelGGL(k_ex_residual<GRID>, dim3(grid_of(n)), dim3(kT), 0, s->stream, s->nx, s->ny, u, s->ax, s->ay, s->ac, r);
+  EX_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int nka_ex_create(nka_ex_t *out, int32_t nx, int32_t ny, double a, int32_t device, void *stream) {
@@ -183,18 +219,12 @@ int nka_ex_destroy(nka_ex_t s) {
   return 0;
 }
 
-int nka_ex_residual(nka_ex_t s, const double *uext, double *r) {
-  if (!s) return nka_detail::set_error(NKA_HIP_EINVAL, "null system");
-  EX_TRY(hipSetDevice(s->device));
-  const int64_t n = (int64_t)s->nx * s->ny, next = (int64_t)(s->nx + 2) * (s->ny + 2);
-  if (int rc = nka_detail::check_device_span(uext, next, "nka_ex_residual: uext")) return rc;
-  if (int rc = nka_detail::check_device_span(r, n, "nka_ex_residual: r")) return rc;
-  const int64_t nfaces = (int64_t)(s->nx + 1) * s->ny + (int64_t)s->nx * (s->ny + 1);
-  hipLaunchKernelGGL(k_ex_faces, dim3(grid_of(nfaces)), dim3(kT), 0, s->stream, s->nx, s->ny, s->a, s->hx * s->hx,
-                     s->hy * s->hy, uext, s->ax, s->ay);
-  hipLaunchKernelGGL(k_ex_residual, dim3(grid_of(n)), dim3(kT), 0, s->stream, s->nx, s->ny, uext, s->ax, s->ay, s->ac, r);
-  EX_TRY(hipGetLastError());
-  return 0;
+int nka_ex_residual(nka_ex_t s, const double *uext, double *r) { return residual_impl<false>(s, uext, r, "nka_ex_residual"); }
+
+// grid-vector layout: the interior prefix of r is written, its ring is left alone
+// (src-F08-vector/nka_example.F90:103-120 assigns r(1:nx,1:ny) only)
+int nka_ex_residual_grid(nka_ex_t s, const double *u_grid, double *r_grid) {
+  return residual_impl<true>(s, u_grid, r_grid, "nka_ex_residual_grid");
 }
 
 int nka_ex_pc_ssor(nka_ex_t s, int32_t nsweep, double omega, double *r) {
@@ -205,6 +235,18 @@ int nka_ex_pc_ssor(nka_ex_t s, int32_t nsweep, double omega, double *r) {
   hipLaunchKernelGGL(k_ex_ssor, dim3(1), dim3(kSsorThreads), 0, s->stream, s->nx, s->ny, nsweep, omega, s->ax, s->ay,
                      s->ac, r, s->z);
   EX_TRY(hipGetLastError());
+  return 0;
+}
+
+// r(:,:) = z with z = 0 on the ring (src-F08-vector/nka_example.F90:150, 178): the interior
+// prefix through the same sweeps, the ring zeroed
+int nka_ex_pc_ssor_grid(nka_ex_t s, int32_t nsweep, double omega, double *r_grid) {
+  if (!s) return nka_detail::set_error(NKA_HIP_EINVAL, "null system");
+  const int64_t n = (int64_t)s->nx * s->ny, next = (int64_t)(s->nx + 2) * (s->ny + 2);
+  EX_TRY(hipSetDevice(s->device));
+  if (int rc = nka_detail::check_device_span(r_grid, next, "nka_ex_pc_ssor_grid: r")) return rc;
+  if (int rc = nka_ex_pc_ssor(s, nsweep, omega, r_grid)) return rc;
+  EX_TRY(hipMemsetAsync(r_grid + n, 0, sizeof(double) * (size_t)(next - n), s->stream));
   return 0;
 }
 

@@ -10,6 +10,15 @@
 !! results are rounded like the Fortran expressions of grid_vector (a*x + b*y + z
 !! evaluated left to right, no fused multiply-add); dot products are
 !! deterministic two-stage reductions.
+!!
+!! UNREDUCED TAIL.  A vector may carry NTAIL extra values behind its fields that
+!! every elementwise procedure covers and NO reduction sees -- the ghost / halo
+!! values of the reference's grid_vector (grid_vector_type.F90:104-165 operate on
+!! the whole array, :170-197 sum the interior only).  Keeping them BEHIND the
+!! reduced values (instead of interleaved, as a ring around a 2-D array) lets every
+!! reduction and every fused stage kernel run over one dense, aligned prefix; the
+!! tail (O(sqrt(n)) values for a ghost ring) is finished by the plain elementwise
+!! kernels.  hip_grid_vector_type.F90 builds the 2-D grid vector on this.
 
 module hip_block_vector_type
 
@@ -23,7 +32,8 @@ module hip_block_vector_type
   type, extends(vector), public :: hip_block_vector
     integer :: nfield = 0
     integer(c_int64_t) :: nper = 0
-    integer(c_int64_t) :: ntot = 0              ! nfield*nper
+    integer(c_int64_t) :: ntot = 0              ! nfield*nper + the unreduced tail
+    integer(c_int64_t) :: nred = 0              ! nfield*nper: the leading values that reductions see
     type(c_ptr) :: base = c_null_ptr            ! device pointer to ntot doubles; field k starts at (k-1)*nper
     type(c_ptr) :: ws = c_null_ptr              ! shared workspace (stream, reduction scratch); not owned
   contains
@@ -66,15 +76,21 @@ contains
     call nka_hip_check(nka_hip_vec_workspace_create(ws, int(device, c_int32_t), c_null_ptr), 'vec_workspace_create')
   end function
 
-  subroutine init(this, nfield, nper, ws)
+  subroutine init(this, nfield, nper, ws, ntail)
     class(hip_block_vector), intent(inout) :: this
     integer, intent(in) :: nfield
     integer(c_int64_t), intent(in) :: nper
     type(c_ptr), intent(in) :: ws
+    integer(c_int64_t), intent(in), optional :: ntail   ! values behind the fields that reductions skip
     call this%release
     this%nfield = nfield
     this%nper = nper
-    this%ntot = nfield * nper
+    this%nred = nfield * nper
+    this%ntot = this%nred
+    if (present(ntail)) then
+      if (ntail < 0) error stop 'hip_block_vector%init: negative tail'
+      this%ntot = this%nred + ntail
+    end if
     this%ws = ws
     call nka_hip_check(nka_hip_vec_alloc(ws, this%ntot, this%base), 'vec_alloc')
   end subroutine
@@ -87,7 +103,16 @@ contains
     this%base = c_null_ptr
     this%nfield = 0
     this%ntot = 0
+    this%nred = 0
   end subroutine
+
+  !! device address of the unreduced tail of `this`
+  type(c_ptr) function tail_ptr(this)
+    class(hip_block_vector), intent(in) :: this
+    integer(c_intptr_t) :: addr
+    addr = transfer(this%base, addr) + int(this%nred, c_intptr_t) * 8_c_intptr_t
+    tail_ptr = transfer(addr, tail_ptr)
+  end function
 
   !! device address of field k
   type(c_ptr) function field_ptr(this, k)
@@ -122,7 +147,7 @@ contains
     allocate(hip_block_vector :: clone)
     select type (clone)
     type is (hip_block_vector)
-      call clone%init(this%nfield, this%nper, this%ws)
+      call clone%init(this%nfield, this%nper, this%ws, this%ntot - this%nred)
     end select
   end subroutine
 
@@ -135,7 +160,7 @@ contains
     select type (clone)
     type is (hip_block_vector)
       do k = 1, n
-        call clone(k)%init(this%nfield, this%nper, this%ws)
+        call clone(k)%init(this%nfield, this%nper, this%ws, this%ntot - this%nred)
       end do
     end select
   end subroutine
@@ -214,14 +239,14 @@ contains
     val = 0.0_r8
     select type (y)
     class is (hip_block_vector)
-      call nka_hip_check(nka_hip_vec_dot(x%ws, x%ntot, x%base, y%base, val), 'vec_dot')
+      call nka_hip_check(nka_hip_vec_dot(x%ws, x%nred, x%base, y%base, val), 'vec_dot')
     end select
   end function
 
   function norm2_(this) result(val)
     class(hip_block_vector), intent(in) :: this
     real(r8) :: val
-    call nka_hip_check(nka_hip_vec_norm2(this%ws, this%ntot, this%base, val), 'vec_norm2')
+    call nka_hip_check(nka_hip_vec_norm2(this%ws, this%nred, this%base, val), 'vec_norm2')
   end function
 
   !! vals(j) = <this, ys(idx(j))>: `this` is read once while the ys stream past.
@@ -241,7 +266,7 @@ contains
     class default
       error stop 'incompatible arguments to VECTOR%DOT_MANY'
     end select
-    call nka_hip_check(nka_hip_vec_dot_many(this%ws, this%ntot, this%base, ptrs, size(idx, kind=c_int32_t), vals), &
+    call nka_hip_check(nka_hip_vec_dot_many(this%ws, this%nred, this%base, ptrs, size(idx, kind=c_int32_t), vals), &
                        'vec_dot_many')
   end subroutine
 
@@ -260,7 +285,7 @@ contains
         do j = 1, size(idx)
           ptrs(j) = ys(idx(j))%base
         end do
-        call nka_hip_check(nka_hip_vec_dot_pair_many(this%ws, this%ntot, this%base, other%base, ptrs, &
+        call nka_hip_check(nka_hip_vec_dot_pair_many(this%ws, this%nred, this%base, other%base, ptrs, &
                            size(idx, kind=c_int32_t), vals_this, vals_other, cross), 'vec_dot_pair_many')
       class default
         error stop 'incompatible arguments to VECTOR%DOT_PAIR_MANY'
@@ -331,7 +356,7 @@ contains
     stored = .false.
     select type (x)
     class is (hip_block_vector)
-      call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%ntot, this%base, a, x%base, 0_c_int32_t, s), &
+      call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%nred, this%base, a, x%base, 0_c_int32_t, s), &
                          'vec_update_norm2')
     class default
       error stop 'incompatible arguments to VECTOR%UPDATE_NORM2'
@@ -353,6 +378,7 @@ contains
     type(c_ptr) :: ptrs(max(size(idx),1))
     integer :: j
     integer(c_int32_t) :: pre
+    integer(c_int64_t) :: nt
     real(r8) :: pa
     pre = 0
     pa = 0.0_r8
@@ -369,9 +395,17 @@ contains
           do j = 1, size(idx)
             ptrs(j) = ys(idx(j))%base
           end do
-          call nka_hip_check(nka_hip_vec_scale_dot_pair_many(this%ws, this%ntot, this%base, v%base, a, &
+          call nka_hip_check(nka_hip_vec_scale_dot_pair_many(this%ws, this%nred, this%base, v%base, a, &
                              merge(1_c_int32_t, 0_c_int32_t, subtract), pre, pa, f%base, ptrs, &
                              size(idx, kind=c_int32_t), vals_this, vals_f, cross), 'vec_scale_dot_pair_many')
+          nt = this%ntot - this%nred
+          if (nt > 0) then   ! the elementwise statements of the stage on the unreduced tail, hook by hook
+            if (pre /= 0) call nka_hip_check(nka_hip_vec_update1(this%ws, nt, tail_ptr(this), pa, tail_ptr(f)), 'vec_update1')
+            call nka_hip_check(nka_hip_vec_scale(this%ws, nt, tail_ptr(this), a), 'vec_scale')
+            call nka_hip_check(nka_hip_vec_scale(this%ws, nt, tail_ptr(v), a), 'vec_scale')
+            if (subtract) call nka_hip_check(nka_hip_vec_update1(this%ws, nt, tail_ptr(v), -1.0_r8, tail_ptr(this)), &
+                                             'vec_update1')
+          end if
           return
         end select
       end select
@@ -401,8 +435,16 @@ contains
               xp(j) = xs(idx(j))%base
               yp(j) = ys(idx(j))%base
             end do
-            call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot, this%base, a, xp, b, yp, &
+            call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%nred, this%base, a, xp, b, yp, &
                                size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_update_many_keep')
+            if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
+              do j = 1, size(idx)
+                xp(j) = tail_ptr(xs(idx(j)))
+                yp(j) = tail_ptr(ys(idx(j)))
+              end do
+              call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, b, yp, &
+                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_update_many_keep')
+            end if
             return
           end select
         end select
@@ -428,8 +470,15 @@ contains
           do j = 1, size(idx)
             xp(j) = xs(idx(j))%base
           end do
-          call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot, this%base, a, xp, &
+          call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%nred, this%base, a, xp, &
                              size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_axpy_many_keep')
+          if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
+            do j = 1, size(idx)
+              xp(j) = tail_ptr(xs(idx(j)))
+            end do
+            call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                               size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_axpy_many_keep')
+          end if
           return
         end select
       end select

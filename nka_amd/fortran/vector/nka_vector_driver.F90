@@ -15,9 +15,18 @@
 !!       small result up to the rounding of the sums (tests/test_hip_fullsize.py).
 !!       Written per call: x, num_vec, the FIRST tile of the result, and the
 !!       2-norm of (result - tiled first tile), which must be exactly zero.
+!!   nka_vector_driver checkgrid NX NY MVEC NCALLS OUTFILE [COMPACT 0|1]
+!!       the same on a hip_grid_vector (NX x NY cells plus a ghost ring, the
+!!       device counterpart of the reference's grid_vector): every value of the
+!!       (NX+2) x (NY+2) array, ghosts included, comes from the LCG, so a
+!!       reduction that saw a ghost would change every decision.  Written per call:
+!!       the input array, num_vec, the returned array (natural layout, ghosts
+!!       included) -- compared with the compiled reference on its own grid_vector.
 !!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
+!!   nka_vector_driver benchgrid NX NY MVEC STEPS [COMPACT 0|1]
+!!       the same on a hip_grid_vector of NX x NY cells plus its ghost ring.
 
 program nka_vector_driver
 
@@ -25,12 +34,13 @@ program nka_vector_driver
   use, intrinsic :: iso_c_binding
   use vector_class
   use hip_block_vector_type
+  use hip_grid_vector_type
   use nka_type
   implicit none
 
   character(256) :: mode, arg, outfile
   integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1
-  logical :: compact
+  logical :: compact, grid = .false.
   integer(i8) :: nper
   integer(i8) :: lcg_state = 1
 
@@ -47,13 +57,21 @@ program nka_vector_driver
     end if
     compact = icompact /= 0
     call run_check
+  case ('checkgrid')
+    call get_command_argument(6, outfile)
+    if (command_argument_count() >= 7) then
+      call get_command_argument(7, arg); read(arg,*) icompact
+    end if
+    compact = icompact /= 0
+    call run_checkgrid
   case ('checktile')
     call get_command_argument(6, outfile)
     call get_command_argument(7, arg); read(arg,*) icompact
     call get_command_argument(8, arg); read(arg,*) rtile
     compact = icompact /= 0
     call run_checktile
-  case ('bench')
+  case ('bench', 'benchgrid')
+    grid = trim(mode) == 'benchgrid'
     if (command_argument_count() >= 6) then
       call get_command_argument(6, arg); read(arg,*) icompact
     end if
@@ -115,6 +133,51 @@ contains
     write(*,'(a,i0,a,i0)') 'check: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
   end subroutine
 
+  subroutine run_checkgrid
+    type(hip_grid_vector) :: f
+    type(nka) :: accel
+    type(c_ptr) :: ws
+    real(r8), allocatable :: host(:,:), pool(:,:,:), coef(:)
+    integer :: t, k, lun, nx, ny, i, j
+    nx = nfield
+    ny = int(nper)
+    ws = hip_block_vector_workspace(0)
+    call f%init_grid(nx, ny, ws)
+    call accel%init(f, mvec, compact=compact)
+    allocate(host(0:nx+1,0:ny+1), pool(0:nx+1,0:ny+1,3), coef(3))
+    do k = 1, 3
+      do j = 0, ny+1
+        do i = 0, nx+1
+          pool(i,j,k) = lcg()
+        end do
+      end do
+    end do
+    open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    do t = 1, ncalls
+      if (mod(t, 5) == 0) then
+        do k = 1, 3
+          coef(k) = lcg()
+        end do
+        host = coef(1)*pool(:,:,1) + coef(2)*pool(:,:,2) + coef(3)*pool(:,:,3)
+      else
+        do j = 0, ny+1
+          do i = 0, nx+1
+            host(i,j) = lcg()
+          end do
+        end do
+      end if
+      write(lun) host
+      call f%set_array(host)
+      call accel%accel_update(f)
+      call f%get_array(host)
+      write(lun) real(accel%num_vec(), r8)
+      write(lun) host
+    end do
+    close(lun)
+    if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
+    write(*,'(a,i0,a,i0)') 'checkgrid: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
+  end subroutine
+
   subroutine run_checktile
     type(hip_block_vector) :: f
     type(nka) :: accel
@@ -172,25 +235,32 @@ contains
   end subroutine
 
   subroutine run_bench
-    type(hip_block_vector) :: f
-    type(hip_block_vector), allocatable :: inputs(:)
+    class(hip_block_vector), allocatable :: f
+    class(hip_block_vector), allocatable :: inputs(:)
     type(nka) :: accel
     type(c_ptr) :: ws
     real(r8), allocatable :: host(:)
     integer :: t, k, warm, ninp
     integer(i8) :: n, c0, c1, rate
     real(r8) :: secs, per, dummy
-    n = nfield * nper
     warm = mvec + 3
     ninp = warm + ncalls
     ws = hip_block_vector_workspace(0)
-    call f%init(nfield, nper, ws)
+    if (grid) then            ! NX = nfield, NY = nper: one field of NX*NY cells plus the ghost ring
+      allocate(hip_grid_vector :: f)
+      allocate(hip_grid_vector :: inputs(ninp))
+    else
+      allocate(hip_block_vector :: f)
+      allocate(hip_block_vector :: inputs(ninp))
+    end if
+    call make(f)
+    n = f%nred
     call accel%init(f, mvec, compact=compact)
     !! independent inputs, resident on the device before the timed region
-    allocate(inputs(ninp), host(nper))
+    allocate(host(f%nper))
     do t = 1, ninp
-      call inputs(t)%init(nfield, nper, ws)
-      do k = 1, nfield
+      call make(inputs(t))
+      do k = 1, f%nfield
         call random_number(host)
         host = 2.0_r8*host - 1.0_r8
         call inputs(t)%set_field(k, host)
@@ -210,8 +280,13 @@ contains
     call system_clock(c1)
     secs = real(c1 - c0, r8) / real(rate, r8)
     per = secs / ncalls
-    write(*,'(a,i0,a,i0,a,i0,a,l1)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec, &
-                                     ' compact=', compact
+    if (grid) then
+      write(*,'(a,i0,a,i0,a,i0,a,i0,a,l1)') 'abstract-vector path on a grid vector: ', nfield, ' x ', nper, &
+          ' cells + ghost ring of ', f%ntot - f%nred, ' mvec=', mvec, ' compact=', compact
+    else
+      write(*,'(a,i0,a,i0,a,i0,a,l1)') 'abstract-vector path: fields=', nfield, ' n_per_field=', nper, ' mvec=', mvec, &
+                                       ' compact=', compact
+    end if
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
     !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector
     !! 8n(11+3m) = the contract figure (compact option: 8n(11+2m))
@@ -223,6 +298,17 @@ contains
     end if
     write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by contract bytes 8n(11+3m) ', &
                         8.0_r8*n*(11+3*mvec)/per/8.0e12_r8
+  contains
+    subroutine make(v)
+      class(hip_block_vector), intent(inout) :: v
+      select type (v)
+      type is (hip_grid_vector)
+        call v%init_grid(nfield, int(nper), ws)
+        call v%setval(0.0_r8)
+      class default
+        call v%init(nfield, nper, ws)
+      end select
+    end subroutine
   end subroutine
 
 end program nka_vector_driver

@@ -72,6 +72,46 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("nx,ny,mvec,ncalls", [(7, 5, 3, 14), (50, 50, 6, 24), (33, 17, 20, 45), (1, 1, 2, 6)])
+def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_build, oracle, tmp_path, nx, ny, mvec,
+                                                                       ncalls, compact):
+    """hip_grid_vector: elementwise hooks cover the ghost ring,
+    reductions do not (grid_vector_type.F90:104-195).  Every value of the
+    (nx+2) x (ny+2) input, ghosts included, is random, so a reduction that saw a
+    ghost would change the coefficients.  Checked against the compiled reference
+    on its OWN grid_vector (oracle/_ref/libnka_ref_f08vec.so) over the whole array,
+    and against the oracle on the interior (which also supplies the pivots of the
+    tolerance rule)."""
+    out = tmp_path / "grid.bin"
+    p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "checkgrid", str(nx), str(ny),
+                        str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    ntot = (nx + 2) * (ny + 2)
+    raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * ntot + 1)
+    ora = oracle.OracleNKA(nx * ny, mvec, oracle.F08_VECTOR)
+    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnka_ref_f08vec.so"))
+    ref = oracle.RefF08Vector(nx, ny, mvec) if have_ref else None
+    key = f"abstract vector on grid vector {nx}x{ny} m={mvec} compact={compact}"
+    for t in range(ncalls):
+        x = raw[t, :ntot].reshape(ny + 2, nx + 2)          # Fortran array(0:nx+1,0:ny+1), first index fastest
+        nv, got = int(raw[t, ntot]), raw[t, ntot + 1:].reshape(ny + 2, nx + 2)
+        xin = np.ascontiguousarray(x[1:-1, 1:-1]).ravel()
+        f = xin.copy()
+        ora.accel_update(f)
+        assert nv == ora.num_vec(), (t, nv, ora.num_vec())
+        gin = np.ascontiguousarray(got[1:-1, 1:-1]).ravel()
+        P.check(S.rel_err(gin, f, xin), ora.state(), key + " interior vs oracle F08-vector", where=t)
+        if ref is not None:
+            full = np.ascontiguousarray(x).ravel().copy()
+            ref.accel_update(full)
+            assert nv == ref.num_vec(), (t, nv, ref.num_vec())
+            # whole array, ghosts included, against the reference's own ghost handling
+            P.check(S.rel_err(got.ravel(), full, x.ravel()), ora.state(), key + " whole array vs compiled reference",
+                    where=t)
+
+
+@pytest.mark.gpu
 def test_fortran_array_bench_runs(fortran_build):
     p = subprocess.run([os.path.join(fortran_build, "nka_bench"), "2000000", "6", "5", "0"],
                        capture_output=True, text=True, timeout=300)

@@ -1,4 +1,5 @@
-python tools/ab_pad.py --pads 0 256 2048 2304 --vlen 1e8 2>&1 | tail -5
-python tools/ab_pad.py --pads 0 256 2304 --vlen 134217728 2>&1 | tail -4
-python tools/ab_pad.py --pads 0 256 2304 --vlen 67108864 2>&1 | tail -4
-python tools/ab_pad.py --pads 0 256 2048 2304 --vlen 1.25e7 2>&1 | tail -5
+B=nka_amd/fortran/build
+$B/nka_vector_driver bench 4 10000000 20 30 0
+$B/nka_vector_driver benchgrid 6324 6325 20 30 0
+$B/nka_vector_driver benchgrid 6324 6325 20 30 1
+$B/nka_vector_driver benchgrid 6325 6325 20 30 0
