@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_dot(int64_t n, const double *__restr
 }
 
 // ---- batched hooks: one pass for many dots / many axpys -----------
-constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24); longer lists run several launches
+constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24; window kernels: every width 1..24); longer lists run several launches
 struct ManyArgs {
   const double *x[kManyMax];
   const double *y[kManyMax];
@@ -398,9 +398,15 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *
 // requested one tile ahead.  4-6 loads in flight per wave move more bytes per second
 // than all of a tile's loads at once (profiles/r02/hbm_probe_rolling_window.txt).  Same
 // arithmetic in the same order => same bits as the kernels above.
-constexpr int kWin = 4;
+// The ring size: a small divisor of the width (4, 5, 6, 3 or 7), or the width itself when it is
+// prime.  The window kernels are instantiated for EVERY width 1..kManyMax: a padded entry is a
+// cache hit that occupies a ring slot and starves the window (nka_hip.hip:win_ring).
+template <int NV>
+constexpr int win_ring() {
+  return NV % 4 == 0 ? 4 : NV % 5 == 0 ? 5 : NV % 6 == 0 ? 6 : NV % 3 == 0 ? 3 : NV % 7 == 0 ? 7 : NV;
+}
 
-template <int NV, bool SUB, bool PRE>
+template <int NV, bool SUB, bool PRE, int kWin = win_ring<NV>()>
 __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, double *w, double *v, double a,
                                                                     double pre_a, const double *__restrict__ f,
                                                                     ManyArgs m, double *__restrict__ partials) {
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
   block_reduce_store<2 * NV + 1>(acc, partials, G);
 }
 
-template <int NV, bool PAIRS>
+template <int NV, bool PAIRS, int kWin = win_ring<NV>()>
 __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, double *z, ManyArgs m, double *keep_in,
                                                                  double *keep_out) {
   constexpr int VEC = 2;
@@ -585,6 +591,17 @@ int width_for(int count) { return std::max(4, ((count + 3) / 4) * 4); }   // unr
     default: CALL(24); break;    \
   }
 
+#define NKA_DISPATCH_EXACT(nv, CALL)                                                              \
+  switch (nv) {                                                                                   \
+    case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;   \
+    case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;   \
+    case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+    case 17: CALL(17); break; case 18: CALL(18); break; case 19: CALL(19); break; case 20: CALL(20); break; \
+    case 21: CALL(21); break; case 22: CALL(22); break; case 23: CALL(23); break; default: CALL(24); break; \
+  }
+static_assert(kManyMax == 24, "NKA_DISPATCH_EXACT covers widths 1..24");
+
 bool al16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 template <int OP>
@@ -641,17 +658,14 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
         v2 = v2 && al16(m.y[j]);
       }
     }
-    const int nv = width_for(m.count);
-    const int g = grid_for(ws, n, v2 ? 2 : 1, (v2 && use_win()) ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
-#define LAUNCH2(NV)                                                                                                  \
-  do {                                                                                                               \
-    if (use_win())                                                                                                   \
-      hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout); \
-    else                                                                                                             \
-      hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout);  \
-  } while (0)
+    const bool win = v2 && use_win();
+    const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernels: exact width, no padding
+    const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
+#define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
 #define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
-    if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+    if (win) { NKA_DISPATCH_EXACT(nv, LAUNCHW) } else if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+#undef LAUNCHW
 #undef LAUNCH2
 #undef LAUNCH1
     HIP_TRYV(hipGetLastError());
@@ -976,29 +990,41 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
       m.x[j] = ys[j];
       v2 = v2 && al16(m.x[j]);
     }
-    const int nv = width_for(m.count);
-    const int g = grid_for(ws, n, v2 ? 2 : 1, (v2 && use_win()) ? 22 : nv + 3);   // rolling-window kernel: one block per CU
+    const bool win = v2 && use_win();
+    const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernel: exact width, no padding
+    const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : nv + 3);   // rolling-window kernel: one block per CU
 #define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
   hipLaunchKernelGGL((k_scale_dot_pair_many<NV, VEC, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
                      ws->partials)
 #define NKA_SDPMW(NV, SUB, PRE)                                                                                  \
   hipLaunchKernelGGL((k_scale_dot_pair_many_win<NV, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
                      ws->partials)
-#define L2SP(NV) do { if (use_win()) NKA_SDPMW(NV, true, true); else NKA_SDPM(NV, 2, true, true); } while (0)
-#define L2SN(NV) do { if (use_win()) NKA_SDPMW(NV, true, false); else NKA_SDPM(NV, 2, true, false); } while (0)
-#define L2NP(NV) do { if (use_win()) NKA_SDPMW(NV, false, true); else NKA_SDPM(NV, 2, false, true); } while (0)
-#define L2NN(NV) do { if (use_win()) NKA_SDPMW(NV, false, false); else NKA_SDPM(NV, 2, false, false); } while (0)
+#define LWSP(NV) NKA_SDPMW(NV, true, true)
+#define LWSN(NV) NKA_SDPMW(NV, true, false)
+#define LWNP(NV) NKA_SDPMW(NV, false, true)
+#define LWNN(NV) NKA_SDPMW(NV, false, false)
+#define L2SP(NV) NKA_SDPM(NV, 2, true, true)
+#define L2SN(NV) NKA_SDPM(NV, 2, true, false)
+#define L2NP(NV) NKA_SDPM(NV, 2, false, true)
+#define L2NN(NV) NKA_SDPM(NV, 2, false, false)
 #define L1SP(NV) NKA_SDPM(NV, 1, true, true)
 #define L1SN(NV) NKA_SDPM(NV, 1, true, false)
 #define L1NP(NV) NKA_SDPM(NV, 1, false, true)
 #define L1NN(NV) NKA_SDPM(NV, 1, false, false)
-    if (v2) {
+    if (win) {
+      if (subtract) { if (pre) { NKA_DISPATCH_EXACT(nv, LWSP) } else { NKA_DISPATCH_EXACT(nv, LWSN) } }
+      else          { if (pre) { NKA_DISPATCH_EXACT(nv, LWNP) } else { NKA_DISPATCH_EXACT(nv, LWNN) } }
+    } else if (v2) {
       if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L2SP) } else { NKA_DISPATCH_NV(nv, L2SN) } }
       else          { if (pre) { NKA_DISPATCH_NV(nv, L2NP) } else { NKA_DISPATCH_NV(nv, L2NN) } }
     } else {
       if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L1SP) } else { NKA_DISPATCH_NV(nv, L1SN) } }
       else          { if (pre) { NKA_DISPATCH_NV(nv, L1NP) } else { NKA_DISPATCH_NV(nv, L1NN) } }
     }
+#undef LWSP
+#undef LWSN
+#undef LWNP
+#undef LWNN
 #undef L2SP
 #undef L2SN
 #undef L2NP

@@ -127,7 +127,10 @@ def test_unaligned_operands_take_the_scalar_path(ws):
 
 
 @pytest.mark.parametrize("n,count,subtract", [(1, 0, 0), (513, 3, 1), (4099, 5, 0), (100003, 20, 0), (100003, 20, 1),
-                                              (777, 37, 1)])
+                                              (777, 37, 1), (1100003, 7, 0)] +
+                         # every unroll width of the rolling-window kernels (exact widths 1..24, ring sizes 1..23);
+                         # 300 007 elements = 586 tiles over 256 blocks: the window crosses tile boundaries
+                         [(300007, c, c % 2) for c in range(1, 25)])
 def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, subtract):
     """update_norm2, scale_dot_pair_many, update_many_keep, axpy_many_keep: stored
     vectors BIT-EXACT against the sequences of deferred-hook expressions they
