@@ -1,7 +1,3 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_vec_ops_gpu.py tests/test_fortran_front_end.py -m gpu -x -q 2>&1 | tail -4
-B=nka_amd/fortran/build
-for m in 5 10 20; do
-$B/nka_vector_driver bench 4 10000000 $m 30 0 | sed -n 2p
-NKA_HIP_VEC_WIN=0 $B/nka_vector_driver bench 4 10000000 $m 30 0 | sed -n 2p
-done
+timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "rc=$?"
+grep -n "passed\|failed\|error" gpurun_out/pytest_gpu.log | tail -5
