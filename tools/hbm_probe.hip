@@ -156,6 +156,89 @@ void runw(const char *name, const double *base, double *wbase, size_t stride, si
   fflush(stdout);
 }
 
+// The rolling window with T 16-byte loads per stream per thread and tile (tile = T x 512 doubles):
+// LAY 0: the T chunks of a thread are 4 KiB apart (each wave instruction covers 1 KiB, the block
+// T x 4 KiB contiguous); LAY 1: each WAVE covers T KiB contiguous (chunks 1 KiB apart).
+template <int S, int W, int WIN, int NTS, int T, int LAY>
+__global__ __launch_bounds__(256) void k_stream_winT(const double *base, double *wbase, size_t stride, size_t n, double *out) {
+  constexpr int R = S - 2;
+  static_assert(R % WIN == 0, "ring must divide the ringed streams");
+  const size_t ntile = n / (512 * T);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto off = [&](size_t t, int q) -> size_t {
+    return LAY ? t * (512 * T) + (size_t)wave * (128 * T) + q * 128 + lane * 2 : t * (512 * T) + q * 512 + threadIdx.x * 2;
+  };
+  double acc = 0.0;
+  double2 a0[T], a1[T], ring[WIN][T];
+  size_t t = blockIdx.x;
+  if (t < ntile) {
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      a0[q] = ld2<true>(base + off(t, q));
+      a1[q] = ld2<true>(base + stride + off(t, q));
+    }
+#pragma unroll
+    for (int j = 0; j < WIN; j++)
+#pragma unroll
+      for (int q = 0; q < T; q++) ring[j][q] = ld2<true>(base + (2 + j) * stride + off(t, q));
+  }
+  for (; t < ntile; t += gridDim.x) {
+    const size_t tn = (t + gridDim.x < ntile) ? t + gridDim.x : t;
+    double2 sum[T];
+#pragma unroll
+    for (int q = 0; q < T; q++) sum[q] = {a0[q].x + a1[q].x, a0[q].y + a1[q].y};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      a0[q] = ld2<true>(base + off(tn, q));
+      a1[q] = ld2<true>(base + stride + off(tn, q));
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      double2 x[T];
+#pragma unroll
+      for (int q = 0; q < T; q++) x[q] = ring[j % WIN][q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        if (j + WIN < R) ring[j % WIN][q] = ld2<true>(base + (2 + j + WIN) * stride + off(t, q));
+        else ring[j % WIN][q] = ld2<true>(base + (2 + j + WIN - R) * stride + off(tn, q));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < T; q++) { sum[q].x += x[q].x; sum[q].y += x[q].y; }
+    }
+#pragma unroll
+    for (int q = 0; q < T; q++) acc += sum[q].x + sum[q].y;
+#pragma unroll
+    for (int w = 0; w < W; w++)
+#pragma unroll
+      for (int q = 0; q < T; q++) st2<NTS>(wbase + w * stride + off(t, q), sum[q]);
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int S, int W, int WIN, int NTS, int T, int LAY>
+void runwT(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 3;
+  hipLaunchKernelGGL((k_stream_winT<S, W, WIN, NTS, T, LAY>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream_winT<S, W, WIN, NTS, T, LAY>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+}
+
 // Burst variant: each block reads B tiles of S streams, THEN writes B tiles of W streams.
 template <int S, int W, int B, int NTS>
 __global__ __launch_bounds__(256) void k_burst(const double *base, double *wbase, size_t stride, size_t n, double *out) {
@@ -340,6 +423,23 @@ int main(int argc, char **argv) {
         R(42, 5, 1, true, 1, 0, g);
         RW(42, 5, 4, 1, g); RW(42, 5, 8, 1, g); RW(42, 5, 10, 1, g);
         RW(22, 0, 4, 1, g);
+      }
+    return 0;
+  }
+#define RWT(S, W, WIN, NTS, T, LAY, G) runwT<S, W, WIN, NTS, T, LAY>("window S=" #S " W=" #W " WIN=" #WIN " T=" #T " lay=" #LAY, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 't') {   // wider tiles in the rolling window ("t" zeros, "tr" random)
+    for (int rep = 0; rep < 2; rep++)
+      for (int g : {cu * 1, cu / 2}) {
+        RW(22, 5, 4, 1, g);
+        RWT(22, 5, 4, 1, 1, 0, g);
+        RWT(22, 5, 2, 1, 2, 0, g); RWT(22, 5, 2, 1, 2, 1, g);
+        RWT(22, 5, 4, 1, 2, 0, g); RWT(22, 5, 4, 1, 2, 1, g);
+        RWT(22, 5, 2, 1, 4, 0, g); RWT(22, 5, 2, 1, 4, 1, g);
+        RWT(22, 5, 1, 1, 4, 1, g);
+        RW(42, 5, 4, 1, g);
+        RWT(42, 5, 4, 1, 2, 1, g); RWT(42, 5, 2, 1, 2, 1, g); RWT(42, 5, 2, 1, 4, 1, g);
+        RW(22, 0, 4, 1, g);
+        RWT(22, 0, 4, 1, 2, 1, g); RWT(22, 0, 2, 1, 2, 1, g); RWT(22, 0, 2, 1, 4, 1, g);
       }
     return 0;
   }
