@@ -277,6 +277,14 @@ constexpr int win_ring() {
   return MAXL % 4 == 0 ? 4 : MAXL % 5 == 0 ? 5 : MAXL % 6 == 0 ? 6 : MAXL % 3 == 0 ? 3 : MAXL % 7 == 0 ? 7 : MAXL;
 }
 
+// The flavours that stream TWO vectors per pair (F08, F08-vector) keep the same number of loads in
+// flight with half the ring: 2 pairs where the width is even (in-process A/B at m = 20: -3.5 % at
+// n = 1.25e7, equal at 1e8; the compact flavour loses 13 % with a ring of 2 single loads).
+template <int MAXK>
+constexpr int win_ring_pairs() {
+  return MAXK % 2 == 0 ? 2 : MAXK % 3 == 0 ? 3 : MAXK % 5 == 0 ? 5 : MAXK % 7 == 0 ? 7 : MAXK;
+}
+
 // instantiated for EVERY width 1..32 so that no list length needs padding
 int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc) {
 #define CASE(L) \
@@ -378,7 +386,7 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
 template <int COMB>
 int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) {
 #define CASE(K) \
-  case K: return launch_combine_win_1<K, COMB, win_ring<K>()>(a, f, bpc);
+  case K: return launch_combine_win_1<K, COMB, (COMB == 2 ? win_ring<K>() : win_ring_pairs<K>())>(a, f, bpc);
   switch (width) {
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
     CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
@@ -676,12 +684,15 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
 static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   const int maxk = (vec == 1) ? 4 : (comb_ub > kMaxPerPass ? kMaxPerPass : round_up4(comb_ub));
   const int npass = std::max(1, (comb_ub + maxk - 1) / maxk);
-  // Automatic choice (in-process A/B, profiles/r02/ab_inproc_window_matrix.txt): the rolling-window
-  // kernel (ring of 4 pairs, one block per CU) is as fast or faster than k_combine over n = 1e6..1e8,
-  // m = 5..20 (-2 % at n = 1e8 m = 20, -4 % at m = 5/10, -5 % at 1e7, -17 % at 1e6 m = 20; +2 % at
-  // 1e7 m = 20) and equals the 4-group pipeline for the two-vectors-per-pair flavours.
+  // Automatic choice (in-process A/B, profiles/r02/ab_inproc_window_matrix.txt).  Compact flavour
+  // (one vector per pair): the rolling-window kernel (ring of 4, one block per CU) is as fast or
+  // faster than k_combine over n = 1e6..1e8, m = 5..20 (-2 % at n = 1e8 m = 20, -7...-11 % at m = 5/10).
+  // Two-vector flavours (ring of 2 pairs): the window wins once the pass moves >~ 8 GB (n = 1e8:
+  // -2...-3 % at m = 10/20, n = 3e7 m = 20: -3 %) and loses below (n = 1e7: +3 % at m = 20, +12 % at
+  // m = 10), where k_combine's deeper queue hides the ramp at both ends of the launch.
   int pipe = a->pb_pipe;
-  if (pipe < 0) pipe = 201;
+  if (pipe < 0)
+    pipe = (a->flavor == NKA_HIP_FLAVOR_C || (double)a->n * (2.0 * comb_ub + 6.0) >= 1.0e9) ? 201 : 0;
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
     launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
     HIP_TRY(hipGetLastError());
