@@ -490,7 +490,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
   block_reduce_store<2 * NV + 1>(acc, partials, G);
 }
 
-template <int NV, bool PAIRS, int kWin = win_ring<NV>()>
+// two vectors per entry: half the ring keeps the same number of loads in flight (nka_hip.hip:win_ring_pairs)
+template <int NV>
+constexpr int win_ring_pairs() {
+  return NV % 2 == 0 ? 2 : NV % 3 == 0 ? 3 : NV % 5 == 0 ? 5 : NV % 7 == 0 ? 7 : NV;
+}
+
+template <int NV, bool PAIRS, int kWin = (PAIRS ? win_ring_pairs<NV>() : win_ring<NV>())>
 __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, double *z, ManyArgs m, double *keep_in,
                                                                  double *keep_out) {
   constexpr int VEC = 2;

@@ -1,2 +1,8 @@
-timeout 2000 python -m pytest tests/test_hip_parity.py tests/test_hip_round2.py tests/test_hip_fullsize.py tests/test_fortran_front_end.py -m gpu -x -q 2>&1 | grep "passed\|failed" | tail -3
-bash tools/sweep.sh f08 2>&1 | tail -16
+B=nka_amd/fortran/build
+for r in 1 2 3; do
+$B/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p
+NKA_HIP_VEC_PAIR_RING4=1 $B/nka_vector_driver bench 4 10000000 20 30 0 | sed -n 2p
+done
+$B/nka_vector_driver bench 4 2500000 20 30 0 | sed -n 2p
+NKA_HIP_VEC_PAIR_RING4=1 $B/nka_vector_driver bench 4 2500000 20 30 0 | sed -n 2p
+NKA_HIP_VEC_WIN=0 $B/nka_vector_driver bench 4 2500000 20 30 0 | sed -n 2p
