@@ -107,6 +107,41 @@ def test_fortran_device_resident_example_driver(args, key):
     assert p.stdout.splitlines() == tables[key]
 
 
+def _to_grid_layout(a):
+    """natural (ny+2, nx+2) array [k, j] -> device grid-vector layout (interior packed, then the ring:
+    row k=0, row k=ny+1, column j=0, column j=nx+1; include/nka_example_dev.h)."""
+    return np.concatenate([a[1:-1, 1:-1].ravel(), a[0, :], a[-1, :], a[1:-1, 0], a[1:-1, -1]])
+
+
+@pytest.mark.parametrize("nx,ny", [(50, 50), (37, 23), (3, 3), (5, 1100)])
+def test_grid_vector_layout_stencils_equal_the_natural_layout_ones(torch_cuda, nx, ny):
+    """nka_ex_residual_grid / nka_ex_pc_ssor_grid read the packed-ring layout of the
+    device grid vector: same bits as the natural-layout entry points on the same
+    values (ghosts random: the boundary terms are exercised), the ring of r left
+    alone by the residual and zeroed by the preconditioner."""
+    import nka_amd
+    torch, L = torch_cuda, nka_amd.load()
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rng = np.random.default_rng(nx * 1000 + ny)
+    u = rng.uniform(0.0, 1.0, (ny + 2, nx + 2))
+    ntot, n = (nx + 2) * (ny + 2), nx * ny
+    h = C.c_void_p()
+    assert L.nka_ex_create(C.byref(h), nx, ny, 0.02, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    u_nat = torch.from_numpy(u.ravel().copy()).cuda()
+    u_grid = torch.from_numpy(_to_grid_layout(u)).cuda()
+    r_nat = torch.zeros(n, dtype=torch.float64, device="cuda")
+    r_grid = torch.full((ntot,), 7.0, dtype=torch.float64, device="cuda")
+    assert L.nka_ex_residual(h, P(u_nat), P(r_nat)) == 0
+    assert L.nka_ex_residual_grid(h, P(u_grid), P(r_grid)) == 0
+    assert np.array_equal(r_grid[:n].cpu().numpy(), r_nat.cpu().numpy())
+    assert np.all(r_grid[n:].cpu().numpy() == 7.0)                       # ring untouched
+    assert L.nka_ex_pc_ssor(h, 2, 1.4, P(r_nat)) == 0
+    assert L.nka_ex_pc_ssor_grid(h, 2, 1.4, P(r_grid)) == 0
+    assert np.array_equal(r_grid[:n].cpu().numpy(), r_nat.cpu().numpy())
+    assert np.all(r_grid[n:].cpu().numpy() == 0.0)                       # r(:,:) = z, z = 0 on the ring
+    L.nka_ex_destroy(h)
+
+
 @pytest.mark.parametrize("args,key", [([], "f08vec"), (["--nka-vec", "5"], "f08vec --nka-vec 5"),
                                       (["--sweeps", "4", "--nka-vec", "5"], "f08vec --sweeps 4 --nka-vec 5")])
 def test_vector_flavour_device_resident_example_prints_the_reference_tables(args, key):
