@@ -163,6 +163,7 @@ struct nka_hip_state {
   Vecs vs{};
   Ctl ctl{};
   double *partials = nullptr;
+  unsigned *tickets = nullptr; // tile-ticket counters of the rolling-window PB (kTicketWords, zero between launches)
   double *f_stage = nullptr;  // device staging for the host-array entry point
   double *hd_scratch = nullptr;  // device vector for the operands of a user host dot product (set_host_dot)
   // what the host knows without reading the device back
@@ -175,6 +176,8 @@ struct nka_hip_state {
   int pa_pipe = -1;           // groups of the software-pipelined PA: 0 = k_dots, 2 or 4 = k_dots_pipe, -1 = automatic
   int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
                               // -1 = automatic (see enqueue_pb)
+  int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
+                              // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
   int solve_variant = 0;      // 0 = k_solve_wave2 (registers + masks), 1 = k_solve_wave (first version, LDS walks)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
@@ -379,7 +382,15 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   const int64_t ntile = a->n / (kBlock * 2);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
-  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
+  // Tile tickets (k_combine_win): in-process A/B and tools/hbm_probe agree that the compact front pays
+  // from a few tiles per block upwards (n = 1.25e7: +4...8 %, n = 1e8: +8...14 %); ONE counter while a
+  // tile carries >= 22 words per element (<= ~60 tickets/us), two below that (a single counter saturates).
+  constexpr int words = (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1) + 5;
+  int ng = a->pb_tickets;
+  if (ng < 0) ng = (ntile >= 16 * g) ? (words >= 22 ? 1 : 2) : 0;
+  if (ng > 0 && (g % ng != 0 || ntile >= (int64_t)1 << 31 || !a->tickets)) ng = 0;
+  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
+                     ng > 0 ? a->tickets : nullptr, std::max(ng, 1));
   return (int)g;
 }
 
@@ -489,6 +500,8 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
   a->pa_pipe = env_int("NKA_HIP_PA_PIPE", a->pa_pipe);
   a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
+  a->pb_tickets = env_int("NKA_HIP_PB_TICKETS", a->pb_tickets);
+  if (a->pb_tickets > 0 && a->pb_tickets != 1 && a->pb_tickets != 2 && a->pb_tickets != 4 && a->pb_tickets != 8) a->pb_tickets = -1;
   a->solve_variant = env_int("NKA_HIP_SOLVE_VARIANT", a->solve_variant);
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
@@ -529,12 +542,14 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   alloc((void **)&a->ctl.ic, sizeof(int32_t) * a->ctl.ic_count());
   alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
   alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 2));  // NACC columns of k_dots
+  alloc((void **)&a->tickets, sizeof(unsigned) * kTicketWords);
   if (rc) {
     nka_hip_destroy(a);
     return rc;
   }
   // zero the control blocks, set vtol, then the device-side restart (F08:198)
-  if (hipMemsetAsync(a->ctl.ic, 0, sizeof(int32_t) * a->ctl.ic_count(), a->stream) != hipSuccess ||
+  if (hipMemsetAsync(a->tickets, 0, sizeof(unsigned) * kTicketWords, a->stream) != hipSuccess ||
+      hipMemsetAsync(a->ctl.ic, 0, sizeof(int32_t) * a->ctl.ic_count(), a->stream) != hipSuccess ||
       hipMemsetAsync(a->ctl.dc, 0, sizeof(double) * a->ctl.dc_count(), a->stream) != hipSuccess ||
       hipMemcpyAsync(a->ctl.dc + DC_VTOL, &a->vtol, sizeof(double), hipMemcpyHostToDevice, a->stream) != hipSuccess) {
     nka_hip_destroy(a);
@@ -582,6 +597,7 @@ int nka_hip_destroy(nka_hip_t a) {
   hipFree(a->ctl.ic);
   hipFree(a->ctl.dc);
   hipFree(a->partials);
+  hipFree(a->tickets);
   hipFree(a->f_stage);
   hipFree(a->hd_scratch);
   for (auto &e : a->ev)
@@ -1153,6 +1169,10 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
       return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pa_pipe = value;
+  } else if (k == "pb_tickets") {
+    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
+    a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
   } else if (k == "solve_variant") {

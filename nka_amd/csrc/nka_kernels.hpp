@@ -760,13 +760,32 @@ __global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, doubl
 // re-loaded with pair j+W of this tile or pair j+W-MAXK of the block's next tile); f
 // and, with compact storage, the raw w of the pending pair are requested one tile ahead.
 // Same arithmetic in the same order => same bits as k_combine.  Single pass, VEC = 2.
+//
+// TILE TICKETS (`tickets` != nullptr).  With the static mapping (tile t -> block t mod G) the
+// blocks of a mixed read/write pass drift apart -- by 5 % of the launch, i.e. ~40 tiles, at
+// n = 1e8 -- and the chip then works on a ~40 MB window of each of the 27 streams at once.
+// tools/hbm_probe (modes d, e, g; profiles/r02/hbm_probe_tile_tickets.txt) shows the same
+// streams moving 8-14 % faster when every block takes its next tile from ONE global counter:
+// the blocks then advance as a compact front (all end within 5 us of each other) and the DRAMs
+// see one narrow window per stream.  A block's first two tiles are static (b, b + G); thread 0
+// requests the tile after next with a returning atomic at the top of an iteration, publishes it
+// in LDS at the end (one workgroup barrier per tile), so the atomic's latency hides behind a
+// whole tile.  `ng` counters (128 B apart), counter g serving the blocks with b % ng == g and
+// the tiles = g (mod ng): a single counter saturates near 60-75 tickets/us, which short lists
+// exceed.  The last block to finish resets the counters (a second counter, `done`), so a launch
+// always finds them zero.  Elementwise pass: which block handles a tile changes no bit.
+constexpr int kTicketStride = 32;                 // uint32 words between counters (128 B)
+constexpr int kTicketGroupsMax = 8;
+constexpr int kTicketWords = kTicketStride * (kTicketGroupsMax + 1);   // ng counters + `done`
+
 template <int MAXK, int COMB, int W>
-__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f) {
+__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng) {
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr bool RCP = (COMB == 1);
   constexpr bool COMPACT = (COMB == 2);
   static_assert(MAXK % W == 0, "the ring must divide the pairs of a tile");
+  __shared__ unsigned s_next[2];
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
   const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
@@ -803,9 +822,18 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
       rv[j] = ld<VEC>(vk[j] + e);
     }
   }
-  for (; t < ntile; t += G) {
+  // ticket counter of this block's group; ticket k of group g is tile (k + 2G/ng)*ng + g
+  const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
+  unsigned *const my_ticket = tickets ? tickets + grp * kTicketStride : nullptr;
+  const unsigned ticket_base = tickets ? 2u * (unsigned)G / (unsigned)ng : 0u;
+  int64_t tnext = t + G;
+  unsigned par = 0;
+  while (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const bool more = tnext < ntile;
+    unsigned claimed = 0xffffffffu;
+    if (tickets && more && threadIdx.x == 0) claimed = (atomicAdd(my_ticket, 1u) + ticket_base) * (unsigned)ng + grp;
+    const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
     const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
     const V fin = finv;
     V w0 = COMPACT ? w0v : fin;
@@ -849,6 +877,25 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     }
     st(vnew + e, x);
     st(f + e, x);
+    if (tickets) {
+      if (threadIdx.x == 0) s_next[par] = claimed;
+      __syncthreads();
+      const unsigned nx = s_next[par];
+      par ^= 1u;
+      t = tnext;
+      tnext = (nx == 0xffffffffu) ? ntile : (int64_t)nx;
+    } else {
+      t = tnext;
+      tnext += G;
+    }
+  }
+  if (tickets && threadIdx.x == 0) {
+    // every ticket request of this block has returned; the block that arrives last resets the counters
+    unsigned *const done = tickets + kTicketGroupsMax * kTicketStride;
+    if (atomicAdd(done, 1u) == (unsigned)G - 1u) {
+      for (int g = 0; g < ng; g++) atomicExch(tickets + g * kTicketStride, 0u);
+      atomicExch(done, 0u);
+    }
   }
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {

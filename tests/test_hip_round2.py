@@ -271,3 +271,45 @@ def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), settings
     with pytest.raises(nka_amd.NKAError):
         nka_amd.nka().init(16, 2).set_tuning("pa_pipe", 7)
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
+    """PB's rolling-window kernel can take its tiles from global ticket counters
+    (k_combine_win, `pb_tickets` = number of counters) instead of the static
+    tile -> block mapping.  The pass is elementwise, so which block handles a tile
+    must not change a bit -- and the counters must be back at zero after every
+    launch (a stale counter would skip tiles of the next update).  Several tiles
+    per block, ragged tail, list growth, drops, relax and restart included."""
+    import nka_amd
+    n, m = 256 * 512 * 5 + 77, 6
+    rng = np.random.default_rng(7 + flavor)
+    basis = rng.standard_normal((3, n))
+    X = [rng.standard_normal(3) @ basis if t % 5 == 3 else rng.standard_normal(n) for t in range(m + 8)]
+    X[m + 2] = X[m + 1].copy()                      # s == 0 -> relax inside the update
+
+    def run(tickets):
+        acc = nka_amd.nka().init(n, m, flavor=flavor)
+        acc.set_tuning("pb_pipe", 201)
+        acc.set_tuning("pb_tickets", tickets)
+        outs = []
+        for t, x in enumerate(X):
+            ft = torch_cuda.from_numpy(x.copy()).cuda()
+            acc.accel_update(ft)
+            outs.append(ft.cpu().numpy())
+            if t == m + 4:
+                acc.relax()
+            if t == m + 6:
+                acc.restart()
+        st = acc.state()
+        return outs, acc.state_digest(), acc.w(st.first), acc.v(st.first)
+
+    ref = run(0)
+    for tickets in (1, 2, 4, 8, -1):
+        got = run(tickets)
+        for t, (a, b) in enumerate(zip(ref[0], got[0])):
+            assert np.array_equal(a, b), (tickets, t, np.abs(a - b).max())
+        assert got[1] == ref[1], tickets
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), tickets
+    with pytest.raises(nka_amd.NKAError):
+        nka_amd.nka().init(16, 2).set_tuning("pb_tickets", 3)

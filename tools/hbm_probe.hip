@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -154,6 +155,210 @@ void runw(const char *name, const double *base, double *wbase, size_t stride, si
   const double bytes = (double)(S + W) * n * 8.0 * reps;
   printf("%-44s grid %5d  %8.1f GB/s  (%.3f ms/launch)\n", name, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
   fflush(stdout);
+}
+
+
+// ---- mode "d": does a STATIC tile->block mapping lose time in the tail? ----------------
+// The rolling-window kernel again, (a) with the start / end time of every block stamped
+// (wall_clock64, 100 MHz) so the spread of block end times can be read, (b) with DYNAMIC
+// chunk claiming: a block takes its first chunk by blockIdx and every further chunk of
+// `chunk_tiles` tiles from a global counter (claimed one chunk ahead by thread 0, so the
+// rolling window can prefetch across the chunk boundary; one workgroup barrier per chunk).
+template <int S, int W, int WIN, int NTS, bool DYN>
+__global__ __launch_bounds__(256) void k_stream_win_d(const double *base, double *wbase, size_t stride, size_t n, double *out,
+                                                      unsigned *counter, unsigned chunk_tiles, unsigned long long *stamps) {
+  constexpr int R = S - 2;
+  static_assert(R % WIN == 0, "ring must divide the ringed streams");
+  const size_t ntile = n / 512;
+  const unsigned nchunk = (unsigned)((ntile + chunk_tiles - 1) / chunk_tiles);
+  __shared__ unsigned s_next[2];
+  const unsigned long long t_start = wall_clock64();
+  double acc = 0.0;
+  double2 a0, a1, ring[WIN];
+  unsigned c = blockIdx.x, par = 0;
+  if (c < nchunk) {
+    const size_t t = (size_t)c * chunk_tiles;
+    a0 = ld2<true>(base + t * 512 + threadIdx.x * 2);
+    a1 = ld2<true>(base + stride + t * 512 + threadIdx.x * 2);
+#pragma unroll
+    for (int j = 0; j < WIN; j++) ring[j] = ld2<true>(base + (2 + j) * stride + t * 512 + threadIdx.x * 2);
+  }
+  while (c < nchunk) {
+    if (threadIdx.x == 0) s_next[par] = DYN ? atomicAdd(counter, 1u) : c + gridDim.x;
+    const size_t t0 = (size_t)c * chunk_tiles;
+    const size_t tend = (t0 + chunk_tiles < ntile) ? t0 + chunk_tiles : ntile;
+    unsigned cn = 0xffffffffu;
+    for (size_t t = t0; t < tend; ++t) {
+      size_t tn = t + 1;
+      if (tn >= tend) {                      // last tile of the chunk: learn the next chunk
+        __syncthreads();
+        cn = s_next[par];
+        tn = (cn < nchunk) ? (size_t)cn * chunk_tiles : t;
+      }
+      double2 sum = {a0.x + a1.x, a0.y + a1.y};
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = ld2<true>(base + tn * 512 + threadIdx.x * 2);
+      a1 = ld2<true>(base + stride + tn * 512 + threadIdx.x * 2);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const double2 x = ring[j % WIN];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + WIN < R) ring[j % WIN] = ld2<true>(base + (2 + j + WIN) * stride + t * 512 + threadIdx.x * 2);
+        else ring[j % WIN] = ld2<true>(base + (2 + j + WIN - R) * stride + tn * 512 + threadIdx.x * 2);
+        __builtin_amdgcn_sched_barrier(0);
+        sum.x += x.x; sum.y += x.y;
+      }
+      acc += sum.x + sum.y;
+#pragma unroll
+      for (int w = 0; w < W; w++) st2<NTS>(wbase + w * stride + t * 512 + threadIdx.x * 2, sum);
+    }
+    c = cn;
+    par ^= 1;
+  }
+  if (acc == 12345.678) out[0] = acc;
+  if (stamps && threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t_start;
+    stamps[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+template <int S, int W, int WIN, int NTS, bool DYN>
+void rund(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid, unsigned chunk_tiles) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 5;
+  unsigned *ctr;
+  unsigned long long *stamps;
+  CK(hipMalloc(&ctr, sizeof(unsigned) * (reps + 1)));
+  CK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * grid));
+  std::vector<unsigned> init(reps + 1, (unsigned)grid);
+  CK(hipMemcpy(ctr, init.data(), sizeof(unsigned) * (reps + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((k_stream_win_d<S, W, WIN, NTS, DYN>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + reps, chunk_tiles, stamps);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream_win_d<S, W, WIN, NTS, DYN>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + r, chunk_tiles, stamps);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * grid);
+  CK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+  unsigned long long s0 = ~0ull;
+  std::vector<double> ends(grid);
+  for (int b = 0; b < grid; b++) s0 = h[2 * b] < s0 ? h[2 * b] : s0;
+  for (int b = 0; b < grid; b++) ends[b] = (double)(h[2 * b + 1] - s0) * 0.01;   // us at 100 MHz
+  std::sort(ends.begin(), ends.end());
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-40s chunk %4u grid %4d  %8.1f GB/s  (%.4f ms/launch)  block ends us: min %.1f p50 %.1f p90 %.1f max %.1f\n", name, chunk_tiles, grid,
+         bytes / (ms * 1e-3) / 1e9, ms / reps, ends[0], ends[grid / 2], ends[grid * 9 / 10], ends[grid - 1]);
+  fflush(stdout);
+  CK(hipFree(ctr));
+  CK(hipFree(stamps));
+}
+
+// Dynamic claiming with the ticket requested ONE CHUNK AHEAD: chunks 0 and 1 of a block are static
+// (b, b + G); at the start of chunk i thread 0 requests the chunk after next (returning atomic, the
+// value stays in a register), publishes it in LDS at the END of the chunk, one barrier per chunk.
+// The atomic's latency hides behind a whole chunk of streaming.
+template <int S, int W, int WIN, int NTS>
+__global__ __launch_bounds__(256) void k_stream_win_d2(const double *base, double *wbase, size_t stride, size_t n, double *out,
+                                                       unsigned *counter, unsigned chunk_tiles, unsigned long long *stamps, unsigned ng) {
+  // ng counter groups (group = blockIdx % ng, one counter per group, 128 B apart): group g owns the chunks = g (mod ng)
+  constexpr int R = S - 2;
+  static_assert(R % WIN == 0, "ring must divide the ringed streams");
+  const size_t ntile = n / 512;
+  const unsigned nchunk = (unsigned)((ntile + chunk_tiles - 1) / chunk_tiles);
+  __shared__ unsigned s_next[2];
+  const unsigned long long t_start = wall_clock64();
+  double acc = 0.0;
+  double2 a0, a1, ring[WIN];
+  const unsigned grp = blockIdx.x % ng;
+  counter += grp * 32;
+  unsigned c = blockIdx.x, cn = blockIdx.x + gridDim.x, par = 0;
+  if (c < nchunk) {
+    const size_t t = (size_t)c * chunk_tiles;
+    a0 = ld2<true>(base + t * 512 + threadIdx.x * 2);
+    a1 = ld2<true>(base + stride + t * 512 + threadIdx.x * 2);
+#pragma unroll
+    for (int j = 0; j < WIN; j++) ring[j] = ld2<true>(base + (2 + j) * stride + t * 512 + threadIdx.x * 2);
+  }
+  while (c < nchunk) {
+    const bool claim = cn < nchunk;
+    unsigned tk = 0xffffffffu;
+    if (threadIdx.x == 0 && claim) tk = atomicAdd(counter, 1u) * ng + grp;   // a group's counter starts at 2G/ng
+    const size_t t0 = (size_t)c * chunk_tiles;
+    const size_t tend = (t0 + chunk_tiles < ntile) ? t0 + chunk_tiles : ntile;
+    for (size_t t = t0; t < tend; ++t) {
+      size_t tn = t + 1;
+      if (tn >= tend) tn = claim ? (size_t)cn * chunk_tiles : t;
+      double2 sum = {a0.x + a1.x, a0.y + a1.y};
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = ld2<true>(base + tn * 512 + threadIdx.x * 2);
+      a1 = ld2<true>(base + stride + tn * 512 + threadIdx.x * 2);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const double2 x = ring[j % WIN];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + WIN < R) ring[j % WIN] = ld2<true>(base + (2 + j + WIN) * stride + t * 512 + threadIdx.x * 2);
+        else ring[j % WIN] = ld2<true>(base + (2 + j + WIN - R) * stride + tn * 512 + threadIdx.x * 2);
+        __builtin_amdgcn_sched_barrier(0);
+        sum.x += x.x; sum.y += x.y;
+      }
+      acc += sum.x + sum.y;
+#pragma unroll
+      for (int w = 0; w < W; w++) st2<NTS>(wbase + w * stride + t * 512 + threadIdx.x * 2, sum);
+    }
+    if (threadIdx.x == 0) s_next[par] = tk;
+    __syncthreads();
+    c = cn;
+    cn = s_next[par];
+    par ^= 1;
+  }
+  if (acc == 12345.678) out[0] = acc;
+  if (stamps && threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t_start;
+    stamps[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+template <int S, int W, int WIN, int NTS>
+void rund2(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid, unsigned chunk_tiles, unsigned ng = 1) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 5;
+  const int CS = 32 * 16;     // counters of one launch: up to 16 groups, 128 B apart
+  unsigned *ctr;
+  unsigned long long *stamps;
+  CK(hipMalloc(&ctr, sizeof(unsigned) * CS * (reps + 1)));
+  CK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * grid));
+  std::vector<unsigned> init(CS * (reps + 1), (unsigned)(2 * grid / ng));
+  CK(hipMemcpy(ctr, init.data(), sizeof(unsigned) * init.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((k_stream_win_d2<S, W, WIN, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + reps * CS, chunk_tiles, stamps, ng);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream_win_d2<S, W, WIN, NTS>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + r * CS, chunk_tiles, stamps, ng);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * grid);
+  CK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+  unsigned long long s0 = ~0ull;
+  std::vector<double> ends(grid);
+  for (int b = 0; b < grid; b++) s0 = h[2 * b] < s0 ? h[2 * b] : s0;
+  for (int b = 0; b < grid; b++) ends[b] = (double)(h[2 * b + 1] - s0) * 0.01;
+  std::sort(ends.begin(), ends.end());
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-40s ng %2u chunk %4u grid %4d  %8.1f GB/s  (%.4f ms/launch)  block ends us: min %.1f p50 %.1f p90 %.1f max %.1f\n", name, ng, chunk_tiles, grid,
+         bytes / (ms * 1e-3) / 1e9, ms / reps, ends[0], ends[grid / 2], ends[grid * 9 / 10], ends[grid - 1]);
+  fflush(stdout);
+  CK(hipFree(ctr));
+  CK(hipFree(stamps));
 }
 
 // The rolling window with T 16-byte loads per stream per thread and tile (tile = T x 512 doubles):
@@ -424,6 +629,53 @@ int main(int argc, char **argv) {
         RW(42, 5, 4, 1, g); RW(42, 5, 8, 1, g); RW(42, 5, 10, 1, g);
         RW(22, 0, 4, 1, g);
       }
+    return 0;
+  }
+#define RD(S, W, WIN, NTS, DYN, G, CH) rund<S, W, WIN, NTS, DYN>("S=" #S " W=" #W " WIN=" #WIN " dyn=" #DYN, rd, wr, stride, n, out, G, CH)
+  if (argc > 3 && argv[3][0] == 'd') {   // static vs dynamic tile assignment, block end-time spread ("d" zeros, "dr" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 0, 4, 1, cu);
+      RD(22, 0, 4, 1, false, cu, 1); RD(22, 0, 4, 1, false, cu, 8);
+      RD(22, 0, 4, 1, true, cu, 1); RD(22, 0, 4, 1, true, cu, 4); RD(22, 0, 4, 1, true, cu, 16); RD(22, 0, 4, 1, true, cu, 64);
+      RW(22, 5, 4, 1, cu);
+      RD(22, 5, 4, 1, false, cu, 1);
+      RD(22, 5, 4, 1, true, cu, 1); RD(22, 5, 4, 1, true, cu, 4); RD(22, 5, 4, 1, true, cu, 16); RD(22, 5, 4, 1, true, cu, 64);
+      RW(42, 5, 4, 1, cu);
+      RD(42, 5, 4, 1, false, cu, 1);
+      RD(42, 5, 4, 1, true, cu, 4); RD(42, 5, 4, 1, true, cu, 16);
+    }
+    return 0;
+  }
+#define RD2(S, W, WIN, NTS, G, CH) rund2<S, W, WIN, NTS>("S=" #S " W=" #W " WIN=" #WIN " dyn=ahead", rd, wr, stride, n, out, G, CH)
+  if (argc > 3 && argv[3][0] == 'e') {   // dynamic claiming one chunk ahead ("e" zeros, "er" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 0, 4, 1, cu);
+      RD2(22, 0, 4, 1, cu, 1); RD2(22, 0, 4, 1, cu, 2); RD2(22, 0, 4, 1, cu, 4);
+      RW(22, 5, 4, 1, cu);
+      RD(22, 5, 4, 1, true, cu, 1);
+      RD2(22, 5, 4, 1, cu, 1); RD2(22, 5, 4, 1, cu, 2); RD2(22, 5, 4, 1, cu, 4); RD2(22, 5, 4, 1, cu * 2, 1);
+      RW(42, 5, 4, 1, cu);
+      RD(42, 5, 4, 1, true, cu, 1);
+      RD2(42, 5, 4, 1, cu, 1); RD2(42, 5, 4, 1, cu, 2); RD2(42, 5, 4, 1, cu, 4);
+      RW(12, 5, 2, 1, cu);
+      RD2(12, 5, 2, 1, cu, 1); RD2(12, 5, 2, 1, cu, 2);
+    }
+    return 0;
+  }
+#define RD3(S, W, WIN, NTS, G, CH, NG) rund2<S, W, WIN, NTS>("S=" #S " W=" #W " WIN=" #WIN " dyn=ahead", rd, wr, stride, n, out, G, CH, NG)
+  if (argc > 3 && argv[3][0] == 'g') {   // one ticket counter per group of blocks (blockIdx % ng) ("g" zeros, "gr" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 0, 4, 1, cu);
+      RD3(22, 0, 4, 1, cu, 1, 1); RD3(22, 0, 4, 1, cu, 1, 2); RD3(22, 0, 4, 1, cu, 1, 4); RD3(22, 0, 4, 1, cu, 1, 8); RD3(22, 0, 4, 1, cu, 1, 16);
+      RW(22, 5, 4, 1, cu);
+      RD3(22, 5, 4, 1, cu, 1, 1); RD3(22, 5, 4, 1, cu, 1, 2); RD3(22, 5, 4, 1, cu, 1, 4); RD3(22, 5, 4, 1, cu, 1, 8); RD3(22, 5, 4, 1, cu, 1, 16);
+      RW(42, 5, 4, 1, cu);
+      RD3(42, 5, 4, 1, cu, 1, 1); RD3(42, 5, 4, 1, cu, 1, 2); RD3(42, 5, 4, 1, cu, 1, 8);
+      RW(12, 5, 2, 1, cu);
+      RD3(12, 5, 2, 1, cu, 1, 1); RD3(12, 5, 2, 1, cu, 1, 2); RD3(12, 5, 2, 1, cu, 1, 8);
+      RW(7, 5, 1, 1, cu);
+      RD3(7, 5, 1, 1, cu, 1, 2); RD3(7, 5, 1, 1, cu, 1, 8);
+    }
     return 0;
   }
 #define RWT(S, W, WIN, NTS, T, LAY, G) runwT<S, W, WIN, NTS, T, LAY>("window S=" #S " W=" #W " WIN=" #WIN " T=" #T " lay=" #LAY, rd, wr, stride, n, out, G)
