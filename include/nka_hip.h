@@ -209,8 +209,13 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * NKA_HIP_PB_PIPE): -1 automatic (default); 0 = every load of a tile in flight
  * (k_dots / k_combine); 2, 4 = software-pipelined over that many load groups per
  * tile (k_dots_pipe / k_combine_pipe); 201..204 = rolling window (k_dots_win /
- * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.  "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave;
- * "serial_solve" = 0/1.  Results are bit-identical across variants. */
+ * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.
+ * "pb_tickets" (env NKA_HIP_PB_TICKETS): how the blocks of the rolling-window PB
+ * get their tiles: -1 automatic (default: tickets from 80 tiles per block), 0 =
+ * static mapping (tile t -> block t mod G), 1, 2, 4, 8 = from that many global
+ * ticket counters, so that the blocks advance as one compact front.
+ * "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave; "serial_solve" = 0/1.
+ * Results are bit-identical across variants. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,
@@ -230,6 +235,9 @@ int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
 int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
+/* A/B switch like nka_hip_set_tuning: "tickets" (env NKA_HIP_VEC_TICKETS) = -1 automatic, 0 static
+ * tile mapping, 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep). */
+int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value);
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
 int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);
 int nka_hip_vec_copy(nka_hip_vec_ws_t ws, int64_t n, double *dst, const double *src);          /* copy_   */

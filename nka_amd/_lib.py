@@ -51,6 +51,7 @@ SIGNATURES = {
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "nka_hip_vec_workspace_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_vec_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nka_hip_vec_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "nka_hip_vec_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_vec_copy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

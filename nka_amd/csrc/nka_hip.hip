@@ -382,13 +382,14 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   const int64_t ntile = a->n / (kBlock * 2);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
-  // Tile tickets (k_combine_win): in-process A/B and tools/hbm_probe agree that the compact front pays
-  // from a few tiles per block upwards (n = 1.25e7: +4...8 %, n = 1e8: +8...14 %); ONE counter while a
-  // tile carries >= 22 words per element (<= ~60 tickets/us), two below that (a single counter saturates).
+  // Tile tickets (k_combine_win), in-process A/B (profiles/r02/ab_inproc_tile_tickets.txt): PB -3...-10 %
+  // at n = 1e8 (the slower the box's static pass, the larger the gain), -2...-4 % at 1.25e7, nothing at
+  // 1e7, +3 % at 3e6 -> from 80 tiles per block.  ONE counter while a tile carries >= 22 words per
+  // element (<= ~60 tickets/us), two below that (a single counter saturates: m = 10 compact +16 %).
   constexpr int words = (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1) + 5;
   int ng = a->pb_tickets;
-  if (ng < 0) ng = (ntile >= 16 * g) ? (words >= 22 ? 1 : 2) : 0;
-  if (ng > 0 && (g % ng != 0 || ntile >= (int64_t)1 << 31 || !a->tickets)) ng = 0;
+  if (ng < 0) ng = (ntile >= 80 * g) ? (words >= 22 ? 1 : 2) : 0;
+  if (ng > 0 && (g % ng != 0 || ntile >= ((int64_t)1 << 31) - 2 * kMaxGrid || !a->tickets)) ng = 0;
   hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
                      ng > 0 ? a->tickets : nullptr, std::max(ng, 1));
   return (int)g;
@@ -703,12 +704,16 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   // Automatic choice (in-process A/B, profiles/r02/ab_inproc_window_matrix.txt).  Compact flavour
   // (one vector per pair): the rolling-window kernel (ring of 4, one block per CU) is as fast or
   // faster than k_combine over n = 1e6..1e8, m = 5..20 (-2 % at n = 1e8 m = 20, -7...-11 % at m = 5/10).
-  // Two-vector flavours (ring of 2 pairs): the window wins once the pass moves >~ 8 GB (n = 1e8:
-  // -2...-3 % at m = 10/20, n = 3e7 m = 20: -3 %) and loses below (n = 1e7: +3 % at m = 20, +12 % at
-  // m = 10), where k_combine's deeper queue hides the ramp at both ends of the launch.
+  // Two-vector flavours (ring of 2 pairs): with the static tile mapping the window wins only once the
+  // pass moves >~ 8 GB and loses below (n = 1e7: +3 % at m = 20, +12 % at m = 10), where k_combine's
+  // deeper queue hides the ramp at both ends of the launch; with tile tickets (taken from 80 tiles per
+  // block, launch_combine_win_1) it wins from there on: n = 1.25e7, m = 20: 0.782 vs 0.837 ms, n = 2.5e7:
+  // 1.540 vs 1.726 ms (profiles/r02/ab_inproc_tile_tickets.txt).
   int pipe = a->pb_pipe;
-  if (pipe < 0)
-    pipe = (a->flavor == NKA_HIP_FLAVOR_C || (double)a->n * (2.0 * comb_ub + 6.0) >= 1.0e9) ? 201 : 0;
+  if (pipe < 0) {
+    const bool tickets = a->pb_tickets != 0 && a->n / (kBlock * 2) >= (int64_t)80 * a->num_cu;
+    pipe = (a->flavor == NKA_HIP_FLAVOR_C || tickets || (double)a->n * (2.0 * comb_ub + 6.0) >= 1.0e9) ? 201 : 0;
+  }
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
     launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
     HIP_TRY(hipGetLastError());

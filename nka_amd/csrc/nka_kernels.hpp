@@ -777,6 +777,31 @@ __global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, doubl
 constexpr int kTicketStride = 32;                 // uint32 words between counters (128 B)
 constexpr int kTicketGroupsMax = 8;
 constexpr int kTicketWords = kTicketStride * (kTicketGroupsMax + 1);   // ng counters + `done`
+constexpr unsigned kNoTicket = 0xffffffffu;
+
+// thread 0: the tile after next of this block's group (returning atomic; the value is used a tile later)
+__device__ __forceinline__ unsigned ticket_request(unsigned *group_counter, unsigned base, unsigned ng, unsigned grp) {
+  return (atomicAdd(group_counter, 1u) + base) * ng + grp;
+}
+// end of a tile: thread 0 publishes what it was given, every thread learns the block's tile after next
+// (two LDS words used alternately: a word is rewritten only after another barrier)
+__device__ __forceinline__ int64_t ticket_publish(unsigned *s_next, unsigned &par, unsigned claimed, int64_t ntile) {
+  if (threadIdx.x == 0) s_next[par] = claimed;
+  __syncthreads();
+  const unsigned nx = s_next[par];
+  par ^= 1u;
+  return nx == kNoTicket ? ntile : (int64_t)nx;
+}
+// end of the kernel: every ticket request of this block has returned; the block that arrives last
+// resets the counters, so the next launch finds them zero
+__device__ __forceinline__ void ticket_finish(unsigned *tickets, int ng, int G) {
+  if (threadIdx.x != 0) return;
+  unsigned *const done = tickets + kTicketGroupsMax * kTicketStride;
+  if (atomicAdd(done, 1u) == (unsigned)G - 1u) {
+    for (int g = 0; g < ng; g++) atomicExch(tickets + g * kTicketStride, 0u);
+    atomicExch(done, 0u);
+  }
+}
 
 template <int MAXK, int COMB, int W>
 __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng) {
@@ -831,8 +856,8 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   while (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     const bool more = tnext < ntile;
-    unsigned claimed = 0xffffffffu;
-    if (tickets && more && threadIdx.x == 0) claimed = (atomicAdd(my_ticket, 1u) + ticket_base) * (unsigned)ng + grp;
+    unsigned claimed = kNoTicket;
+    if (tickets && more && threadIdx.x == 0) claimed = ticket_request(my_ticket, ticket_base, (unsigned)ng, grp);
     const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
     const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
     const V fin = finv;
@@ -877,26 +902,11 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     }
     st(vnew + e, x);
     st(f + e, x);
-    if (tickets) {
-      if (threadIdx.x == 0) s_next[par] = claimed;
-      __syncthreads();
-      const unsigned nx = s_next[par];
-      par ^= 1u;
-      t = tnext;
-      tnext = (nx == 0xffffffffu) ? ntile : (int64_t)nx;
-    } else {
-      t = tnext;
-      tnext += G;
-    }
+    const int64_t t2 = tickets ? ticket_publish(s_next, par, claimed, ntile) : tnext + G;
+    t = tnext;
+    tnext = t2;
   }
-  if (tickets && threadIdx.x == 0) {
-    // every ticket request of this block has returned; the block that arrives last resets the counters
-    unsigned *const done = tickets + kTicketGroupsMax * kTicketStride;
-    if (atomicAdd(done, 1u) == (unsigned)G - 1u) {
-      for (int g = 0; g < ng; g++) atomicExch(tickets + g * kTicketStride, 0u);
-      atomicExch(done, 0u);
-    }
-  }
+  if (tickets) ticket_finish(tickets, ng, G);
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fin = f[i];

@@ -32,6 +32,8 @@ struct nka_hip_vec_ws {
   hipStream_t stream = nullptr;
   int num_cu = 256;
   double *partials = nullptr;  // kMaxGrid
+  unsigned *tickets = nullptr; // tile-ticket counters of k_update_many_keep_win (kTicketWords, zero between launches)
+  int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning)
   double *host_result = nullptr;  // pinned
   double *host_results = nullptr; // pinned, 2*kManyMax+1 doubles
   double *host_result_dev = nullptr;   // device-side addresses of the two pinned buffers: the final-sum
@@ -498,10 +500,12 @@ constexpr int win_ring_pairs() {
 
 template <int NV, bool PAIRS, int kWin = (PAIRS ? win_ring_pairs<NV>() : win_ring<NV>())>
 __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, double *z, ManyArgs m, double *keep_in,
-                                                                 double *keep_out) {
+                                                                 double *keep_out, unsigned *tickets, int ng) {
+  // `tickets` != nullptr: tiles from global ticket counters (compact front), as in k_combine_win
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   static_assert(NV % kWin == 0, "the ring must divide the unroll width");
+  __shared__ unsigned s_next[2];
   const int G = gridDim.x;
   const double *xs[NV], *ys[PAIRS ? NV : 1];
 #pragma unroll
@@ -521,9 +525,17 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
       if (PAIRS) ry[j] = ld<VEC>(ys[j] + e);
     }
   }
-  for (; t < ntile; t += G) {
+  const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
+  unsigned *const my_ticket = tickets ? tickets + grp * kTicketStride : nullptr;
+  const unsigned ticket_base = tickets ? 2u * (unsigned)G / (unsigned)ng : 0u;
+  int64_t tnext = t + G;
+  unsigned par = 0;
+  while (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
+    const bool more = tnext < ntile;
+    unsigned claimed = kNoTicket;
+    if (tickets && more && threadIdx.x == 0) claimed = ticket_request(my_ticket, ticket_base, (unsigned)ng, grp);
+    const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
     const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
     V zv = znext;
     if (keep_in) st(keep_in + e, zv);
@@ -552,7 +564,11 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
     }
     if (keep_out) st(keep_out + e, zv);
     st(z + e, zv);
+    const int64_t t2 = tickets ? ticket_publish(s_next, par, claimed, ntile) : tnext + G;
+    t = tnext;
+    tnext = t2;
   }
+  if (tickets) ticket_finish(tickets, ng, G);
   if (blockIdx.x == G - 1)
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
       double zi = z[i];
@@ -583,6 +599,13 @@ bool use_win() {
     return !(e && e[0] == '0');
   }();
   return on;
+}
+
+// NKA_HIP_VEC_TICKETS: initial value of the workspace's `tickets` tunable (-1 automatic, 0 static, 1, 2, 4, 8)
+int ticket_groups_env() {
+  const char *e = getenv("NKA_HIP_VEC_TICKETS");
+  const int x = (e && *e) ? atoi(e) : -1;
+  return (x == 0 || x == 1 || x == 2 || x == 4 || x == 8) ? x : -1;
 }
 
 int width_for(int count) { return std::max(4, ((count + 3) / 4) * 4); }   // unroll width 4, 8, ..., kManyMax
@@ -667,7 +690,13 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     const bool win = v2 && use_win();
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernels: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
-#define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+    // tile tickets (k_combine_win): one counter while a tile carries >= 22 words per element, else two
+    const int words = (PAIRS ? 2 : 1) * nv + 1 + 1 + (kin ? 1 : 0) + (kout ? 1 : 0);
+    int ng = ws->ticket_groups;
+    if (ng < 0) ng = (win && n / (kBlock * 2) >= (int64_t)80 * g) ? (words >= 22 ? 1 : 2) : 0;
+    if (!win || !ws->tickets || g % std::max(ng, 1) != 0 || n / (kBlock * 2) >= ((int64_t)1 << 31) - 2 * kMaxGrid) ng = 0;
+    unsigned *const tix = ng > 0 ? ws->tickets : nullptr;
+#define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, tix, std::max(ng, 1))
 #define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
 #define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
     if (win) { NKA_DISPATCH_EXACT(nv, LAUNCHW) } else if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
@@ -693,10 +722,13 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   auto *ws = new nka_hip_vec_ws();
   ws->device = device;
   ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
+  ws->ticket_groups = ticket_groups_env();
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e == hipSuccess) ws->num_cu = prop.multiProcessorCount;
   if (e == hipSuccess) e = hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->tickets, sizeof(unsigned) * kTicketWords);
+  if (e == hipSuccess) e = hipMemset(ws->tickets, 0, sizeof(unsigned) * kTicketWords);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_result_dev, ws->host_result, 0);
@@ -716,10 +748,22 @@ int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   hipSetDevice(ws->device);
   hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
+  hipFree(ws->tickets);
   hipHostFree(ws->host_result);
   hipHostFree(ws->host_results);
   delete ws;
   return 0;
+}
+
+int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value) {
+  if (!ws || !key) return nka_detail::set_error(NKA_HIP_EINVAL, "null argument");
+  if (std::string(key) == "tickets") {
+    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return nka_detail::set_error(NKA_HIP_EINVAL, "tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
+    ws->ticket_groups = value;
+    return 0;
+  }
+  return nka_detail::set_error(NKA_HIP_EINVAL, std::string("unknown tuning key: ") + key);
 }
 
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev) {

@@ -182,7 +182,10 @@ def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, s
     Xd = [_dev(torch, X[j]) for j in range(count)]
     xs = (C.c_void_p * max(count, 1))(*[t.data_ptr() for t in Xd])
     ca, cb = rng.standard_normal(max(count, 1)), rng.standard_normal(max(count, 1))
-    for pairs in (True, False):
+    # (the combine stage also with its tiles taken from 1, 2 or 8 global ticket counters: same bits,
+    #  and the counters are back at zero for the launch that follows)
+    for pairs, tickets in [(True, -1), (False, -1)] + ([(True, 1), (False, 2), (True, 8), (False, 1), (True, -1)] if n >= 300007 else []):
+        assert L.nka_hip_vec_set_tuning(h, b"tickets", tickets) == 0
         zd = _dev(torch, f)
         kin = torch.zeros(n, dtype=torch.float64, device="cuda")
         kout = torch.zeros(n, dtype=torch.float64, device="cuda")

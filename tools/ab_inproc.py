@@ -18,6 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--key", default="pb_pipe")
     ap.add_argument("--values", type=int, nargs="+", default=[0, 2, 4])
+    ap.add_argument("--combos", nargs="+", default=None,
+                    help="variants as key=value[,key=value...] (overrides --key/--values), e.g. pb_tickets=1,pb_store=0")
     ap.add_argument("--flavor", default="f08", choices=["f08", "c", "f08vec"])
     ap.add_argument("--vlen", type=float, default=1e8)
     ap.add_argument("--mvec", type=int, default=20)
@@ -40,12 +42,20 @@ def main():
         acc.accel_update(pool[t % P, :n])
         t += 1
     assert acc.num_vec() == m
+    if a.combos:
+        a.values = a.combos
+        a.key = "combo"
     res = {v: {"PA": [], "PB": [], "all": []} for v in a.values}
     acc.set_timing(a.steps)
     for r in range(a.rounds):
         order = a.values if r % 2 == 0 else list(reversed(a.values))
         for v in order:
-            acc.set_tuning(a.key, v)
+            if a.combos:
+                for kv in v.split(","):
+                    k_, v_ = kv.split("=")
+                    acc.set_tuning(k_, int(v_))
+            else:
+                acc.set_tuning(a.key, v)
             for _ in range(a.steps):
                 synth.fill_torch(pool[t % P, :n], 12345, t, 0, n)
                 acc.accel_update(pool[t % P, :n])

@@ -25,8 +25,13 @@ typedef double nd2 __attribute__((ext_vector_type(2)));
 // store policy: 0 plain, 1 nt (builtin), 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
 template <int POL> __device__ __forceinline__ void st2(double *p, double2 v) {
   if (POL == 1) {
-    __builtin_nontemporal_store(v.x, p);
-    __builtin_nontemporal_store(v.y, p + 1);
+    nd2 q = {v.x, v.y};
+    __builtin_nontemporal_store(q, reinterpret_cast<nd2 *>(p));   // one global_store_dwordx4 ... nt (two scalar nt stores merge into a PLAIN x4)
+  } else if (POL == 5) {   // sc1 as a compiler-issued buffer store (counted by its s_waitcnt bookkeeping)
+    typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+    nd2 q = {v.x, v.y};
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p, 0, 16, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu4, q), r, 0, 0, 16);
   } else if (POL == 2) {
     nd2 q = {v.x, v.y};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
@@ -444,6 +449,107 @@ void runwT(const char *name, const double *base, double *wbase, size_t stride, s
   fflush(stdout);
 }
 
+// Rolling window + wide tiles + tile tickets (one tile per ticket, requested one tile ahead).
+template <int S, int W, int WIN, int NTS, int T, int LAY>
+__global__ __launch_bounds__(256) void k_stream_tix(const double *base, double *wbase, size_t stride, size_t n, double *out,
+                                                    unsigned *counter, unsigned ng) {
+  constexpr int R = S - 2;
+  static_assert(R % WIN == 0, "ring must divide the ringed streams");
+  const size_t ntile = n / (512 * T);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto off = [&](size_t t, int q) -> size_t {
+    return LAY ? t * (512 * T) + (size_t)wave * (128 * T) + q * 128 + lane * 2 : t * (512 * T) + q * 512 + threadIdx.x * 2;
+  };
+  __shared__ unsigned s_next[2];
+  const unsigned grp = blockIdx.x % ng;
+  counter += grp * 32;
+  double acc = 0.0;
+  double2 a0[T], a1[T], ring[WIN][T];
+  size_t t = blockIdx.x, tnext = t + gridDim.x;
+  unsigned par = 0;
+  if (t < ntile) {
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      a0[q] = ld2<true>(base + off(t, q));
+      a1[q] = ld2<true>(base + stride + off(t, q));
+    }
+#pragma unroll
+    for (int j = 0; j < WIN; j++)
+#pragma unroll
+      for (int q = 0; q < T; q++) ring[j][q] = ld2<true>(base + (2 + j) * stride + off(t, q));
+  }
+  while (t < ntile) {
+    const bool more = tnext < ntile;
+    unsigned tk = 0xffffffffu;
+    if (threadIdx.x == 0 && more) tk = atomicAdd(counter, 1u) * ng + grp;   // a group's counter starts at 2G/ng
+    const size_t tn = more ? tnext : t;
+    double2 sum[T];
+#pragma unroll
+    for (int q = 0; q < T; q++) sum[q] = {a0[q].x + a1[q].x, a0[q].y + a1[q].y};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      a0[q] = ld2<true>(base + off(tn, q));
+      a1[q] = ld2<true>(base + stride + off(tn, q));
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      double2 x[T];
+#pragma unroll
+      for (int q = 0; q < T; q++) x[q] = ring[j % WIN][q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        if (j + WIN < R) ring[j % WIN][q] = ld2<true>(base + (2 + j + WIN) * stride + off(t, q));
+        else ring[j % WIN][q] = ld2<true>(base + (2 + j + WIN - R) * stride + off(tn, q));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < T; q++) { sum[q].x += x[q].x; sum[q].y += x[q].y; }
+    }
+#pragma unroll
+    for (int q = 0; q < T; q++) acc += sum[q].x + sum[q].y;
+#pragma unroll
+    for (int w = 0; w < W; w++)
+#pragma unroll
+      for (int q = 0; q < T; q++) st2<NTS>(wbase + w * stride + off(t, q), sum[q]);
+    if (threadIdx.x == 0) s_next[par] = tk;
+    __syncthreads();
+    const unsigned nx = s_next[par];
+    par ^= 1;
+    t = tnext;
+    tnext = nx == 0xffffffffu ? ntile : nx;
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int S, int W, int WIN, int NTS, int T, int LAY>
+void runtix(const char *name, const double *base, double *wbase, size_t stride, size_t n, double *out, int grid, unsigned ng) {
+  static_assert(S <= 42 && W <= 6, "variant exceeds the allocated slots");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 5;
+  const int CS = 32 * 16;
+  unsigned *ctr;
+  CK(hipMalloc(&ctr, sizeof(unsigned) * CS * (reps + 1)));
+  std::vector<unsigned> init(CS * (reps + 1), (unsigned)(2 * grid / ng));
+  CK(hipMemcpy(ctr, init.data(), sizeof(unsigned) * init.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((k_stream_tix<S, W, WIN, NTS, T, LAY>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + reps * CS, ng);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL((k_stream_tix<S, W, WIN, NTS, T, LAY>), dim3(grid), dim3(256), 0, 0, base, wbase, stride, n, out, ctr + r * CS, ng);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)(S + W) * n * 8.0 * reps;
+  printf("%-52s ng %u grid %4d  %8.1f GB/s  (%.4f ms/launch)\n", name, ng, grid, bytes / (ms * 1e-3) / 1e9, ms / reps);
+  fflush(stdout);
+  CK(hipFree(ctr));
+}
+
 // Burst variant: each block reads B tiles of S streams, THEN writes B tiles of W streams.
 template <int S, int W, int B, int NTS>
 __global__ __launch_bounds__(256) void k_burst(const double *base, double *wbase, size_t stride, size_t n, double *out) {
@@ -678,7 +784,56 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+#define RT(S, W, WIN, NTS, T, LAY, G, NG) runtix<S, W, WIN, NTS, T, LAY>("tickets S=" #S " W=" #W " WIN=" #WIN " st=" #NTS " T=" #T " lay=" #LAY, rd, wr, stride, n, out, G, NG)
+  if (argc > 3 && argv[3][0] == 'h') {   // tile tickets x store policy x ring depth x tile width ("h" zeros, "hr" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 5, 4, 1, cu);
+      RT(22, 5, 4, 1, 1, 0, cu, 1);
+      RT(22, 5, 4, 0, 1, 0, cu, 1); RT(22, 5, 4, 2, 1, 0, cu, 1); RT(22, 5, 4, 3, 1, 0, cu, 1); RT(22, 5, 4, 4, 1, 0, cu, 1);
+      RT(22, 5, 2, 1, 1, 0, cu, 1); RT(22, 5, 5, 1, 1, 0, cu, 1); RT(22, 5, 10, 1, 1, 0, cu, 1);
+      RT(22, 5, 4, 1, 2, 0, cu, 1); RT(22, 5, 4, 1, 2, 1, cu, 1); RT(22, 5, 2, 1, 2, 0, cu, 1); RT(22, 5, 2, 1, 2, 1, cu, 1);
+      RT(22, 5, 2, 1, 4, 1, cu, 1); RT(22, 5, 1, 1, 4, 1, cu, 1);
+      RT(22, 5, 4, 1, 1, 0, cu / 2, 1); RT(22, 5, 4, 1, 2, 1, cu / 2, 1);
+      RW(42, 5, 4, 1, cu);
+      RT(42, 5, 4, 1, 1, 0, cu, 1); RT(42, 5, 2, 1, 1, 0, cu, 1); RT(42, 5, 8, 1, 1, 0, cu, 1); RT(42, 5, 4, 1, 2, 1, cu, 1); RT(42, 5, 2, 1, 2, 1, cu, 1);
+      RW(12, 5, 2, 1, cu);
+      RT(12, 5, 2, 1, 1, 0, cu, 2); RT(12, 5, 2, 1, 2, 1, cu, 1); RT(12, 5, 2, 1, 2, 0, cu, 1); RT(12, 5, 5, 1, 2, 1, cu, 1);
+      RW(7, 5, 1, 1, cu);
+      RT(7, 5, 1, 1, 1, 0, cu, 2); RT(7, 5, 1, 1, 2, 1, cu, 1); RT(7, 5, 5, 1, 2, 1, cu, 1); RT(7, 5, 5, 1, 4, 1, cu, 1);
+    }
+    return 0;
+  }
 #define RWT(S, W, WIN, NTS, T, LAY, G) runwT<S, W, WIN, NTS, T, LAY>("window S=" #S " W=" #W " WIN=" #WIN " T=" #T " lay=" #LAY, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 'j') {   // tile tickets: true nt vs plain vs sc1 stores ("j" zeros, "jr" random)
+    for (int rep = 0; rep < 3; rep++) {
+      RW(22, 5, 4, 0, cu); RW(22, 5, 4, 1, cu); RW(22, 5, 4, 2, cu);
+      RT(22, 5, 4, 0, 1, 0, cu, 1); RT(22, 5, 4, 1, 1, 0, cu, 1); RT(22, 5, 4, 2, 1, 0, cu, 1); RT(22, 5, 4, 3, 1, 0, cu, 1); RT(22, 5, 4, 5, 1, 0, cu, 1);
+      RW(42, 5, 4, 1, cu);
+      RT(42, 5, 4, 0, 1, 0, cu, 1); RT(42, 5, 4, 1, 1, 0, cu, 1); RT(42, 5, 4, 2, 1, 0, cu, 1);
+      RW(12, 5, 2, 1, cu);
+      RT(12, 5, 2, 1, 2, 1, cu, 1); RT(12, 5, 2, 2, 2, 1, cu, 1); RT(12, 5, 2, 1, 1, 0, cu, 2); RT(12, 5, 2, 2, 1, 0, cu, 2);
+    }
+    return 0;
+  }
+  if (argc > 3 && argv[3][0] == 'i') {   // tile tickets + write-through stores x tile width x ring ("i" zeros, "ir" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 5, 4, 1, cu); RW(22, 5, 4, 2, cu); RWT(22, 5, 4, 2, 2, 1, cu);
+      RT(22, 5, 4, 1, 1, 0, cu, 1);
+      RT(22, 5, 4, 2, 1, 0, cu, 1); RT(22, 5, 5, 2, 1, 0, cu, 1); RT(22, 5, 10, 2, 1, 0, cu, 1);
+      RT(22, 5, 4, 2, 2, 1, cu, 1); RT(22, 5, 2, 2, 2, 1, cu, 1); RT(22, 5, 4, 2, 2, 0, cu, 1); RT(22, 5, 2, 2, 2, 0, cu, 1);
+      RT(22, 5, 2, 2, 4, 1, cu, 1);
+      RT(22, 5, 4, 2, 1, 0, cu, 2); RT(22, 5, 4, 2, 2, 1, cu, 2);
+      RW(42, 5, 4, 1, cu); RW(42, 5, 4, 2, cu);
+      RT(42, 5, 4, 2, 1, 0, cu, 1); RT(42, 5, 8, 2, 1, 0, cu, 1); RT(42, 5, 4, 2, 2, 1, cu, 1); RT(42, 5, 2, 2, 2, 1, cu, 1);
+      RW(12, 5, 2, 1, cu);
+      RT(12, 5, 2, 2, 2, 1, cu, 1); RT(12, 5, 5, 2, 2, 1, cu, 1); RT(12, 5, 2, 2, 1, 0, cu, 2); RT(12, 5, 2, 2, 4, 1, cu, 1);
+      RW(7, 5, 1, 1, cu);
+      RT(7, 5, 1, 2, 2, 1, cu, 1); RT(7, 5, 5, 2, 2, 1, cu, 1); RT(7, 5, 1, 2, 1, 0, cu, 2); RT(7, 5, 5, 2, 4, 1, cu, 1);
+      RW(4, 5, 1, 1, cu);
+      RT(4, 5, 2, 2, 2, 1, cu, 1); RT(4, 5, 2, 2, 4, 1, cu, 1);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 't') {   // wider tiles in the rolling window ("t" zeros, "tr" random)
     for (int rep = 0; rep < 2; rep++)
       for (int g : {cu * 1, cu / 2}) {
