@@ -215,7 +215,10 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * static mapping (tile t -> block t mod G), 1, 2, 4, 8 = from that many global
  * ticket counters, so that the blocks advance as one compact front.
  * "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave; "serial_solve" = 0/1.
- * Results are bit-identical across variants. */
+ * Results are bit-identical across variants.
+ * "timing_stride" = s (1..1024): with nka_hip_set_timing on, record the events of every
+ * s-th update only (the first one after the call included): four event records widen
+ * the kernel boundaries of an update by ~15 us, which matters below n ~ 1e7. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,

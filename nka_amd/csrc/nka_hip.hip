@@ -192,6 +192,9 @@ struct nka_hip_state {
   // kTimingEvents events per update, in a ring of timing_cap updates
   int timing_cap = 0;
   int64_t timing_count = 0;   // updates recorded since set_timing
+  int timing_stride = 1;      // record the events of every stride-th update only (tuning key "timing_stride"):
+  int64_t update_seq = 0;     // four event records widen the kernel boundaries of an update by ~15 us
+  bool timing_this = false;   // the update in progress is a recorded one
   std::vector<hipEvent_t> ev;
 };
 
@@ -455,7 +458,8 @@ static_assert(lst_smem_bytes(kMaxMvec) <= kMaxDynamicLds && lst_smem_bytes(kMaxM
               "kMaxMvec out of step with lst_smem_bytes");
 
 int record(nka_hip_state *a, int i) {
-  if (a->timing_cap <= 0) return 0;
+  if (i == 0) a->timing_this = a->timing_cap > 0 && (a->update_seq++ % a->timing_stride) == 0;
+  if (!a->timing_this) return 0;
   const int slot = (int)(a->timing_count % a->timing_cap);
   HIP_TRY(hipEventRecord(a->ev[(size_t)slot * kTimingEvents + i], a->stream));
   return 0;
@@ -853,7 +857,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = enqueue_pb(a, f, vec, comb_ub)) return rc;
   if (int rc = record(a, 3)) return rc;
 
-  if (a->timing_cap > 0) a->timing_count++;
+  if (a->timing_this) a->timing_count++;
   a->list_ub = comb_ub + 1;
   a->pending = true;
   return 0;
@@ -1109,6 +1113,7 @@ int nka_hip_set_timing(nka_hip_t a, int32_t capacity) {
   for (auto &e : a->ev) HIP_TRY(hipEventCreate(&e));
   a->timing_cap = capacity;
   a->timing_count = 0;
+  a->update_seq = 0;
   return 0;
 }
 
@@ -1174,6 +1179,10 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
       return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pa_pipe = value;
+  } else if (k == "timing_stride") {
+    if (value < 1 || value > 1024) return fail(NKA_HIP_EINVAL, "timing_stride: 1..1024");
+    a->timing_stride = value;
+    a->update_seq = 0;
   } else if (k == "pb_tickets") {
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
