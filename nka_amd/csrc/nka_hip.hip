@@ -398,8 +398,17 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   return (int)g;
 }
 
+// does the automatic rule hand out the tiles of this accelerator's PB by tickets? (see launch_combine_win_1)
+bool pb_tickets_apply(const nka_hip_state *a) {
+  return a->pb_tickets != 0 && a->tickets && a->n / (kBlock * 2) >= (int64_t)80 * a->num_cu;
+}
+
 template <int COMB>
 int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) {
+  // One vector per pair, tiles by tickets: a ring of 5 beats the ring of 4 (in-process A/B at m = 20:
+  // 3.351 vs 3.406 ms at n = 1e8, 0.435 vs 0.442 at 1.25e7; ring of 10: 3.340 / 0.437), while the static
+  // mapping prefers 4 (n = 1e7: 0.359 vs 0.366 ms).  Among the widths 1..32 only 20 has both divisors.
+  if (COMB == 2 && width == 20 && pb_tickets_apply(a)) return launch_combine_win_1<20, 2, 5>(a, f, bpc);
 #define CASE(K) \
   case K: return launch_combine_win_1<K, COMB, (COMB == 2 ? win_ring<K>() : win_ring_pairs<K>())>(a, f, bpc);
   switch (width) {
@@ -715,7 +724,7 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   // 1.540 vs 1.726 ms (profiles/r02/ab_inproc_tile_tickets.txt).
   int pipe = a->pb_pipe;
   if (pipe < 0) {
-    const bool tickets = a->pb_tickets != 0 && a->n / (kBlock * 2) >= (int64_t)80 * a->num_cu;
+    const bool tickets = pb_tickets_apply(a);
     pipe = (a->flavor == NKA_HIP_FLAVOR_C || tickets || (double)a->n * (2.0 * comb_ub + 6.0) >= 1.0e9) ? 201 : 0;
   }
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
