@@ -19,7 +19,7 @@ for N in $NS; do
 import csv, glob, json, re, sys
 out, n = sys.argv[1], sys.argv[2]
 try:
-    d = json.loads(open(out + "/bench.log").read().strip().splitlines()[-1])
+    d = json.loads([ln for ln in open(out + "/bench.log").read().splitlines() if ln.startswith("{")][-1])
     k = d["roofline"]["kernels"]
     print(f"# n={n}: bench under trace: {d['value']:.0f} updates/s, {1e3*d['ms_per_step']:.1f} us/update (wall); HIP-event phases "
           f"PA {1e3*k['PA_k_dots']['mean_ms']:.1f} solve {1e3*k['k_solve']['mean_ms']:.1f} PB {1e3*k['PB_k_combine']['mean_ms']:.1f} us")
