@@ -25,6 +25,7 @@ pass ea_level    TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_REQ_sum TCC
 pass tcp_lat     TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum
 pass sq_wait     SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL
 pass grbm        GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum
+pass utcl1       TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum
 mkdir -p "$ROOT/gpurun_out/profiles_$TAG"
 python3 "$ROOT/tools/pmc_memsys_summary.py" "$OUT" > "$ROOT/gpurun_out/profiles_$TAG/memsys_counters_$FL.txt"
 cat "$ROOT/gpurun_out/profiles_$TAG/memsys_counters_$FL.txt"
