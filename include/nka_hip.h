@@ -211,9 +211,11 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * tile (k_dots_pipe / k_combine_pipe); 201..204 = rolling window (k_dots_win /
  * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.
  * "pb_tickets" (env NKA_HIP_PB_TICKETS): how the blocks of the rolling-window PB
- * get their tiles: -1 automatic (default: tickets from 80 tiles per block), 0 =
+ * get their tiles: -1 automatic (default: tickets from 64 tiles per block), 0 =
  * static mapping (tile t -> block t mod G), 1, 2, 4, 8 = from that many global
  * ticket counters, so that the blocks advance as one compact front.
+ * "pb_tile" (-1 automatic, 1, 2): 512- or 1024-element tiles for the shortest lists (<= 14 words
+ * per element and tile), where double-width tiles let one ticket counter serve the pass.
  * "solve_variant": 0 = k_solve_wave2, 1 = k_solve_wave; "serial_solve" = 0/1.
  * Results are bit-identical across variants.
  * "timing_stride" = s (1..1024): with nka_hip_set_timing on, record the events of every

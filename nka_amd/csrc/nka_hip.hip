@@ -176,6 +176,8 @@ struct nka_hip_state {
   int pa_pipe = -1;           // groups of the software-pipelined PA: 0 = k_dots, 2 or 4 = k_dots_pipe, -1 = automatic
   int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
                               // -1 = automatic (see enqueue_pb)
+  int pb_tile = -1;           // tile width of the rolling-window PB for short lists: -1 automatic (double-width tiles
+                              // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
   int solve_variant = 0;      // 0 = k_solve_wave2 (registers + masks), 1 = k_solve_wave (first version, LDS walks)
@@ -378,29 +380,45 @@ int launch_combine_pipe(int pipe, int flavor, int maxk, const nka_hip_state *a, 
   }
 }
 
-// rolling-window PB: ring of W pairs, `bpc` blocks per CU; every width 1..32 (no padding)
-template <int MAXK, int COMB, int W>
+// rolling-window PB: ring of W pairs, `bpc` blocks per CU; every width 1..32 (no padding);
+// T = 16-byte pieces per thread, stream and tile (2 only for short lists, see launch_combine_win_k)
+template <int MAXK, int COMB, int W, int T = 1>
 int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
-  static const int occ = occupancy_of(k_combine_win<MAXK, COMB, W>);
-  const int64_t ntile = a->n / (kBlock * 2);
+  static const int occ = occupancy_of(k_combine_win<MAXK, COMB, W, T>);
+  const int64_t ntile = a->n / (kBlock * 2 * T);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
   // Tile tickets (k_combine_win), in-process A/B (profiles/r02/ab_inproc_tile_tickets.txt): PB -3...-10 %
-  // at n = 1e8 (the slower the box's static pass, the larger the gain), -2...-4 % at 1.25e7, nothing at
-  // 1e7, +3 % at 3e6 -> from 80 tiles per block.  ONE counter while a tile carries >= 22 words per
-  // element (<= ~60 tickets/us), two below that (a single counter saturates: m = 10 compact +16 %).
-  constexpr int words = (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1) + 5;
+  // at n = 1e8 (the slower the box's static pass, the larger the gain), -2...-4 % at 1.25e7, 0 (m = 20) to
+  // -10 % (m = 10) at 1e7, +3 % at 3e6 -> from 64 tiles of 512 elements per block.  ONE counter while a tile carries >= 22
+  // words per element and 512 elements (<= ~60 tickets/us), two below that (a single counter saturates).
+  constexpr int words = ((COMB == 2 ? MAXK + 2 : 2 * MAXK + 1) + 5) * T;
   int ng = a->pb_tickets;
-  if (ng < 0) ng = (ntile >= 80 * g) ? (words >= 22 ? 1 : 2) : 0;
+  if (ng < 0) ng = (ntile * T >= 64 * g) ? (words >= 22 ? 1 : 2) : 0;
   if (ng > 0 && (g % ng != 0 || ntile >= ((int64_t)1 << 31) - 2 * kMaxGrid || !a->tickets)) ng = 0;
-  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
+  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W, T>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
                      ng > 0 ? a->tickets : nullptr, std::max(ng, 1));
   return (int)g;
 }
 
 // does the automatic rule hand out the tiles of this accelerator's PB by tickets? (see launch_combine_win_1)
 bool pb_tickets_apply(const nka_hip_state *a) {
-  return a->pb_tickets != 0 && a->tickets && a->n / (kBlock * 2) >= (int64_t)80 * a->num_cu;
+  return a->pb_tickets != 0 && a->tickets && a->n / (kBlock * 2) >= (int64_t)64 * a->num_cu;
+}
+
+// One width: the shortest lists (a 512-element tile carries <= 14 words per element) exist with
+// double-width tiles too, so that under tickets ONE counter serves them: in-process A/B at n = 1e8,
+// compact m = 5 (12 words): 1.511 ms against 1.643 with 512-element tiles and two counters (static
+// 1.733); from m = 10 (17 words) on the narrow tile with two counters is as good or better
+// (2.110 vs 2.148 ms; two-vector m = 5, 16 words: 2.040 vs 2.028) -- profiles/r02/ab_inproc_tile_tickets.txt.
+template <int K, int COMB>
+int launch_combine_win_k(const nka_hip_state *a, double *f, int bpc) {
+  constexpr int W = (COMB == 2 ? win_ring<K>() : win_ring_pairs<K>());
+  constexpr int words = (COMB == 2 ? K + 2 : 2 * K + 1) + 5;
+  if constexpr (words <= 14) {
+    if (a->pb_tile == 2 || (a->pb_tile < 0 && pb_tickets_apply(a))) return launch_combine_win_1<K, COMB, W, 2>(a, f, bpc);
+  }
+  return launch_combine_win_1<K, COMB, W, 1>(a, f, bpc);
 }
 
 template <int COMB>
@@ -410,7 +428,7 @@ int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) 
   // mapping prefers 4 (n = 1e7: 0.359 vs 0.366 ms).  Among the widths 1..32 only 20 has both divisors.
   if (COMB == 2 && width == 20 && pb_tickets_apply(a)) return launch_combine_win_1<20, 2, 5>(a, f, bpc);
 #define CASE(K) \
-  case K: return launch_combine_win_1<K, COMB, (COMB == 2 ? win_ring<K>() : win_ring_pairs<K>())>(a, f, bpc);
+  case K: return launch_combine_win_k<K, COMB>(a, f, bpc);
   switch (width) {
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
     CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
@@ -719,7 +737,7 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   // faster than k_combine over n = 1e6..1e8, m = 5..20 (-2 % at n = 1e8 m = 20, -7...-11 % at m = 5/10).
   // Two-vector flavours (ring of 2 pairs): with the static tile mapping the window wins only once the
   // pass moves >~ 8 GB and loses below (n = 1e7: +3 % at m = 20, +12 % at m = 10), where k_combine's
-  // deeper queue hides the ramp at both ends of the launch; with tile tickets (taken from 80 tiles per
+  // deeper queue hides the ramp at both ends of the launch; with tile tickets (taken from 64 tiles per
   // block, launch_combine_win_1) it wins from there on: n = 1.25e7, m = 20: 0.782 vs 0.837 ms, n = 2.5e7:
   // 1.540 vs 1.726 ms (profiles/r02/ab_inproc_tile_tickets.txt).
   int pipe = a->pb_pipe;
@@ -1192,6 +1210,9 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value < 1 || value > 1024) return fail(NKA_HIP_EINVAL, "timing_stride: 1..1024");
     a->timing_stride = value;
     a->update_seq = 0;
+  } else if (k == "pb_tile") {
+    if (value != -1 && value != 1 && value != 2) return fail(NKA_HIP_EINVAL, "pb_tile: -1 (auto), 1, 2");
+    a->pb_tile = value;
   } else if (k == "pb_tickets") {
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");

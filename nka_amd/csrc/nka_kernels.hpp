@@ -803,12 +803,17 @@ __device__ __forceinline__ void ticket_finish(unsigned *tickets, int ng, int G) 
   }
 }
 
-template <int MAXK, int COMB, int W>
+template <int MAXK, int COMB, int W, int T = 1>
 __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng) {
+  // T = 16-byte pieces per thread, stream and tile (tile = 512*T elements, 4*T KiB per stream and
+  // block): T = 2 halves the ticket rate, which is what lets SHORT lists use one counter (a
+  // single counter saturates near 60-75 tickets/us; tools/hbm_probe mode i: 12 + 5 streams move
+  // 6.3-6.4 TB/s with T = 2 and one counter against 5.7 with T = 1 and two, 5.4 static).
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr bool RCP = (COMB == 1);
   constexpr bool COMPACT = (COMB == 2);
+  constexpr int TILE = kBlock * VEC * T;
   static_assert(MAXK % W == 0, "the ring must divide the pairs of a tile");
   __shared__ unsigned s_next[2];
   const int G = gridDim.x;
@@ -834,18 +839,24 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   // compact storage reads w only for the pending pair that is normalised now
   const double *w0src = norm0 ? wk[0] : f;
 
-  const int64_t ntile = vs.n / (kBlock * VEC);
-  V finv, w0v, rw[COMPACT ? 1 : W], rv[W];
+  const int64_t ntile = vs.n / TILE;
+  const int lane_off = threadIdx.x * VEC;                  // piece q of a tile starts q*512 elements further
+  V finv[T], w0v[T], rw[COMPACT ? 1 : W][T], rv[W][T];
   int64_t t = blockIdx.x;
   if (t < ntile) {
-    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    finv = ld<VEC>(f + e);
-    if (COMPACT) w0v = ld<VEC>(w0src + e);
+    const int64_t e = t * TILE + lane_off;
 #pragma unroll
-    for (int j = 0; j < W; j++) {
-      if (!COMPACT) rw[j] = ld<VEC>(wk[j] + e);
-      rv[j] = ld<VEC>(vk[j] + e);
+    for (int q = 0; q < T; q++) {
+      finv[q] = ld<VEC>(f + e + q * (kBlock * VEC));
+      if (COMPACT) w0v[q] = ld<VEC>(w0src + e + q * (kBlock * VEC));
     }
+#pragma unroll
+    for (int j = 0; j < W; j++)
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        if (!COMPACT) rw[j][q] = ld<VEC>(wk[j] + e + q * (kBlock * VEC));
+        rv[j][q] = ld<VEC>(vk[j] + e + q * (kBlock * VEC));
+      }
   }
   // ticket counter of this block's group; ticket k of group g is tile (k + 2G/ng)*ng + g
   const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
@@ -854,61 +865,83 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   int64_t tnext = t + G;
   unsigned par = 0;
   while (t < ntile) {
-    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
+    const int64_t e = t * TILE + lane_off;
     const bool more = tnext < ntile;
     unsigned claimed = kNoTicket;
     if (tickets && more && threadIdx.x == 0) claimed = ticket_request(my_ticket, ticket_base, (unsigned)ng, grp);
     const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
-    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
-    const V fin = finv;
-    V w0 = COMPACT ? w0v : fin;
-    V x = fin;
-    st(wnew + e, fin);
+    const int64_t en = tn * TILE + lane_off;
+    V fin[T], w0[T], x[T];
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      fin[q] = finv[q];
+      w0[q] = COMPACT ? w0v[q] : fin[q];
+      x[q] = fin[q];
+      st(wnew + e + q * (kBlock * VEC), fin[q]);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    finv = ld<VEC>(f + en);
-    if (COMPACT) w0v = ld<VEC>(w0src + en);
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      finv[q] = ld<VEC>(f + en + q * (kBlock * VEC));
+      if (COMPACT) w0v[q] = ld<VEC>(w0src + en + q * (kBlock * VEC));
+    }
 #pragma unroll
     for (int j = 0; j < MAXK; j++) {
-      V wj = COMPACT ? w0 : rw[COMPACT ? 0 : j % W];
-      V vj = rv[j % W];
+      V wj[T], vj[T];
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        wj[q] = COMPACT ? w0[q] : rw[COMPACT ? 0 : j % W][q];
+        vj[q] = rv[j % W][q];
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (j + W < MAXK) {
-        if (!COMPACT) rw[COMPACT ? 0 : j % W] = ld<VEC>(wk[j + W] + e);
-        rv[j % W] = ld<VEC>(vk[j + W] + e);
-      } else {
-        if (!COMPACT) rw[COMPACT ? 0 : j % W] = ld<VEC>(wk[j + W - MAXK] + en);
-        rv[j % W] = ld<VEC>(vk[j + W - MAXK] + en);
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        if (j + W < MAXK) {
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W] + e + q * (kBlock * VEC));
+          rv[j % W][q] = ld<VEC>(vk[j + W] + e + q * (kBlock * VEC));
+        } else {
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W - MAXK] + en + q * (kBlock * VEC));
+          rv[j % W][q] = ld<VEC>(vk[j + W - MAXK] + en + q * (kBlock * VEC));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (j == 0 && norm0) {
 #pragma unroll
-        for (int q = 0; q < VEC; q++) {
-          const double d = ex(wj, q) - ex(fin, q);
-          const double wn = RCP ? rs * d : d / s;
-          const double vn = RCP ? rs * ex(vj, q) : ex(vj, q) / s;
-          setc(wj, q, wn);
-          setc(vj, q, COMPACT ? vn - wn : vn);
+        for (int q = 0; q < T; q++) {
+#pragma unroll
+          for (int c = 0; c < VEC; c++) {
+            const double d = ex(wj[q], c) - ex(fin[q], c);
+            const double wn = RCP ? rs * d : d / s;
+            const double vn = RCP ? rs * ex(vj[q], c) : ex(vj[q], c) / s;
+            setc(wj[q], c, wn);
+            setc(vj[q], c, COMPACT ? vn - wn : vn);
+          }
+          st(wk[0] + e + q * (kBlock * VEC), wj[q]);
+          st(vk[0] + e + q * (kBlock * VEC), vj[q]);
         }
-        st(wk[0] + e, wj);
-        st(vk[0] + e, vj);
       }
       if (j < ncomb) {
 #pragma unroll
-        for (int q = 0; q < VEC; q++) {
-          if (COMPACT) setc(x, q, ex(x, q) + ck[j] * ex(vj, q));
-          else setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wj, q), ex(vj, q)));
-        }
+        for (int q = 0; q < T; q++)
+#pragma unroll
+          for (int c = 0; c < VEC; c++) {
+            if (COMPACT) setc(x[q], c, ex(x[q], c) + ck[j] * ex(vj[q], c));
+            else setc(x[q], c, comb1<COMB>(ex(x[q], c), ck[j], ex(wj[q], c), ex(vj[q], c)));
+          }
       }
     }
-    st(vnew + e, x);
-    st(f + e, x);
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      st(vnew + e + q * (kBlock * VEC), x[q]);
+      st(f + e + q * (kBlock * VEC), x[q]);
+    }
     const int64_t t2 = tickets ? ticket_publish(s_next, par, claimed, ntile) : tnext + G;
     t = tnext;
     tnext = t2;
   }
   if (tickets) ticket_finish(tickets, ng, G);
   if (blockIdx.x == G - 1) {  // ragged tail, scalar
-    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
+    for (int64_t i = ntile * TILE + threadIdx.x; i < vs.n; i += kBlock) {
       const double fin = f[i];
       double x = fin;
 #pragma unroll

@@ -693,7 +693,7 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     // tile tickets (k_combine_win): one counter while a tile carries >= 22 words per element, else two
     const int words = (PAIRS ? 2 : 1) * nv + 1 + 1 + (kin ? 1 : 0) + (kout ? 1 : 0);
     int ng = ws->ticket_groups;
-    if (ng < 0) ng = (win && n / (kBlock * 2) >= (int64_t)80 * g) ? (words >= 22 ? 1 : 2) : 0;
+    if (ng < 0) ng = (win && n / (kBlock * 2) >= (int64_t)64 * g) ? (words >= 22 ? 1 : 2) : 0;
     if (!win || !ws->tickets || g % std::max(ng, 1) != 0 || n / (kBlock * 2) >= ((int64_t)1 << 31) - 2 * kMaxGrid) ng = 0;
     unsigned *const tix = ng > 0 ? ws->tickets : nullptr;
 #define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, tix, std::max(ng, 1))

@@ -288,10 +288,11 @@ def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
     X = [rng.standard_normal(3) @ basis if t % 5 == 3 else rng.standard_normal(n) for t in range(m + 8)]
     X[m + 2] = X[m + 1].copy()                      # s == 0 -> relax inside the update
 
-    def run(tickets):
+    def run(tickets, tile=1):
         acc = nka_amd.nka().init(n, m, flavor=flavor)
         acc.set_tuning("pb_pipe", 201)
         acc.set_tuning("pb_tickets", tickets)
+        acc.set_tuning("pb_tile", tile)            # 2: double-width tiles (short lists only)
         outs = []
         for t, x in enumerate(X):
             ft = torch_cuda.from_numpy(x.copy()).cuda()
@@ -305,11 +306,11 @@ def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
         return outs, acc.state_digest(), acc.w(st.first), acc.v(st.first)
 
     ref = run(0)
-    for tickets in (1, 2, 4, 8, -1):
-        got = run(tickets)
+    for tickets, tile in ((1, 1), (2, 1), (4, 1), (8, 1), (-1, 1), (0, 2), (1, 2), (2, 2), (-1, -1)):
+        got = run(tickets, tile)
         for t, (a, b) in enumerate(zip(ref[0], got[0])):
-            assert np.array_equal(a, b), (tickets, t, np.abs(a - b).max())
-        assert got[1] == ref[1], tickets
-        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), tickets
+            assert np.array_equal(a, b), (tickets, tile, t, np.abs(a - b).max())
+        assert got[1] == ref[1], (tickets, tile)
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), (tickets, tile)
     with pytest.raises(nka_amd.NKAError):
         nka_amd.nka().init(16, 2).set_tuning("pb_tickets", 3)
