@@ -519,13 +519,16 @@ def test_follows_the_current_torch_stream(torch_cuda, oracle):
         P.record(S.rel_err(out, f, x), TOL_SMALL, "torch stream following n=50021 m=4")
 
 
-def test_steady_state_update_is_hipgraph_capturable(torch_cuda):
+@pytest.mark.parametrize("n,tickets", [(200003, -1), (400037, 1)])
+def test_steady_state_update_is_hipgraph_capturable(torch_cuda, n, tickets):
     """accel_update only enqueues kernels; once capture_safe() is true, ONE update
     captured into a hipGraph and replayed with fresh inputs reproduces the eager
-    results bit for bit (launch-bound small-n loops can be replayed as graphs)."""
+    results bit for bit (launch-bound small-n loops can be replayed as graphs).
+    Second case: PB takes its tiles from the global ticket counter -- device-side
+    state that every launch, replayed ones included, must leave at zero."""
     import nka_amd
     torch = torch_cuda
-    n, m = 200003, 6
+    m = 6
     rng = np.random.default_rng(0)
     X = [rng.standard_normal(n) for _ in range(m + 12)]
     ref = nka_amd.nka().init(n, m)
@@ -535,6 +538,9 @@ def test_steady_state_update_is_hipgraph_capturable(torch_cuda):
         ref.accel_update(t)
         want.append(t.cpu().numpy())
     acc = nka_amd.nka().init(n, m)
+    if tickets >= 0:
+        acc.set_tuning("pb_pipe", 201)
+        acc.set_tuning("pb_tickets", tickets)
     side = torch.cuda.Stream()
     static = torch.empty(n, dtype=torch.float64, device="cuda")
     got = []

@@ -42,10 +42,10 @@ def main():
             rows.append(np.diff(st[:10]))
     d = np.median(np.array(rows), axis=0)
     tot = d.sum()
-    print(f"{'k_solve_wave' if a.variant else 'k_solve_wave2'} phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (100 MHz => 10 ns):")
+    print(f"{'k_solve_wave' if a.variant else 'k_solve_wave2'} phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
     for nm, v in zip(NAMES, d):
-        print(f"  {nm:<42s} {v:8.0f} ticks  {v * 0.01:7.2f} us  {100 * v / tot:5.1f} %")
-    print(f"  {'total inside the kernel':<42s} {tot:8.0f} ticks  {tot * 0.01:7.2f} us")
+        print(f"  {nm:<42s} {v:8.0f} cycles  {100 * v / tot:5.1f} %")
+    print(f"  {'total inside the kernel':<42s} {tot:8.0f} cycles")
 
 
 if __name__ == "__main__":
