@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--key", default="pb_pipe")
     ap.add_argument("--values", type=int, nargs="+", default=[0, 2, 4])
     ap.add_argument("--combos", nargs="+", default=None,
-                    help="variants as key=value[,key=value...] (overrides --key/--values), e.g. pb_tickets=1,pb_store=0")
+                    help="variants as key=value[,key=value...] (overrides --key/--values), e.g. pb_tickets=1,pb_tile=2")
     ap.add_argument("--flavor", default="f08", choices=["f08", "c", "f08vec"])
     ap.add_argument("--vlen", type=float, default=1e8)
     ap.add_argument("--mvec", type=int, default=20)
