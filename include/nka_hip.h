@@ -207,8 +207,7 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
 /* Kernel-variant switches for A/B measurements inside one process (same
  * allocations, same thermal state).  "pa_pipe" / "pb_pipe" (env NKA_HIP_PA_PIPE /
  * NKA_HIP_PB_PIPE): -1 automatic (default); 0 = every load of a tile in flight
- * (k_dots / k_combine); 2, 4 = software-pipelined over that many load groups per
- * tile (k_dots_pipe / k_combine_pipe); 201..204 = rolling window (k_dots_win /
+ * (k_dots / k_combine, any list length); 201..204 = rolling window (k_dots_win /
  * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.
  * "pb_tickets" (env NKA_HIP_PB_TICKETS): how the blocks of the rolling-window PB
  * get their tiles: -1 automatic (default: tickets from 64 tiles per block), 0 =

@@ -173,9 +173,9 @@ struct nka_hip_state {
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
   char devname[64] = {0};
-  int pa_pipe = -1;           // groups of the software-pipelined PA: 0 = k_dots, 2 or 4 = k_dots_pipe, -1 = automatic
-  int pb_pipe = -1;           // groups of the software-pipelined PB: 0 = k_combine, 2 or 4 = k_combine_pipe,
-                              // -1 = automatic (see enqueue_pb)
+  int pa_pipe = -1;           // form of PA: 0 = k_dots (every load of a tile in flight; any list length), 201..204 = k_dots_win
+                              // (rolling window) with 1..4 blocks per CU, -1 = automatic (see enqueue_pa)
+  int pb_pipe = -1;           // form of PB: 0 = k_combine, 201..204 = k_combine_win, -1 = automatic (see enqueue_pb)
   int pb_tile = -1;           // tile width of the rolling-window PB for short lists: -1 automatic (double-width tiles
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
@@ -244,25 +244,6 @@ int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) 
   return g;
 }
 
-template <int MAXL, int GP>
-int launch_dots_pipe_1(const nka_hip_state *a, const double *f) {
-  static const int occ = occupancy_of(k_dots_pipe<MAXL, GP>);
-  const int g = grid_for(a, 0, 2, occ, MAXL + 2);
-  hipLaunchKernelGGL((k_dots_pipe<MAXL, GP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
-  hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, g, 0, MAXL);
-  return g;
-}
-
-// `pipe` = 2 or 4 load groups per tile (finer groups measured no better: profiles/r02/ab_inproc_pipelined_passes.txt)
-template <int MAXL>
-int launch_dots_pipe_g(int pipe, const nka_hip_state *a, const double *f) {
-  switch (pipe) {
-    case 4: return launch_dots_pipe_1<MAXL, MAXL / 4>(a, f);
-    default: return launch_dots_pipe_1<MAXL, MAXL / 2>(a, f);
-  }
-}
-
 // rolling-window PA: ring of W registers, `bpc` blocks per CU
 template <int MAXL, int W>
 int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
@@ -306,16 +287,6 @@ int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc)
   return 0;
 }
 
-int launch_dots_pipe(int pipe, int maxl, const nka_hip_state *a, const double *f) {
-#define CASE(L) \
-  case L: return launch_dots_pipe_g<L>(pipe, a, f);
-  switch (maxl) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
-  }
-#undef CASE
-  return 0;
-}
-
 int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass, int npass) {
 #define CASE(L) \
   case L: return launch_dots_1<L, 2>(a, f, pass, npass);
@@ -343,41 +314,6 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
   }
 #undef CASE
   return 0;
-}
-
-template <int MAXK, int COMB, int GP>
-int launch_combine_pipe_1(const nka_hip_state *a, double *f) {
-  static const int occ = occupancy_of(k_combine_pipe<MAXK, COMB, GP>);
-  const int g = grid_for(a, 1, 2, occ, (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1));
-  hipLaunchKernelGGL((k_combine_pipe<MAXK, COMB, GP>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f);
-  return g;
-}
-
-template <int MAXK, int COMB>
-int launch_combine_pipe_g(int pipe, const nka_hip_state *a, double *f) {
-  switch (pipe) {
-    case 4: return launch_combine_pipe_1<MAXK, COMB, MAXK / 4>(a, f);
-    default: return launch_combine_pipe_1<MAXK, COMB, MAXK / 2>(a, f);
-  }
-}
-
-template <int COMB>
-int launch_combine_pipe_w(int pipe, int maxk, const nka_hip_state *a, double *f) {
-#define CASE(K) \
-  case K: return launch_combine_pipe_g<K, COMB>(pipe, a, f);
-  switch (maxk) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
-  }
-#undef CASE
-  return 0;
-}
-
-int launch_combine_pipe(int pipe, int flavor, int maxk, const nka_hip_state *a, double *f) {
-  switch (flavor) {
-    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_pipe_w<1>(pipe, maxk, a, f);
-    case NKA_HIP_FLAVOR_C: return launch_combine_pipe_w<2>(pipe, maxk, a, f);
-    default: return launch_combine_pipe_w<0>(pipe, maxk, a, f);
-  }
 }
 
 // rolling-window PB: ring of W pairs, `bpc` blocks per CU; every width 1..32 (no padding);
@@ -709,16 +645,13 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
   // carries no padding (m = 20: 2.58 vs 2.75 ms at n = 1e8, 0.374 vs 0.394 at 1.25e7, 44 vs 48 us
   // at 1e6; m = 10: 1.43 vs 1.60 ms at n = 1e8) -- padded entries are cache hits that occupy ring
   // slots and starve the window (m = 5 padded to 8 at n = 1e8: +20 %), which is why it is instantiated
-  // for EVERY width 1..32; the fallbacks (k_dots_pipe for large vectors, k_dots) serve mvec > 32 and
-  // unaligned f.
+  // for EVERY width 1..32; the fallback k_dots (multi-pass) serves mvec > 32 and unaligned f.
   int pa_pipe = a->pa_pipe;
   // the rolling-window kernel exists for every width 1..32, so the list needs no padding
   const bool exact = vec == 2 && older_ub >= 1 && older_ub <= kMaxPerPass;
-  if (pa_pipe < 0) pa_pipe = exact ? 201 : ((a->n >= 30000000) ? 4 : 0);
+  if (pa_pipe < 0) pa_pipe = exact ? 201 : 0;
   if (vec == 2 && npass == 1 && pa_pipe > 200 && pa_pipe < 210) {     // rolling window, 200 + blocks per CU
     launch_dots_win(exact ? older_ub : maxl, a, f, std::max(1, pa_pipe - 200));
-  } else if (vec == 2 && npass == 1 && pa_pipe > 0) {  // software-pipelined single pass (k_dots_pipe)
-    launch_dots_pipe(pa_pipe, maxl, a, f);
   } else {
     for (int p = 0; p < npass; p++) {
       if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
@@ -747,11 +680,6 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   }
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
     launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  if (vec == 2 && npass == 1 && pipe > 0) {   // software-pipelined single pass (k_combine_pipe)
-    launch_combine_pipe(pipe, a->flavor, maxk, a, f);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1199,12 +1127,12 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   if (!a || !key) return fail(NKA_HIP_EINVAL, "null argument");
   const std::string k(key);
   if (k == "pb_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
-      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
+    if (value != -1 && value != 0 && !(value > 200 && value <= 204))
+      return fail(NKA_HIP_EINVAL, "pb_pipe: -1 (auto), 0 (every load of a tile in flight), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pb_pipe = value;
   } else if (k == "pa_pipe") {
-    if (value != -1 && value != 0 && value != 2 && value != 4 && !(value > 200 && value <= 204))
-      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0, 2, 4 (load groups per tile), 201..204 (rolling window, 1..4 blocks per CU)");
+    if (value != -1 && value != 0 && !(value > 200 && value <= 204))
+      return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0 (every load of a tile in flight), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pa_pipe = value;
   } else if (k == "timing_stride") {
     if (value < 1 || value > 1024) return fail(NKA_HIP_EINVAL, "timing_stride: 1..1024");

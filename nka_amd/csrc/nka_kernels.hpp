@@ -278,93 +278,6 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
   block_reduce_store<NACC>(acc, partials, G);
 }
 
-// PA, software-pipelined over NG groups of stored vectors (single pass, VEC = 2):
-// as soon as group g of a tile has been accumulated, group g of the block's next
-// tile is requested into the same registers (cf. k_combine_pipe).  Same products,
-// same per-thread accumulation order => same bits as k_dots.
-template <int MAXL, int GP>
-__global__ __launch_bounds__(kBlock) void k_dots_pipe(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                      double *__restrict__ partials) {
-  constexpr int VEC = 2;
-  using V = typename VecT<VEC>::type;
-  constexpr int NACC = 2 * MAXL + 2;
-  constexpr int NG = MAXL / GP;          // GP stored vectors per group
-  static_assert(MAXL % GP == 0, "groups must divide the unroll width");
-  const int G = gridDim.x;
-  const int pending = ctl.ic[IC_PLAN_PENDING];
-  const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  const int32_t *slots = ctl.plan_slots();
-  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
-  const double *wk[MAXL];
-#pragma unroll
-  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? vs.w + (size_t)(slots[j] - 1) * vs.stride : f;
-  double acc[NACC];
-#pragma unroll
-  for (int a = 0; a < NACC; a++) acc[a] = 0.0;
-
-  const int64_t ntile = vs.n / (kBlock * VEC);
-  V fv, w1v, wkv[MAXL];
-  int64_t t = blockIdx.x;
-  if (t < ntile) {
-    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    fv = ld<VEC>(f + e);
-    w1v = ld<VEC>(w1 + e);
-#pragma unroll
-    for (int j = 0; j < MAXL; j++) wkv[j] = ld<VEC>(wk[j] + e);
-  }
-  for (; t < ntile; t += G) {
-    const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
-    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
-    double dq[VEC], fq[VEC];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (g == 0) {
-#pragma unroll
-        for (int q = 0; q < VEC; q++) {
-          fq[q] = ex(fv, q);
-          dq[q] = ex(w1v, q) - fq[q];                  // F08:266
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < VEC; q++) {
-        if (g == 0) {
-          acc[0] = fma(dq[q], dq[q], acc[0]);
-          acc[1] = fma(fq[q], dq[q], acc[1]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < GP; jj++) {
-          const int j = g * GP + jj;
-          acc[2 + j] = fma(dq[q], ex(wkv[j], q), acc[2 + j]);
-          acc[2 + MAXL + j] = fma(fq[q], ex(wkv[j], q), acc[2 + MAXL + j]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (g == 0) {
-        fv = ld<VEC>(f + en);
-        w1v = ld<VEC>(w1 + en);
-      }
-#pragma unroll
-      for (int jj = 0; jj < GP; jj++) wkv[g * GP + jj] = ld<VEC>(wk[g * GP + jj] + en);
-    }
-  }
-  if (blockIdx.x == G - 1) {  // ragged tail, scalar
-    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
-      const double fq = f[i];
-      const double d = w1[i] - fq;
-      acc[0] = fma(d, d, acc[0]);
-      acc[1] = fma(fq, d, acc[1]);
-#pragma unroll
-      for (int j = 0; j < MAXL; j++) {
-        const double x = wk[j][i];
-        acc[2 + j] = fma(d, x, acc[2 + j]);
-        acc[2 + MAXL + j] = fma(fq, x, acc[2 + MAXL + j]);
-      }
-    }
-  }
-  block_reduce_store<NACC>(acc, partials, G);
-}
-
 // PA with a SMALL ROLLING WINDOW of loads.  tools/hbm_probe (mode f) showed that a
 // pure-read kernel with the arithmetic of this pass runs at 7.15 TB/s when each wave
 // keeps only ~6 loads in flight and re-issues one as soon as one has been consumed,
@@ -610,142 +523,6 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
       if (store_w) wnew[i] = fin;
       if (store_v) vnew[i] = x;
       if (store_f) f[i] = x;
-    }
-  }
-}
-
-// ---- PB, software-pipelined over groups of pairs ---------------------------------
-// k_combine above issues every load of a tile, waits, computes, stores, and only
-// then issues the next tile: between the last return and the next issue the
-// wave has nothing in flight.  Here the MAXK pairs of a tile form NG groups of
-// GP = MAXK/NG pairs; as soon as group g of tile t has been consumed, group g of
-// the block's NEXT tile is requested into the same registers, so (NG-1)/NG of a
-// tile's loads are in flight at every moment and the CU's memory pipeline never
-// runs dry.  Same arithmetic in the same order => same bits as k_combine.
-// Single pass only (MAXK covers the list: mvec <= 32), VEC = 2.  The block's last
-// iteration prefetches its own tile again (cache hits) so that the loop body has
-// no load under a branch: the compiler's s_waitcnt vmcnt(N) counts stay exact.
-template <int MAXK, int COMB, int GP>
-__global__ __launch_bounds__(kBlock) void k_combine_pipe(Ctl ctl, Vecs vs, double *f) {
-  constexpr int VEC = 2;
-  using V = typename VecT<VEC>::type;
-  constexpr bool RCP = (COMB == 1);
-  constexpr bool COMPACT = (COMB == 2);
-  constexpr int NW = COMPACT ? 1 : MAXK;
-  constexpr int NG = MAXK / GP;          // GP pairs per group
-  static_assert(MAXK % GP == 0, "groups must divide the unroll width");
-  const int G = gridDim.x;
-  const int ncomb = ctl.ic[IC_NCOMB];
-  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
-  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
-  const int32_t *cs = ctl.comb_slots();
-  const double *cc = ctl.comb_c();
-  const bool norm0 = ctl.ic[IC_NORMED] != 0;
-  const double s = ctl.dc[DC_S];
-  const double rs = 1.0 / s;
-
-  double *wk[MAXK], *vk[MAXK];
-  double ck[MAXK];
-#pragma unroll
-  for (int j = 0; j < MAXK; j++) {
-    const bool live = j < ncomb;
-    const size_t off = live ? (size_t)(cs[j] - 1) * vs.stride : 0;
-    wk[j] = live ? vs.w + off : f;
-    vk[j] = live ? vs.v + off : f;
-    ck[j] = cc[j];
-  }
-  // compact storage reads w only for the pending pair that is normalised now
-  const double *w0src = (!COMPACT || norm0) ? wk[0] : f;
-
-  const int64_t ntile = vs.n / (kBlock * VEC);
-  V finv, wv[NW], vv[MAXK];
-  int64_t t = blockIdx.x;
-  if (t < ntile) {
-    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    finv = ld<VEC>(f + e);
-    wv[0] = ld<VEC>(w0src + e);
-#pragma unroll
-    for (int j = 1; j < NW; j++) wv[j] = ld<VEC>(wk[j] + e);
-#pragma unroll
-    for (int j = 0; j < MAXK; j++) vv[j] = ld<VEC>(vk[j] + e);
-  }
-  for (; t < ntile; t += G) {
-    const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    const int64_t tn = (t + G < ntile) ? t + G : t;
-    const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
-    V x;
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (g == 0) {
-        const V fin = finv;
-        if (norm0) {
-#pragma unroll
-          for (int q = 0; q < VEC; q++) {
-            const double d = ex(wv[0], q) - ex(fin, q);
-            const double wn = RCP ? rs * d : d / s;
-            const double vn = RCP ? rs * ex(vv[0], q) : ex(vv[0], q) / s;
-            setc(wv[0], q, wn);
-            setc(vv[0], q, COMPACT ? vn - wn : vn);
-          }
-          st(wk[0] + e, wv[0]);
-          st(vk[0] + e, vv[0]);
-        }
-        x = fin;
-        st(wnew + e, fin);
-      }
-#pragma unroll
-      for (int jj = 0; jj < GP; jj++) {
-        const int j = g * GP + jj;
-        if (j < ncomb) {
-#pragma unroll
-          for (int q = 0; q < VEC; q++) {
-            if (COMPACT) setc(x, q, ex(x, q) + ck[j] * ex(vv[j], q));
-            else setc(x, q, comb1<COMB>(ex(x, q), ck[j], ex(wv[j < NW ? j : 0], q), ex(vv[j], q)));
-          }
-        }
-      }
-      if (g == NG - 1) {
-        st(vnew + e, x);
-        st(f + e, x);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // group g of the next tile into the registers just consumed
-      if (g == 0) {
-        finv = ld<VEC>(f + en);
-        wv[0] = ld<VEC>(w0src + en);
-      }
-#pragma unroll
-      for (int jj = 0; jj < GP; jj++) {
-        const int j = g * GP + jj;
-        if (j > 0 && j < NW) wv[j] = ld<VEC>(wk[j] + en);
-        vv[j] = ld<VEC>(vk[j] + en);
-      }
-    }
-  }
-  if (blockIdx.x == G - 1) {  // ragged tail, scalar
-    for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
-      const double fin = f[i];
-      double x = fin;
-#pragma unroll
-      for (int j = 0; j < MAXK; j++) {
-        if (j < ncomb) {
-          double v = vk[j][i];
-          double w = (!COMPACT || (j == 0 && norm0)) ? wk[j][i] : 0.0;
-          if (j == 0 && norm0) {
-            const double d = w - fin;
-            w = RCP ? rs * d : d / s;
-            v = RCP ? rs * v : v / s;
-            if (COMPACT) v = v - w;
-            wk[0][i] = w;
-            vk[0][i] = v;
-          }
-          x = COMPACT ? x + ck[j] * v : comb1<COMB>(x, ck[j], w, v);
-        }
-      }
-      wnew[i] = fin;
-      vnew[i] = x;
-      f[i] = x;
     }
   }
 }

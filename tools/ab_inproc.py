@@ -3,7 +3,7 @@
 inputs, same thermal state), the variants alternated in blocks of K updates for
 R rounds; per-phase device times from the library's HIP events.
 
-  tools/ab_inproc.py --key pb_pipe --values 0 2 4 [--flavor f08] [--vlen 1e8] [--mvec 20] [--rounds 8] [--steps 10]
+  tools/ab_inproc.py --key pb_pipe --values 0 201 [--flavor f08] [--vlen 1e8] [--mvec 20] [--rounds 8] [--steps 10]
 """
 import argparse
 import os
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--key", default="pb_pipe")
-    ap.add_argument("--values", type=int, nargs="+", default=[0, 2, 4])
+    ap.add_argument("--values", type=int, nargs="+", default=[0, 201])
     ap.add_argument("--combos", nargs="+", default=None,
                     help="variants as key=value[,key=value...] (overrides --key/--values), e.g. pb_tickets=1,pb_tile=2")
     ap.add_argument("--flavor", default="f08", choices=["f08", "c", "f08vec"])

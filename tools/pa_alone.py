@@ -19,7 +19,7 @@ for t in range(m + 3):
     acc.accel_update(f)
 synth.fill_torch(f, 12345, 99, 0, n)
 L = nka_amd.load()
-for v in [int(x) for x in (sys.argv[2:] or ["0", "4", "201", "221", "231"])]:
+for v in [int(x) for x in (sys.argv[2:] or ["0", "201", "202"])]:
     acc.set_tuning("pa_pipe", v)
     ms = C.c_float()
     for _ in range(2):
