@@ -180,7 +180,6 @@ struct nka_hip_state {
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
-  int solve_variant = 0;      // 0 = k_solve_wave2 (registers + masks), 1 = k_solve_wave (first version, LDS walks)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
@@ -470,7 +469,6 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
   a->pb_tickets = env_int("NKA_HIP_PB_TICKETS", a->pb_tickets);
   if (a->pb_tickets > 0 && a->pb_tickets != 1 && a->pb_tickets != 2 && a->pb_tickets != 4 && a->pb_tickets != 8) a->pb_tickets = -1;
-  a->solve_variant = env_int("NKA_HIP_SOLVE_VARIANT", a->solve_variant);
   a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
   a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
@@ -615,10 +613,7 @@ static int enqueue_solve(nka_hip_t a, int mode) {
     const int ns = solve_pairs_per_lane(a->mvec);
 #define SOLVE(NS)                                                                                        \
   do {                                                                                                   \
-    if (a->solve_variant == 1)                                                                           \
-      hipLaunchKernelGGL((k_solve_wave<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);         \
-    else                                                                                                 \
-      hipLaunchKernelGGL((k_solve_wave2<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);        \
+    hipLaunchKernelGGL((k_solve_wave2<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);          \
   } while (0)
     if (ns <= 1) SOLVE(1);
     else if (ns <= 2) SOLVE(2);
@@ -1147,9 +1142,6 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
-  } else if (k == "solve_variant") {
-    if (value != 0 && value != 1) return fail(NKA_HIP_EINVAL, "solve_variant: 0 or 1");
-    a->solve_variant = value;
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);
   }

@@ -1003,222 +1003,17 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   return b;
 }
 
-// All 64 lanes run the O(m) list bookkeeping REDUNDANTLY on private copies of
-// the scalars (first/last/free/flags) -- LDS reads are uniform-address
-// broadcasts, LDS writes store the same value from every lane -- so the state
-// stays consistent across the wavefront without any broadcast, and nothing on
-// the critical path waits on global memory (red[] and the plan are staged into
-// LDS by one coalesced load each).
-// NS = pairs per lane = ceil((mvec+2)(mvec+1)/2 / 64), a template parameter so
-// the per-column update loop is exactly as long as this mvec needs: a lone
-// wavefront issues ~1 instruction per 4-5 cycles, so instruction COUNT, not
-// latency, sets the run time here (NS = 19 for every mvec took 50 us at m = 20).
-template <int NS>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_wave(Ctl ctl, int mode) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Lst L;
-  NKA_STAMP(ctl, 0);
-  lst_load(L, ctl, smem);
-  NKA_STAMP(ctl, 1);
-  const int lane = threadIdx.x;
-  const int NL = ctl.m1(), LDA = NL + 1, M = ctl.mvec;
-  // A has NL+1 rows: row nl (one past the list) carries the right-hand side
-  // <f,w_j> through the factorisation, which IS the forward substitution
-  // F08:369-379 (same recurrence, same order) -- it then costs nothing extra.
-  double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
-  double *dd = A + (NL + 1) * LDA;   // running pivots 1 - sum l^2
-  double *Ld = dd + NL;              // accepted pivots sqrt(hkk)
-  double *bb = Ld + NL;              // right-hand side / solution by list position
-  double *redL = bb + NL;            // LDS copy of red[2+2M]
-  int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));  // list position -> slot
-  int32_t *alive = ord + NL;
-  int32_t *psL = alive + NL;         // LDS copy of the dot plan (slots PA read)
-  const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  const double vtol2 = L.vtol * L.vtol;
-  for (int i = lane; i < 2 + 2 * M; i += kSolveThreads) redL[i] = ctl.red()[i];
-  for (int i = lane; i < nolder; i += kSolveThreads) psL[i] = ctl.plan_slots()[i];
-  __syncthreads();
-
-  // ---- phase 0: norm, s == 0 -> relax, Gram row of w1' = d/s, right-hand side
-  const int entry_first = L.first;
-  int normed = 0;
-  double s = 0.0;
-  if (L.pending) {
-    s = sqrt(redL[0]);                        // F08:267
-    if (s == 0.0) lst_relax(L);               // F08:275
-  }
-  if (L.pending) normed = 1;
-  {
-    const double rs = 1.0 / s;
-    for (int p = lane; p < nolder; p += kSolveThreads) {
-      if (normed) L.H(L.first, psL[p]) = solve_nrm(redL[2 + p], s, rs, mode);         // F08:286-290
-      L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
-    }
-    if (normed && lane == 0) L.c[entry_first] = solve_nrm(redL[1], s, rs, mode);     // <f,w1'> = <f,d>/s
-  }
-  int nl = 0;
-  for (int k = L.first; k != 0; k = L.next[k]) ord[nl++] = k;
-  __syncthreads();
-  NKA_STAMP(ctl, 2);
-  int capdrop = -1;
-  bool forward_done = false;
-
-  if (normed) {
-    // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
-    //      plus the right-hand side as row nl.
-    // this lane's share of the strictly-lower pairs (p,q), p in 1..nl, q < p
-    int pp[NS], qq[NS];
-    const int npairs = (nl + 1) * nl / 2;
-#pragma unroll
-    for (int t = 0; t < NS; t++) {
-      const int idx = lane + kSolveThreads * t;
-      int p = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
-      while (p * (p - 1) / 2 > idx) p--;
-      while ((p + 1) * p / 2 <= idx) p++;
-      pp[t] = idx < npairs ? p : 0;
-      qq[t] = idx < npairs ? idx - p * (p - 1) / 2 : 0;
-      if (idx < npairs) A[p * LDA + qq[t]] = (p < nl) ? L.H(ord[qq[t]], ord[p])   // raw <w_q,w_p>, q newer
-                                                       : L.c[ord[qq[t]]];           // rhs <f,w_q>
-    }
-    for (int p = lane; p < nl; p += kSolveThreads) {
-      dd[p] = 1.0;
-      alive[p] = 1;
-    }
-    __syncthreads();
-    NKA_STAMP(ctl, 3);
-    int kept = 0;
-    for (int i = 0; i < nl; i++) {
-      bool keep;
-      double Lii = 1.0;
-      if (i == 0) {
-        keep = true;                           // F08:295 h(first,first) = 1
-      } else if (kept + 1 > L.mvec) {
-        keep = false;                          // F08:301-308 capacity: i is the last entry
-        capdrop = i;
-      } else {
-        const double hkk = dd[i];
-        keep = hkk > vtol2;                    // F08:326
-        if (keep) Lii = sqrt(hkk);
-      }
-      if (!keep) {
-        alive[i] = 0;
-        if (capdrop >= 0) break;
-        continue;
-      }
-      kept++;
-      Ld[i] = Lii;
-      for (int p = i + 1 + lane; p <= nl; p += kSolveThreads) {
-        const double l = A[p * LDA + i] / Lii;   // F08:320 (row nl: F08:377)
-        A[p * LDA + i] = l;
-        if (p < nl) dd[p] = dd[p] - l * l;       // F08:321
-      }
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < NS; t++) {
-        const int p = pp[t], q = qq[t];
-        if (q > i && p > q)                      // trailing entry: F08:317 (row nl: F08:374)
-          A[p * LDA + q] = A[p * LDA + q] - A[p * LDA + i] * A[q * LDA + i];
-      }
-      __syncthreads();
-    }
-    __syncthreads();
-    NKA_STAMP(ctl, 4);
-    // ---- phase 2: scatter the factor back by slot, compact the forward-
-    //      substituted right-hand side, replay the drops in list order
-#pragma unroll
-    for (int t = 0; t < NS; t++) {
-      const int p = pp[t], q = qq[t];
-      if (p > q && p < nl && alive[p] && alive[q]) L.H(ord[p], ord[q]) = A[p * LDA + q];
-    }
-    for (int p = lane; p < nl; p += kSolveThreads)
-      if (alive[p]) L.H(ord[p], ord[p]) = Ld[p];
-    {
-      int nk = 0;
-      for (int p = 0; p < nl; p++)
-        if (alive[p]) bb[nk++] = A[nl * LDA + p];
-    }
-    forward_done = true;
-    for (int p = 1; p < nl; p++) {
-      if (alive[p]) continue;
-      const int k = ord[p];
-      if (p == capdrop) {                      // F08:303-307
-        L.next[L.last] = L.free_;
-        L.free_ = k;
-        L.last = L.prev[k];
-        L.next[L.last] = 0;
-      } else {                                 // F08:331-340
-        const int pv = L.prev[k], nx = L.next[k];
-        L.next[pv] = nx;
-        if (nx == 0) L.last = pv; else L.prev[nx] = pv;
-        L.next[k] = L.free_;
-        L.free_ = k;
-      }
-    }
-    L.subspace = 1;
-    L.pending = 0;
-    __syncthreads();
-  }
-
-  // ---- phase 3: new slot, then the substitutions on the current list
-  NKA_STAMP(ctl, 5);
-  const int slot = L.free_;                    // F08:357-358
-  L.free_ = L.next[slot];
-  int nk = 0;
-  if (L.subspace)
-    for (int k = L.first; k != 0; k = L.next[k]) ord[nk++] = k;
-  __syncthreads();
-  if (nk > 0) {
-    if (!forward_done)
-      for (int p = lane; p < nk; p += kSolveThreads) bb[p] = L.c[ord[p]];
-    for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
-      const int p = idx / nk, q = idx - p * nk;
-      if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
-    }
-    __syncthreads();
-    if (!forward_done) {
-      for (int i = 0; i < nk; i++) {           // forward, F08:369-379
-        const double ci = bb[i] / A[i * LDA + i];
-        __syncthreads();
-        if (lane == 0) bb[i] = ci;
-        for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
-        __syncthreads();
-      }
-    }
-    NKA_STAMP(ctl, 6);
-    for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
-      const double ci = bb[i] / A[i * LDA + i];
-      __syncthreads();
-      if (lane == 0) bb[i] = ci;
-      for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
-      __syncthreads();
-    }
-    NKA_STAMP(ctl, 7);
-    for (int p = lane; p < nk; p += kSolveThreads) {
-      ctl.comb_slots()[p] = ord[p];
-      ctl.comb_c()[p] = bb[p];
-      L.c[ord[p]] = bb[p];
-    }
-  }
-  __syncthreads();
-  lst_prepend(L, slot);                        // F08:406-417 (every lane, same values)
-  if (lane == 0) {
-    ctl.dc[DC_S] = s;
-    if (entry_first != 0 && !normed && ctl.ic[IC_PENDING]) ctl.ic[IC_NRELAX] += 1;
-    ctl.ic[IC_NEW] = slot;
-    ctl.ic[IC_NCOMB] = nk;
-    ctl.ic[IC_NORMED] = normed;
-  }
-  NKA_STAMP(ctl, 8);
-  lst_store(L, ctl);
-  NKA_STAMP(ctl, 9);
-}
-
-// ---- the wavefront solve, second version: registers where the first one walks LDS ----
-// k_solve_wave spends most of its ~66 k cycles (m = 20, tools/solve_phases.py) not on
+// ---- the wavefront solve -----------------------------------------------------------------
+// NS = pairs per lane = ceil((mvec+2)(mvec+1)/2 / 64), a template parameter so the per-column
+// update loop is exactly as long as this mvec needs: a lone wavefront issues ~1 instruction per
+// 4-5 cycles, so instruction COUNT, not latency, sets the run time here.  All 64 lanes run the
+// O(m) list bookkeeping redundantly on private copies of the scalars (first/last/free/flags).
+// A first version (k_solve_wave, removed at the end of round 2) walked the lists and read the
+// pivots through LDS: it spent most of its ~66 k cycles (m = 20, tools/solve_phases.py) not on
 // arithmetic but on SERIAL LDS round trips of ~130 cycles each: the list walks
 // (three per update), the per-column pivot read, the position loops over `alive`,
-// and two global round trips at entry.  Same algorithm, same operation order per
-// matrix entry (hence the same bits), with
+// and two global round trips at entry.  This one keeps the algorithm and the operation order
+// per matrix entry (hence the bits), with
 //   * ONE global round trip at entry (state, sums and plan loaded together);
 //   * lane k holding next[k]: the list is walked with v_readlane (~10 cycles a step);
 //   * lane p holding the running pivot, the accepted pivot and the right-hand side
@@ -1250,7 +1045,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
   L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
   L.prev = L.next + (m1 + 1);
   double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
-  double *bb = A + (NL + 1) * LDA + 2 * NL;   // (same carve-up as k_solve_wave: dd and Ld slots unused here)
+  double *bb = A + (NL + 1) * LDA + 2 * NL;   // (the 2*NL doubles in between are unused)
   double *redL = bb + NL;
   int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
   int32_t *psL = ord + 2 * NL;

@@ -224,7 +224,7 @@ def test_bench_two_gpus(torch_cuda):
 @pytest.mark.parametrize("n,m", [(40961, 8), (100003, 20), (5003, 5)])
 def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
     """The streaming passes exist in two forms (every load of a tile in flight,
-    rolling window) and the scalar step in two;
+    rolling window) and the scalar step in two (one wavefront, or the reference's loops on one lane);
     nka_hip_set_tuning switches between them.  All of them restate the same
     arithmetic in the same order: outputs, stored vectors and the replicated state
     must agree BIT FOR BIT with the automatic choice, through list growth, capacity
@@ -258,7 +258,7 @@ def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
 
     ref = run({})
     variants = [{"pa_pipe": 0, "pb_pipe": 0}, {"pa_pipe": 201, "pb_pipe": 201}, {"pa_pipe": 202, "pb_pipe": 202},
-                {"pa_pipe": 201, "pb_pipe": 0}, {"pa_pipe": 0, "pb_pipe": 201}, {"solve_variant": 1},
+                {"pa_pipe": 201, "pb_pipe": 0}, {"pa_pipe": 0, "pb_pipe": 201},
                 {"serial_solve": 1}]
     for settings in variants:
         got = run(settings)

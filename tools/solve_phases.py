@@ -23,13 +23,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--vlen", type=float, default=1e5)
-    ap.add_argument("--variant", type=int, default=0, help="0 = k_solve_wave2, 1 = k_solve_wave")
     a = ap.parse_args()
     import torch
     import nka_amd
     n, m = int(a.vlen), a.mvec
     acc = nka_amd.nka().init(n, m)
-    acc.set_tuning("solve_variant", a.variant)
     L = nka_amd.load()
     rng = np.random.default_rng(0)
     rows = []
@@ -42,7 +40,7 @@ def main():
             rows.append(np.diff(st[:10]))
     d = np.median(np.array(rows), axis=0)
     tot = d.sum()
-    print(f"{'k_solve_wave' if a.variant else 'k_solve_wave2'} phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
+    print(f"k_solve_wave2 phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
     for nm, v in zip(NAMES, d):
         print(f"  {nm:<42s} {v:8.0f} cycles  {100 * v / tot:5.1f} %")
     print(f"  {'total inside the kernel':<42s} {tot:8.0f} cycles")
