@@ -313,3 +313,32 @@ def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), (tickets, tile)
     with pytest.raises(nka_amd.NKAError):
         nka_amd.nka().init(16, 2).set_tuning("pb_tickets", 3)
+
+
+def test_tile_tickets_soak(torch_cuda):
+    """300 consecutive updates with PB's tiles taken from the ticket counter (one
+    counter; then two with double-width tiles) in lock step with an accelerator on the
+    static mapping: every output bit for bit, every launch -- a rare hand-off slip
+    (a tile skipped or done twice, a counter not back at zero) would show as a
+    difference that persists."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 256 * 512 * 6 + 311, 4
+    accs = []
+    for tickets, tile in ((0, 1), (1, 1), (2, 2)):
+        a = nka_amd.nka().init(n, m, flavor=nka_amd.FLAVOR_C)
+        a.set_tuning("pb_pipe", 201)
+        a.set_tuning("pb_tickets", tickets)
+        a.set_tuning("pb_tile", tile)
+        accs.append(a)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for t in range(300):
+        x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+        outs = []
+        for a in accs:
+            f = x.clone()
+            a.accel_update(f)
+            outs.append(f)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), t
+    assert accs[0].state_digest() == accs[1].state_digest() == accs[2].state_digest()
