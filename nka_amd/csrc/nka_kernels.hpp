@@ -545,9 +545,9 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
 // streams moving 8-14 % faster when every block takes its next tile from ONE global counter:
 // the blocks then advance as a compact front (all end within 5 us of each other) and the DRAMs
 // see one narrow window per stream.  A block's first two tiles are static (b, b + G); thread 0
-// requests the tile after next with a returning atomic at the top of an iteration, publishes it
-// in LDS at the end (one workgroup barrier per tile), so the atomic's latency hides behind a
-// whole tile.  `ng` counters (128 B apart), counter g serving the blocks with b % ng == g and
+// requests the tile after next with a returning atomic at the top of an iteration and publishes it
+// in LDS at the end (one workgroup barrier per tile): the OTHER three waves never wait for the
+// atomic, wave 0 does (see ticket_request).  `ng` counters (128 B apart), counter g serving the blocks with b % ng == g and
 // the tiles = g (mod ng): a single counter saturates near 60-75 tickets/us, which short lists
 // exceed.  The last block to finish resets the counters (a second counter, `done`), so a launch
 // always finds them zero.  Elementwise pass: which block handles a tile changes no bit.
@@ -556,7 +556,12 @@ constexpr int kTicketGroupsMax = 8;
 constexpr int kTicketWords = kTicketStride * (kTicketGroupsMax + 1);   // ng counters + `done`
 constexpr unsigned kNoTicket = 0xffffffffu;
 
-// thread 0: the tile after next of this block's group (returning atomic; the value is used a tile later)
+// thread 0: the tile after next of this block's group (returning atomic; the value is used a tile later).
+// hipcc's atomic optimiser broadcasts the result with v_readfirstlane right behind the instruction, so
+// wave 0 does wait for the atomic here (s_waitcnt vmcnt(0)); measured against an inline-asm request
+// whose result is only read at the end of the tile, that costs 0-2 % of PB -- and the asm form needs a
+// hand-counted s_waitcnt that turned out NOT to be safe: stores retire out of order with respect to the
+// atomic, a short tile read its ticket too early (tests caught it).  The plain form stays.
 __device__ __forceinline__ unsigned ticket_request(unsigned *group_counter, unsigned base, unsigned ng, unsigned grp) {
   return (atomicAdd(group_counter, 1u) + base) * ng + grp;
 }
