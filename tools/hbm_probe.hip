@@ -804,6 +804,16 @@ int main(int argc, char **argv) {
     return 0;
   }
 #define RWT(S, W, WIN, NTS, T, LAY, G) runwT<S, W, WIN, NTS, T, LAY>("window S=" #S " W=" #W " WIN=" #WIN " T=" #T " lay=" #LAY, rd, wr, stride, n, out, G)
+  if (argc > 3 && argv[3][0] == 'k') {   // few write streams: does the compact front still pay? ("k" zeros, "kr" random)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 0, 4, 1, cu); RT(22, 0, 4, 1, 1, 0, cu, 2);
+      RW(22, 1, 4, 1, cu); RT(22, 1, 4, 1, 1, 0, cu, 1); RT(22, 1, 4, 1, 1, 0, cu, 2);
+      RW(22, 2, 4, 1, cu); RT(22, 2, 4, 1, 1, 0, cu, 1); RT(22, 2, 4, 1, 1, 0, cu, 2);
+      RW(22, 3, 4, 1, cu); RT(22, 3, 4, 1, 1, 0, cu, 1);
+      RW(42, 3, 4, 1, cu); RT(42, 3, 4, 1, 1, 0, cu, 1);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'j') {   // tile tickets: true nt vs plain vs sc1 stores ("j" zeros, "jr" random)
     for (int rep = 0; rep < 3; rep++) {
       RW(22, 5, 4, 0, cu); RW(22, 5, 4, 1, cu); RW(22, 5, 4, 2, cu);
