@@ -16,8 +16,11 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
   roofline     : PHYSICAL fractions only.  Top level = the dominant kernel (PB
                  k_combine): bytes that launch really moves (byte model confirmed by
                  the PMC passes under profiles/) / its mean duration over the timed
-                 steps (HIP events on the kernel stream) / 8 TB/s; `whole_update`
-                 = PA + scalar step + PB the same way; `kernels` per launch.  The
+                 steps (HIP events on the kernel stream; every timed update at the
+                 headline size, every 4th below 5e7 elements per GPU, where four
+                 event records would widen a 0.8 ms update by 2 %) / 8 TB/s;
+                 `whole_update` = PA + scalar step + PB the same way; `kernels`
+                 per launch.  The
                  contract's B_alg = 8n(11+L+2k) (a three-pass
                  schedule that moves more bytes than this one) appears only as
                  `contract_bytes_ratio` / `contract_GBps`, never as a fraction.
