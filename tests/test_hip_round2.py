@@ -342,3 +342,34 @@ def test_tile_tickets_soak(torch_cuda):
             outs.append(f)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), t
     assert accs[0].state_digest() == accs[1].state_digest() == accs[2].state_digest()
+
+
+@pytest.mark.parametrize("n", [64 * 256 * 512, 64 * 256 * 512 + 1, 64 * 256 * 512 + 1023, 64 * 256 * 512 + 513 * 1024 + 77])
+@pytest.mark.parametrize("flavor,m", [(2, 2), (0, 9)])
+def test_automatic_tickets_at_the_threshold_sizes(torch_cuda, flavor, m, n):
+    """At the sizes where the automatic rule switches the tickets on (64 tiles per
+    block), with and without a ragged tail, odd and even tile counts (double-width
+    tiles pair them up), the automatic choice must reproduce the static mapping bit
+    for bit."""
+    import nka_amd
+    torch = torch_cuda
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n % 1000 + m)
+    X = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1 for _ in range(m + 3)]
+    outs = []
+    for tickets in (0, -1):
+        acc = nka_amd.nka().init(n, m, flavor=flavor)
+        acc.set_tuning("pb_tickets", tickets)
+        if tickets == 0:
+            acc.set_tuning("pb_pipe", 201)
+            acc.set_tuning("pb_tile", 1)
+        res = []
+        for x in X:
+            f = x.clone()
+            acc.accel_update(f)
+            res.append(f)
+        outs.append((res, acc.state_digest()))
+        acc.delete()
+    for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert torch.equal(a, b), t
+    assert outs[0][1] == outs[1][1]
