@@ -298,6 +298,26 @@ int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, cons
                                  int32_t count, double *keep_in, double *keep_out);
 int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                                const double *const *xs, int32_t count, double *keep_in, double *keep_out);
+/* The scale-and-dot stage as a PURE READ, and the combine stage normalising the new pair itself
+ * ("pending pair": entry 0 of its lists is the raw pair the first call left untouched):
+ *   dot_pair_many_scaled:   with w' = a*(pre_a*f + w) [pre != 0; else a*w] formed in registers only:
+ *                           vals_w[j] = <w',ys[j]>, vals_f[j] = <f,ys[j]>, *cross = <f,w'> ; count <= 24
+ *   update_many_keep_pend:  update_many_keep with xs[0] = w, ys[0] = v rewritten on the way as
+ *                           w <- a*(pre_a*z_in + w) [pre], v <- a*v [, subtract: v <- (-1)*w + v]
+ *   axpy_many_keep_pend:    axpy_many_keep for compact storage: xs[0] = v, pend_w = w, subtract implied
+ * Same expressions as scale_dot_pair_many, hence the same bits; the new pair is read raw once more by
+ * the combine instead of being written and re-read normalised: 8n(10+3m) bytes, the scale-and-dot
+ * stage without a store stream. */
+int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre,
+                                     double pre_a, const double *f, const double *const *ys, int32_t count,
+                                     double *host_vals_w, double *host_vals_f, double *host_cross);
+int nka_hip_vec_update_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                                      const double *const *xs, const double *b, const double *const *ys,
+                                      int32_t count, double *keep_in, double *keep_out, double pend_a,
+                                      int32_t pend_pre, double pend_pre_a, int32_t pend_subtract);
+int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
+                                    const double *const *xs, int32_t count, double *keep_in, double *keep_out,
+                                    double *pend_w, double pend_a, int32_t pend_pre, double pend_pre_a);
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
 int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 

@@ -294,7 +294,10 @@ __global__ __launch_bounds__(kBlock) void k_update_norm2(int64_t n, double *z, c
 template <int NV, int VEC, bool SUB, bool PRE>
 __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, double *w, double *v, double a, double pre_a,
                                                                 const double *__restrict__ f, ManyArgs m,
-                                                                double *__restrict__ partials) {
+                                                                double *__restrict__ partials, int store) {
+  // store == 0: a PURE-READ pass -- the same sums, formed with the same a*(pre_a*f + w) in registers, but
+  // neither w nor v is written (v is not even read): the combine stage then normalises the pair itself
+  // (k_update_many_keep*, `Pend`).
   using V = typename VecT<VEC>::type;
   const int G = gridDim.x;
   double acc[2 * NV + 1];
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
   const int64_t ntile = n / (kBlock * VEC);
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    V wv = ld<VEC>(w + e), vv = ld<VEC>(v + e);
+    V wv = ld<VEC>(w + e), vv = store ? ld<VEC>(v + e) : wv;
     const V fv = ld<VEC>(f + e);
     V yv[NV];
 #pragma unroll
@@ -325,18 +328,22 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
         acc[NV + j] = fma(fq, ex(yv[j], q), acc[NV + j]);
       }
     }
-    st(w + e, wv);
-    st(v + e, vv);
+    if (store) {
+      st(w + e, wv);
+      st(v + e, vv);
+    }
   }
   if (blockIdx.x == G - 1)
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) {
       const double fq = f[i];
       const double w0 = PRE ? pre_a * fq + w[i] : w[i];
       const double wn = a * w0;
-      double vn = a * v[i];
-      if (SUB) vn = (-1.0) * wn + vn;
-      w[i] = wn;
-      v[i] = vn;
+      if (store) {
+        double vn = a * v[i];
+        if (SUB) vn = (-1.0) * wn + vn;
+        w[i] = wn;
+        v[i] = vn;
+      }
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
@@ -352,12 +359,34 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
 // z <- (a_j*x_j + b_j*y_j) + z for j in order (PAIRS; update3_, grid_vector_type.F90:151)
 // or z <- a_j*x_j + z (!PAIRS; update1_, :127), then keep_out <- z (v_new).
 // keep_in / keep_out may be NULL (groups of a list longer than one launch).
+// PENDING PAIR.  When the scale-and-dot stage ran as a pure read (k_scale_dot_pair_many*, store == 0),
+// entry 0 of the lists is the RAW new pair: w = w1 (not yet differenced when PRE) and v = v1.  The
+// combine then forms  wn = a*(pre_a*z_in + w)  [PRE; else a*w],  vn = a*v,  [SUB: vn = (-1)*wn + vn]
+// -- the very expressions of the scale-and-dot stage, z_in being f --, stores both, and combines
+// with them.  PAIRS: w = xs[0], v = ys[0].  !PAIRS (the v slots hold v - w): v = xs[0], w = pend.w.
+struct Pend {
+  double *w = nullptr;     // !PAIRS only: the w of the pending pair (PAIRS: xs[0])
+  double a = 0.0, pre_a = 0.0;
+  int flags = 0;           // 1 active, 2 PRE, 4 SUB
+};
+__device__ __forceinline__ void pend_normalise(const Pend &pd, double zin, double &w, double &v) {
+  const double w0 = (pd.flags & 2) ? pd.pre_a * zin + w : w;
+  const double wn = pd.a * w0;
+  double vn = pd.a * v;
+  if (pd.flags & 4) vn = (-1.0) * wn + vn;
+  w = wn;
+  v = vn;
+}
+
 template <int NV, int VEC, bool PAIRS>
 __global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *z, ManyArgs m, double *keep_in,
-                                                             double *keep_out) {
+                                                             double *keep_out, Pend pd) {
   using V = typename VecT<VEC>::type;
   const int G = gridDim.x;
   const int64_t ntile = n / (kBlock * VEC);
+  const bool pend = (pd.flags & 1) != 0 && m.count > 0;
+  double *const pw = PAIRS ? const_cast<double *>(m.x[0]) : pd.w;
+  double *const pv = PAIRS ? const_cast<double *>(m.y[0]) : const_cast<double *>(m.x[0]);
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     V zv = ld<VEC>(z + e);
@@ -367,8 +396,23 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *
       xv[j] = ld<VEC>((j < m.count ? m.x[j] : z) + e);
       if (PAIRS) yv[j] = ld<VEC>((j < m.count ? m.y[j] : z) + e);
     }
+    V pwv = zv;
+    if (!PAIRS && pend) pwv = ld<VEC>(pw + e);
     __builtin_amdgcn_sched_barrier(0);
     if (keep_in) st(keep_in + e, zv);
+    if (pend) {
+      V wq = PAIRS ? xv[0] : pwv, vq = PAIRS ? yv[0] : xv[0];
+#pragma unroll
+      for (int q = 0; q < VEC; q++) {
+        double w = ex(wq, q), v = ex(vq, q);
+        pend_normalise(pd, ex(zv, q), w, v);
+        setc(wq, q, w);
+        setc(vq, q, v);
+      }
+      st(pw + e, wq);
+      st(pv + e, vq);
+      if (PAIRS) { xv[0] = wq; yv[0] = vq; } else xv[0] = vq;
+    }
 #pragma unroll
     for (int j = 0; j < NV; j++)
       if (j < m.count)
@@ -386,7 +430,17 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep(int64_t n, double *
       if (keep_in) keep_in[i] = zi;
 #pragma unroll
       for (int j = 0; j < NV; j++)
-        if (j < m.count) zi = PAIRS ? (m.a[j] * m.x[j][i] + m.b[j] * m.y[j][i]) + zi : m.a[j] * m.x[j][i] + zi;
+        if (j < m.count) {
+          double x = m.x[j][i], y = PAIRS ? m.y[j][i] : 0.0;
+          if (j == 0 && pend) {
+            double w = PAIRS ? x : pw[i], v = PAIRS ? y : x;
+            pend_normalise(pd, zi, w, v);      // j == 0: zi is still the input
+            pw[i] = w;
+            pv[i] = v;
+            if (PAIRS) { x = w; y = v; } else x = v;
+          }
+          zi = PAIRS ? (m.a[j] * x + m.b[j] * y) + zi : m.a[j] * x + zi;
+        }
       if (keep_out) keep_out[i] = zi;
       z[i] = zi;
     }
@@ -411,7 +465,8 @@ constexpr int win_ring() {
 template <int NV, bool SUB, bool PRE, int kWin = win_ring<NV>()>
 __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, double *w, double *v, double a,
                                                                     double pre_a, const double *__restrict__ f,
-                                                                    ManyArgs m, double *__restrict__ partials) {
+                                                                    ManyArgs m, double *__restrict__ partials, int store) {
+  // store == 0: pure read, see k_scale_dot_pair_many
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   static_assert(NV % kWin == 0, "the ring must divide the unroll width");
@@ -428,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
   if (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     wv = ld<VEC>(w + e);
-    vv = ld<VEC>(v + e);
+    vv = store ? ld<VEC>(v + e) : wv;
     fv = ld<VEC>(f + e);
 #pragma unroll
     for (int j = 0; j < kWin; j++) ring[j] = ld<VEC>(ys[j] + e);
@@ -450,12 +505,14 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
       setc(vout, q, vn);
       acc[2 * NV] = fma(fq[q], wn[q], acc[2 * NV]);
     }
-    st(w + e, wout);
-    st(v + e, vout);
+    if (store) {
+      st(w + e, wout);
+      st(v + e, vout);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (tn != t) {                       // (on the last iteration w, v of this tile were just rewritten)
       wv = ld<VEC>(w + en);
-      vv = ld<VEC>(v + en);
+      if (store) vv = ld<VEC>(v + en);
     }
     fv = ld<VEC>(f + en);
 #pragma unroll
@@ -477,10 +534,12 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
       const double fq = f[i];
       const double w0 = PRE ? pre_a * fq + w[i] : w[i];
       const double wn = a * w0;
-      double vn = a * v[i];
-      if (SUB) vn = (-1.0) * wn + vn;
-      w[i] = wn;
-      v[i] = vn;
+      if (store) {
+        double vn = a * v[i];
+        if (SUB) vn = (-1.0) * wn + vn;
+        w[i] = wn;
+        v[i] = vn;
+      }
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
@@ -500,13 +559,18 @@ constexpr int win_ring_pairs() {
 
 template <int NV, bool PAIRS, int kWin = (PAIRS ? win_ring_pairs<NV>() : win_ring<NV>())>
 __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, double *z, ManyArgs m, double *keep_in,
-                                                                 double *keep_out, unsigned *tickets, int ng) {
+                                                                 double *keep_out, unsigned *tickets, int ng, Pend pd) {
   // `tickets` != nullptr: tiles from global ticket counters (compact front), as in k_combine_win
+  // `pd`: entry 0 is the raw pending pair, normalised here (see Pend)
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   static_assert(NV % kWin == 0, "the ring must divide the unroll width");
   __shared__ unsigned s_next[2];
   const int G = gridDim.x;
+  const bool pend = (pd.flags & 1) != 0 && m.count > 0;
+  double *const pw = PAIRS ? const_cast<double *>(m.x[0]) : pd.w;
+  double *const pv = PAIRS ? const_cast<double *>(m.y[0]) : const_cast<double *>(m.x[0]);
+  const double *const pwsrc = (!PAIRS && pend) ? pw : z;    // !PAIRS: the raw w of the pending pair, one more stream
   const double *xs[NV], *ys[PAIRS ? NV : 1];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -514,11 +578,12 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
     if (PAIRS) ys[j] = (j < m.count) ? m.y[j] : z;
   }
   const int64_t ntile = n / (kBlock * VEC);
-  V znext, rx[kWin], ry[PAIRS ? kWin : 1];
+  V znext, pwnext, rx[kWin], ry[PAIRS ? kWin : 1];
   int64_t t = blockIdx.x;
   if (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     znext = ld<VEC>(z + e);
+    if (!PAIRS) pwnext = ld<VEC>(pwsrc + e);
 #pragma unroll
     for (int j = 0; j < kWin; j++) {
       rx[j] = ld<VEC>(xs[j] + e);
@@ -538,13 +603,17 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
     const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
     const int64_t en = tn * (kBlock * VEC) + threadIdx.x * VEC;
     V zv = znext;
+    const V zin = zv, pwv = PAIRS ? zv : pwnext;
     if (keep_in) st(keep_in + e, zv);
     __builtin_amdgcn_sched_barrier(0);
-    if (tn != t) znext = ld<VEC>(z + en);
+    if (tn != t) {
+      znext = ld<VEC>(z + en);
+      if (!PAIRS) pwnext = ld<VEC>(pwsrc + en);
+    }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
-      const V xj = rx[j % kWin];
-      const V yj = ry[PAIRS ? j % kWin : 0];
+      V xj = rx[j % kWin];
+      V yj = ry[PAIRS ? j % kWin : 0];
       __builtin_amdgcn_sched_barrier(0);
       if (j + kWin < NV) {
         rx[j % kWin] = ld<VEC>(xs[j + kWin] + e);
@@ -554,6 +623,19 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
         if (PAIRS) ry[j % kWin] = ld<VEC>(ys[j + kWin - NV] + en);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (j == 0 && pend) {
+        V wq = PAIRS ? xj : pwv, vq = PAIRS ? yj : xj;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+          double w = ex(wq, q), v = ex(vq, q);
+          pend_normalise(pd, ex(zin, q), w, v);
+          setc(wq, q, w);
+          setc(vq, q, v);
+        }
+        st(pw + e, wq);
+        st(pv + e, vq);
+        if (PAIRS) { xj = wq; yj = vq; } else xj = vq;
+      }
       if (j < m.count) {
 #pragma unroll
         for (int q = 0; q < VEC; q++) {
@@ -575,7 +657,17 @@ __global__ __launch_bounds__(kBlock) void k_update_many_keep_win(int64_t n, doub
       if (keep_in) keep_in[i] = zi;
 #pragma unroll
       for (int j = 0; j < NV; j++)
-        if (j < m.count) zi = PAIRS ? (m.a[j] * m.x[j][i] + m.b[j] * m.y[j][i]) + zi : m.a[j] * m.x[j][i] + zi;
+        if (j < m.count) {
+          double x = m.x[j][i], y = PAIRS ? m.y[j][i] : 0.0;
+          if (j == 0 && pend) {
+            double w = PAIRS ? x : pw[i], v = PAIRS ? y : x;
+            pend_normalise(pd, zi, w, v);      // j == 0: zi is still the input
+            pw[i] = w;
+            pv[i] = v;
+            if (PAIRS) { x = w; y = v; } else x = v;
+          }
+          zi = PAIRS ? (m.a[j] * x + m.b[j] * y) + zi : m.a[j] * x + zi;
+        }
       if (keep_out) keep_out[i] = zi;
       z[i] = zi;
     }
@@ -658,11 +750,15 @@ int run_elementwise(nka_hip_vec_ws *ws, int64_t n, double *z, const double *x, c
 namespace {
 template <bool PAIRS>
 int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs, const double *b,
-                     const double *const *ys, int32_t count, double *keep_in, double *keep_out, const char *who) {
+                     const double *const *ys, int32_t count, double *keep_in, double *keep_out, const char *who,
+                     Pend pend = Pend()) {
   if (!ws || n < 0 || count < 0 || (count > 0 && (!a || !xs || (PAIRS && (!b || !ys)))))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if ((pend.flags & 1) && (count < 1 || (!PAIRS && !pend.w)))
+    return nka_detail::set_error(NKA_HIP_EINVAL, "pending pair: entry 0 of the lists (and its w) must be given");
   if (n == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if ((pend.flags & 1) && !PAIRS) if (int rc = nka_detail::check_device_span(pend.w, n, who)) return rc;
   if (int rc = nka_detail::check_device_span(z, n, who)) return rc;
   if (keep_in) if (int rc = nka_detail::check_device_span(keep_in, n, who)) return rc;
   if (keep_out) if (int rc = nka_detail::check_device_span(keep_out, n, who)) return rc;
@@ -687,18 +783,20 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
         v2 = v2 && al16(m.y[j]);
       }
     }
+    Pend pd = (base == 0) ? pend : Pend();     // the pending pair is entry 0 of the first launch
+    if ((pd.flags & 1) && !PAIRS) v2 = v2 && al16(pd.w);
     const bool win = v2 && use_win();
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernels: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
     // tile tickets (k_combine_win): one counter while a tile carries >= 22 words per element, else two
-    const int words = (PAIRS ? 2 : 1) * nv + 1 + 1 + (kin ? 1 : 0) + (kout ? 1 : 0);
+    const int words = (PAIRS ? 2 : 1) * nv + 1 + 1 + (kin ? 1 : 0) + (kout ? 1 : 0) + ((pd.flags & 1) ? (PAIRS ? 2 : 3) : 0);
     int ng = ws->ticket_groups;
     if (ng < 0) ng = (win && n / (kBlock * 2) >= (int64_t)64 * g) ? (words >= 22 ? 1 : 2) : 0;
     if (!win || !ws->tickets || g % std::max(ng, 1) != 0 || n / (kBlock * 2) >= ((int64_t)1 << 31) - 2 * kMaxGrid) ng = 0;
     unsigned *const tix = ng > 0 ? ws->tickets : nullptr;
-#define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, tix, std::max(ng, 1))
-#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
-#define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout)
+#define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, tix, std::max(ng, 1), pd)
+#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, pd)
+#define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, pd)
     if (win) { NKA_DISPATCH_EXACT(nv, LAUNCHW) } else if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCHW
 #undef LAUNCH2
@@ -1018,9 +1116,30 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
 // [pre != 0: w <- pre_a*f + w ;] w <- a*w ; v <- a*v (subtract != 0: then v <- (-1)*w + v) ;
 // with the new w: vals_w[j] = <w, ys[j]>, vals_f[j] = <f, ys[j]>, *cross = <f, w>.  One pass
 // when count <= 24; longer lists scale in the first launch and only add dots after it.
+static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
+                                    int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
+                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store);
+
 int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
                                     double *host_vals_w, double *host_vals_f, double *host_cross) {
+  return scale_dot_pair_many_impl(ws, n, w, v, a, subtract, pre, pre_a, f, ys, count, host_vals_w, host_vals_f, host_cross, 1);
+}
+
+// The same sums with NOTHING stored: w stays as it is (raw, or already differenced when pre == 0),
+// v is not touched; the caller hands (w, v, a, pre, pre_a) to nka_hip_vec_update_many_keep_pend /
+// nka_hip_vec_axpy_many_keep_pend, which normalise the pair while they combine.  count <= 24.
+int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
+                                     const double *f, const double *const *ys, int32_t count, double *host_vals_w,
+                                     double *host_vals_f, double *host_cross) {
+  if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_dot_pair_many_scaled: more than 24 vectors");
+  return scale_dot_pair_many_impl(ws, n, const_cast<double *>(w), const_cast<double *>(w), a, 0, pre, pre_a, f, ys, count,
+                                  host_vals_w, host_vals_f, host_cross, 0);
+}
+
+static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
+                                    int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
+                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store) {
   if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals_w || !host_vals_f)))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_cross = 0.0;
@@ -1045,10 +1164,10 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : nv + 3);   // rolling-window kernel: one block per CU
 #define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
   hipLaunchKernelGGL((k_scale_dot_pair_many<NV, VEC, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
-                     ws->partials)
+                     ws->partials, store)
 #define NKA_SDPMW(NV, SUB, PRE)                                                                                  \
   hipLaunchKernelGGL((k_scale_dot_pair_many_win<NV, SUB, PRE>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, \
-                     ws->partials)
+                     ws->partials, store)
 #define LWSP(NV) NKA_SDPMW(NV, true, true)
 #define LWSN(NV) NKA_SDPMW(NV, true, false)
 #define LWNP(NV) NKA_SDPMW(NV, false, true)
@@ -1114,6 +1233,33 @@ int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, cons
 int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
                                int32_t count, double *keep_in, double *keep_out) {
   return update_many_keep<false>(ws, n, z, a, xs, nullptr, nullptr, count, keep_in, keep_out, "vec_axpy_many_keep");
+}
+
+// The same with entry 0 of the lists being the RAW new pair, normalised on the way (see Pend): after
+// nka_hip_vec_dot_pair_many_scaled, which left it untouched.  xs[0] = w1, ys[0] = v1 are rewritten with
+//   w1 <- a*(pre_a*z_in + w1)  [pre != 0; else a*w1] ,  v1 <- a*v1 ,  [subtract != 0: v1 <- (-1)*w1 + v1].
+int nka_hip_vec_update_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                                      const double *b, const double *const *ys, int32_t count, double *keep_in,
+                                      double *keep_out, double pend_a, int32_t pend_pre, double pend_pre_a,
+                                      int32_t pend_subtract) {
+  Pend pd;
+  pd.a = pend_a;
+  pd.pre_a = pend_pre_a;
+  pd.flags = 1 | (pend_pre ? 2 : 0) | (pend_subtract ? 4 : 0);
+  return update_many_keep<true>(ws, n, z, a, xs, b, ys, count, keep_in, keep_out, "vec_update_many_keep_pend", pd);
+}
+
+// Compact storage (the v slots hold v - w): xs[0] = v1 raw, pend_w = w1 raw; rewritten with
+//   w1 <- a*(pre_a*z_in + w1)  [pre != 0; else a*w1] ,  v1 <- (-1)*w1 + a*v1 .
+int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a, const double *const *xs,
+                                    int32_t count, double *keep_in, double *keep_out, double *pend_w, double pend_a,
+                                    int32_t pend_pre, double pend_pre_a) {
+  Pend pd;
+  pd.w = pend_w;
+  pd.a = pend_a;
+  pd.pre_a = pend_pre_a;
+  pd.flags = 1 | (pend_pre ? 2 : 0) | 4;
+  return update_many_keep<false>(ws, n, z, a, xs, nullptr, nullptr, count, keep_in, keep_out, "vec_axpy_many_keep_pend", pd);
 }
 
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host) {

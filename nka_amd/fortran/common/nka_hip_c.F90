@@ -249,6 +249,36 @@ module nka_hip_c
       type(c_ptr), intent(in) :: xs(*)
       integer(c_int32_t), value :: count
     end function
+    integer(c_int) function nka_hip_vec_dot_pair_many_scaled(ws, n, w, a, pre, pre_a, f, ys, count, &
+                                                             vals_w, vals_f, cross) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, w, f
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a, pre_a
+      integer(c_int32_t), value :: pre, count
+      type(c_ptr), intent(in) :: ys(*)
+      real(c_double), intent(out) :: vals_w(*), vals_f(*), cross
+    end function
+    integer(c_int) function nka_hip_vec_update_many_keep_pend(ws, n, z, a, xs, b, ys, count, keep_in, keep_out, &
+                                                              pend_a, pend_pre, pend_pre_a, pend_subtract) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, keep_in, keep_out
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*), b(*)
+      type(c_ptr), intent(in) :: xs(*), ys(*)
+      integer(c_int32_t), value :: count, pend_pre, pend_subtract
+      real(c_double), value :: pend_a, pend_pre_a
+    end function
+    integer(c_int) function nka_hip_vec_axpy_many_keep_pend(ws, n, z, a, xs, count, keep_in, keep_out, &
+                                                            pend_w, pend_a, pend_pre, pend_pre_a) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, keep_in, keep_out, pend_w
+      integer(c_int64_t), value :: n
+      real(c_double), intent(in) :: a(*)
+      type(c_ptr), intent(in) :: xs(*)
+      integer(c_int32_t), value :: count, pend_pre
+      real(c_double), value :: pend_a, pend_pre_a
+    end function
     integer(c_int) function nka_hip_vec_h2d(ws, n, dst_dev, src_host) bind(C)
       import :: c_int, c_int64_t, c_ptr, c_double
       type(c_ptr), value :: ws, dst_dev

@@ -200,3 +200,86 @@ def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, s
         assert np.array_equal(kin.cpu().numpy(), f)
         assert np.array_equal(zd.cpu().numpy(), ref)
         assert np.array_equal(kout.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("unaligned", [0, 1])
+@pytest.mark.parametrize("n,count,pre,tickets", [(1, 1, 1, -1), (513, 1, 0, -1), (4099, 4, 1, -1), (100003, 21, 1, -1),
+                                                 (100003, 24, 0, -1), (300007, 7, 1, 1), (1100003, 21, 1, 2),
+                                                 (777, 23, 1, -1)])
+def test_deferred_normalisation_equals_the_storing_stages(ws, n, count, pre, tickets, unaligned):
+    """The scale-and-dot stage as a pure read (dot_pair_many_scaled) followed by a
+    combine that normalises the pending pair itself (update_many_keep_pend /
+    axpy_many_keep_pend) must leave EVERY bit where the storing stages
+    (scale_dot_pair_many, then update_many_keep / axpy_many_keep) leave it: the new
+    pair, f, both kept copies, and the three rows of inner products.  `count` counts
+    the pending pair; 16-byte path and (unaligned = 1) the 8-byte fallback; with
+    the tiles of the combine taken from ticket counters where the size allows."""
+    L, h, torch = ws
+    rng = np.random.default_rng(11 * n + count + pre)
+    dp = C.POINTER(C.c_double)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    off = unaligned
+
+    def dev(a):                      # a device copy whose data pointer is 8 (not 16) bytes aligned when asked
+        t = torch.empty(a.size + 1, dtype=torch.float64, device="cuda")
+        t[off:off + a.size] = torch.from_numpy(a)
+        return t[off:off + a.size]
+
+    f = rng.standard_normal(n)
+    w1, v1 = rng.standard_normal(n), rng.standard_normal(n)
+    nold = count - 1
+    Wo, Vo = rng.standard_normal((max(nold, 1), n)), rng.standard_normal((max(nold, 1), n))
+    s = float(np.linalg.norm(-1.0 * f + w1)) if pre else float(np.linalg.norm(w1))
+    a = 1.0 / s
+    ca, cb = rng.standard_normal(count), rng.standard_normal(count)
+    assert L.nka_hip_vec_set_tuning(h, b"tickets", tickets) == 0
+    for compact in (0, 1):
+        res = []
+        for deferred in (0, 1):
+            fd, w1d, v1d = dev(f), dev(w1), dev(v1)
+            Wd = [dev(Wo[j]) for j in range(nold)]
+            Vd = [dev(Vo[j]) for j in range(nold)]
+            kin, kout = dev(np.zeros(n)), dev(np.zeros(n))
+            ys = (C.c_void_p * max(nold, 1))(*[t.data_ptr() for t in Wd])
+            vw, vf, cross = np.zeros(max(nold, 1)), np.zeros(max(nold, 1)), C.c_double()
+            if deferred:
+                assert L.nka_hip_vec_dot_pair_many_scaled(h, n, P(w1d), a, pre, -1.0, P(fd), ys, nold,
+                                                          vw.ctypes.data_as(dp), vf.ctypes.data_as(dp), C.byref(cross)) == 0
+                assert np.array_equal(w1d.cpu().numpy(), w1) and np.array_equal(v1d.cpu().numpy(), v1)   # untouched
+            else:
+                assert L.nka_hip_vec_scale_dot_pair_many(h, n, P(w1d), P(v1d), a, compact, pre, -1.0, P(fd), ys, nold,
+                                                         vw.ctypes.data_as(dp), vf.ctypes.data_as(dp), C.byref(cross)) == 0
+            # the combine over the whole list, newest (the pending pair) first
+            if compact:
+                xs = (C.c_void_p * count)(*([v1d.data_ptr()] + [t.data_ptr() for t in Vd]))
+                if deferred:
+                    assert L.nka_hip_vec_axpy_many_keep_pend(h, n, P(fd), ca.ctypes.data_as(dp), xs, count, P(kin), P(kout),
+                                                             P(w1d), a, pre, -1.0) == 0
+                else:
+                    assert L.nka_hip_vec_axpy_many_keep(h, n, P(fd), ca.ctypes.data_as(dp), xs, count, P(kin), P(kout)) == 0
+            else:
+                xs = (C.c_void_p * count)(*([w1d.data_ptr()] + [t.data_ptr() for t in Wd]))
+                yv = (C.c_void_p * count)(*([v1d.data_ptr()] + [t.data_ptr() for t in Vd]))
+                if deferred:
+                    assert L.nka_hip_vec_update_many_keep_pend(h, n, P(fd), ca.ctypes.data_as(dp), xs, cb.ctypes.data_as(dp),
+                                                               yv, count, P(kin), P(kout), a, pre, -1.0, 0) == 0
+                else:
+                    assert L.nka_hip_vec_update_many_keep(h, n, P(fd), ca.ctypes.data_as(dp), xs, cb.ctypes.data_as(dp), yv,
+                                                          count, P(kin), P(kout)) == 0
+            res.append([t.cpu().numpy() for t in (w1d, v1d, fd, kin, kout)] + [vw.copy(), vf.copy(), np.array([cross.value])])
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y), (compact, np.abs(x - y).max())
+        # and against the expressions themselves (numpy: IEEE, left to right, no FMA)
+        d = -1.0 * f + w1 if pre else w1
+        wn = a * d
+        vn = a * v1
+        if compact:
+            vn = -1.0 * wn + vn
+        assert np.array_equal(res[1][0], wn) and np.array_equal(res[1][1], vn)
+        ref = f.copy()
+        for j in range(count):
+            xj = (vn if j == 0 else Vo[j - 1]) if compact else (wn if j == 0 else Wo[j - 1])
+            yj = vn if j == 0 else Vo[j - 1]
+            ref = ca[j] * xj + ref if compact else (ca[j] * xj + cb[j] * yj) + ref
+        assert np.array_equal(res[1][2], ref) and np.array_equal(res[1][3], f) and np.array_equal(res[1][4], ref)
+    assert L.nka_hip_vec_set_tuning(h, b"tickets", -1) == 0
