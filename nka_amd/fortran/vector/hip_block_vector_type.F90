@@ -365,7 +365,7 @@ contains
 
   !! [apply the deferred update,] scale both members of the new pair and take both
   !! inner-product rows while the stored vectors stream past once (R (3+L)n, W 2n).
-  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a)
+  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled)
     class(hip_block_vector), intent(inout) :: this
     class(vector), intent(inout) :: v
     real(r8), intent(in) :: a
@@ -375,7 +375,9 @@ contains
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
     real(r8), intent(in), optional :: pre_a
+    logical, intent(out), optional :: scaled
     type(c_ptr) :: ptrs(max(size(idx),1))
+    logical :: defer
     integer :: j
     integer(c_int32_t) :: pre
     integer(c_int64_t) :: nt
@@ -395,6 +397,15 @@ contains
           do j = 1, size(idx)
             ptrs(j) = ys(idx(j))%base
           end do
+          !! Asked whether it stored, and the list fits one launch: a PURE-READ pass (R (2+L)n, no
+          !! store stream); the pair is normalised by the combine stage, which reads it anyway.
+          defer = present(scaled) .and. size(idx) <= 24 .and. defer_scale_enabled()
+          if (present(scaled)) scaled = .not. defer
+          if (defer) then
+            call nka_hip_check(nka_hip_vec_dot_pair_many_scaled(this%ws, this%nred, this%base, a, pre, pa, f%base, ptrs, &
+                               size(idx, kind=c_int32_t), vals_this, vals_f, cross), 'vec_dot_pair_many_scaled')
+            return
+          end if
           call nka_hip_check(nka_hip_vec_scale_dot_pair_many(this%ws, this%nred, this%base, v%base, a, &
                              merge(1_c_int32_t, 0_c_int32_t, subtract), pre, pa, f%base, ptrs, &
                              size(idx, kind=c_int32_t), vals_this, vals_f, cross), 'vec_scale_dot_pair_many')
@@ -415,14 +426,26 @@ contains
 
   !! keep_in <- this ; combine ; keep_out <- this, `this` read once and written once
   !! (R (1+2k)n, W 3n).
-  subroutine update_many_keep_fused(this, a, xs, b, ys, idx, keep_in, keep_out)
+  subroutine update_many_keep_fused(this, a, xs, b, ys, idx, keep_in, keep_out, pend_a, pend_pre_a, pend_subtract)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a(:), b(:)
     class(vector), intent(in) :: xs(:), ys(:)
     integer, intent(in) :: idx(:)
     class(vector), intent(inout) :: keep_in, keep_out
+    real(r8), intent(in), optional :: pend_a, pend_pre_a
+    logical, intent(in), optional :: pend_subtract
     type(c_ptr) :: xp(max(size(idx),1)), yp(max(size(idx),1))
     integer :: j
+    integer(c_int32_t) :: ppre, psub
+    real(r8) :: ppa
+    ppre = 0
+    ppa = 0.0_r8
+    psub = 0
+    if (present(pend_pre_a)) then
+      ppre = 1
+      ppa = pend_pre_a
+    end if
+    if (present(pend_subtract)) psub = merge(1_c_int32_t, 0_c_int32_t, pend_subtract)
     select type (xs)
     class is (hip_block_vector)
       select type (ys)
@@ -435,15 +458,28 @@ contains
               xp(j) = xs(idx(j))%base
               yp(j) = ys(idx(j))%base
             end do
-            call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%nred, this%base, a, xp, b, yp, &
-                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_update_many_keep')
+            if (present(pend_a)) then      ! entry 1 is the raw new pair: normalised on the way
+              call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%nred, this%base, a, xp, b, yp, &
+                                 size(idx, kind=c_int32_t), keep_in%base, keep_out%base, pend_a, ppre, ppa, psub), &
+                                 'vec_update_many_keep_pend')
+            else
+              call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%nred, this%base, a, xp, b, yp, &
+                                 size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_update_many_keep')
+            end if
             if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
               do j = 1, size(idx)
                 xp(j) = tail_ptr(xs(idx(j)))
                 yp(j) = tail_ptr(ys(idx(j)))
               end do
-              call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, b, yp, &
-                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_update_many_keep')
+              if (present(pend_a)) then
+                call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                                   b, yp, size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out), pend_a, ppre, &
+                                   ppa, psub), 'vec_update_many_keep_pend')
+              else
+                call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, b, &
+                                   yp, size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), &
+                                   'vec_update_many_keep')
+              end if
             end if
             return
           end select
@@ -453,14 +489,35 @@ contains
     error stop 'incompatible arguments to VECTOR%UPDATE_MANY_KEEP'
   end subroutine
 
-  subroutine axpy_many_keep_fused(this, a, xs, idx, keep_in, keep_out)
+  subroutine axpy_many_keep_fused(this, a, xs, idx, keep_in, keep_out, pend_w, pend_a, pend_pre_a)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a(:)
     class(vector), intent(in) :: xs(:)
     integer, intent(in) :: idx(:)
     class(vector), intent(inout) :: keep_in, keep_out
-    type(c_ptr) :: xp(max(size(idx),1))
+    class(vector), intent(in), optional :: pend_w
+    real(r8), intent(in), optional :: pend_a, pend_pre_a
+    type(c_ptr) :: xp(max(size(idx),1)), pw, pwt
     integer :: j
+    integer(c_int32_t) :: ppre
+    real(r8) :: ppa
+    ppre = 0
+    ppa = 0.0_r8
+    if (present(pend_pre_a)) then
+      ppre = 1
+      ppa = pend_pre_a
+    end if
+    pw = c_null_ptr
+    pwt = c_null_ptr
+    if (present(pend_w)) then
+      select type (pend_w)
+      class is (hip_block_vector)
+        pw = pend_w%base
+        pwt = tail_ptr(pend_w)
+      class default
+        error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
+      end select
+    end if
     select type (xs)
     class is (hip_block_vector)
       select type (keep_in)
@@ -470,14 +527,26 @@ contains
           do j = 1, size(idx)
             xp(j) = xs(idx(j))%base
           end do
-          call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%nred, this%base, a, xp, &
-                             size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_axpy_many_keep')
+          if (present(pend_w) .and. present(pend_a)) then   ! entry 1 is the raw v of the new pair, pend_w its raw w
+            call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%nred, this%base, a, xp, &
+                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base, pw, pend_a, ppre, ppa), &
+                               'vec_axpy_many_keep_pend')
+          else
+            call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%nred, this%base, a, xp, &
+                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_axpy_many_keep')
+          end if
           if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
             do j = 1, size(idx)
               xp(j) = tail_ptr(xs(idx(j)))
             end do
-            call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
-                               size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_axpy_many_keep')
+            if (present(pend_w) .and. present(pend_a)) then
+              call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out), pwt, pend_a, ppre, ppa), &
+                                 'vec_axpy_many_keep_pend')
+            else
+              call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_axpy_many_keep')
+            end if
           end if
           return
         end select
@@ -485,5 +554,18 @@ contains
     end select
     error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
   end subroutine
+
+  !! NKA_HIP_VEC_DEFER_SCALE=0: scale_dot_pair_many always stores (A/B aid; read once)
+  logical function defer_scale_enabled()
+    logical, save :: known = .false., on = .true.
+    character(len=8) :: val
+    integer :: stat
+    if (.not. known) then
+      call get_environment_variable('NKA_HIP_VEC_DEFER_SCALE', val, status=stat)
+      if (stat == 0) on = .not. (val(1:1) == '0')
+      known = .true.
+    end if
+    defer_scale_enabled = on
+  end function
 
 end module hip_block_vector_type

@@ -230,10 +230,11 @@ contains
     class(vector), intent(inout) :: f
     real(r8) :: s, c(this%mvec+1), vals(this%mvec+1), bvals(this%mvec+1), cross
     integer :: k, slot, idx(this%mvec+1), nidx, j
-    logical :: have_rows, stored
+    logical :: have_rows, stored, scaled
 
     have_rows = .false.
     stored = .true.
+    scaled = .true.
     if (this%pending) then
       s = this%w(this%first)%update_norm2(-1.0_r8, f, stored)   ! s = ||w1 - f|| ; w1 <- w1 - f now or in the next stage   F08V:237-238
       if (s == 0.0_r8) call this%relax                       ! nothing to learn from a zero difference
@@ -252,12 +253,15 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
+      !! (`scaled` comes back .false. when the vector type took the rows in a pure-read pass and left
+      !!  the normalisation itself to the combine stage below, which reads the pair anyway)
       if (stored) then
         call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
-                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross)
+                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, scaled=scaled)
       else                                                   ! the norm stage left w1 <- w1 - f to this one
         call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
-                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, pre_a=-1.0_r8)
+                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, pre_a=-1.0_r8, &
+                                                    scaled=scaled)
       end if
       c(this%first) = cross
       do j = 1, nidx
@@ -291,10 +295,27 @@ contains
       end do
       !! w_new <- f (F08V:336) ; f <- f - c w + c v for every k in list order (F08V:374) ;
       !! v_new <- f (F08V:382): one stage
+      !! (a pair left un-normalised above is entry 1 = this%first of the lists: never dropped)
       if (this%compact) then                                 ! v slots hold v - w: f <- f + c*(v - w)
-        call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+        if (scaled) then
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+        else if (stored) then
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+                                pend_w=this%w(idx(1)), pend_a=1.0_r8/s)
+        else
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+                                pend_w=this%w(idx(1)), pend_a=1.0_r8/s, pend_pre_a=-1.0_r8)
+        end if
       else
-        call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+        if (scaled) then
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+        else if (stored) then
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+                                  pend_a=1.0_r8/s, pend_subtract=.false.)
+        else
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+                                  pend_a=1.0_r8/s, pend_pre_a=-1.0_r8, pend_subtract=.false.)
+        end if
       end if
     else
       call this%w(slot)%copy(f)                              ! no subspace yet: f is returned unchanged

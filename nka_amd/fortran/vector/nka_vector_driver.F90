@@ -288,13 +288,15 @@ contains
                                        ' compact=', compact
     end if
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
-    !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector
-    !! 8n(11+3m) = the contract figure (compact option: 8n(11+2m))
+    !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector (norm stage
+    !! and scale-and-dot stage pure reads, the combine normalising the new pair itself) 8n(10+3m), one
+    !! word per element below the contract figure 8n(11+3m); compact option: 8n(11+2m)
     if (compact) then
       write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks compact (8n(11+2m)) ', 8.0_r8*n*(11+2*mvec)/per/1e9_r8, &
                                    '   contract GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
     else
-      write(*,'(a,f10.1)') 'moved GB/s, stage hooks = contract bytes (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
+      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks (8n(10+3m)) ', 8.0_r8*n*(10+3*mvec)/per/1e9_r8, &
+                                   '   contract GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
     end if
     write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by contract bytes 8n(11+3m) ', &
                         8.0_r8*n*(11+3*mvec)/per/8.0e12_r8

@@ -274,7 +274,13 @@ contains
   !!   [pre_a present: this <- pre_a*f + this, the update update_norm2 did not store ;]
   !!   v <- a*v ; this <- a*this ; [subtract: v <- v - this] ;
   !!   vals_this(j) = <this, ys(idx(j))>, vals_f(j) = <f, ys(idx(j))>, cross = <f, this>.
-  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a)
+  !! `scaled` (optional, like `stored` of update_norm2): .true. = this default, `this` and v now HOLD
+  !! the normalised pair; an override may answer .false. after a PURE-READ pass that only formed
+  !! a*(pre_a*f + this) in registers for the inner products -- the caller then passes the pending
+  !! normalisation (pend_a, pend_pre_a, pend_subtract[, pend_w]) to the combine stage, whose
+  !! override applies it to entry 1 of its lists while it combines (a type that answers .false.
+  !! must override update_many_keep / axpy_many_keep accordingly).
+  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled)
     class(vector), intent(inout) :: this, v
     real(r8), intent(in) :: a
     logical, intent(in) :: subtract
@@ -283,33 +289,48 @@ contains
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
     real(r8), intent(in), optional :: pre_a
+    logical, intent(out), optional :: scaled
     if (present(pre_a)) call this%update(pre_a, f)
     call v%scale(a)
     call this%scale(a)
     if (subtract) call v%update(-1.0_r8, this)
     call this%dot_pair_many(f, ys, idx, vals_this, vals_f, cross)
+    if (present(scaled)) scaled = .true.
   end subroutine
 
   !! keep_in <- this ; this <- this + sum_j (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) in
   !! order ; keep_out <- this  (F08V:336, 374, 382).
-  subroutine update_many_keep(this, a, xs, b, ys, idx, keep_in, keep_out)
+  !! pend_a present: xs(idx(1)), ys(idx(1)) are the RAW new pair that a pure-read scale_dot_pair_many
+  !! left untouched; the override normalises them on the way (see there).  Never passed to a type
+  !! whose scale_dot_pair_many stores (this default).
+  subroutine update_many_keep(this, a, xs, b, ys, idx, keep_in, keep_out, pend_a, pend_pre_a, pend_subtract)
     class(vector), intent(inout) :: this
     real(r8), intent(in) :: a(:), b(:)
     class(vector), intent(in) :: xs(:), ys(:)
     integer, intent(in) :: idx(:)
     class(vector), intent(inout) :: keep_in, keep_out
+    real(r8), intent(in), optional :: pend_a, pend_pre_a
+    logical, intent(in), optional :: pend_subtract
+    if (present(pend_a) .or. present(pend_pre_a) .or. present(pend_subtract)) &
+      error stop 'VECTOR%UPDATE_MANY_KEEP: a pending normalisation needs an override that applies it'
     call keep_in%copy(this)
     call this%update_many(a, xs, b, ys, idx)
     call keep_out%copy(this)
   end subroutine
 
   !! keep_in <- this ; this <- this + sum_j a(j)*xs(idx(j)) in order ; keep_out <- this.
-  subroutine axpy_many_keep(this, a, xs, idx, keep_in, keep_out)
+  !! (pend_w, pend_a[, pend_pre_a]): the pending normalisation, compact storage -- xs(idx(1)) is the raw v
+  !! of the new pair, pend_w its raw w; see update_many_keep.
+  subroutine axpy_many_keep(this, a, xs, idx, keep_in, keep_out, pend_w, pend_a, pend_pre_a)
     class(vector), intent(inout) :: this
     real(r8), intent(in) :: a(:)
     class(vector), intent(in) :: xs(:)
     integer, intent(in) :: idx(:)
     class(vector), intent(inout) :: keep_in, keep_out
+    class(vector), intent(in), optional :: pend_w
+    real(r8), intent(in), optional :: pend_a, pend_pre_a
+    if (present(pend_w) .or. present(pend_a) .or. present(pend_pre_a)) &
+      error stop 'VECTOR%AXPY_MANY_KEEP: a pending normalisation needs an override that applies it'
     call keep_in%copy(this)
     call this%axpy_many(a, xs, idx)
     call keep_out%copy(this)
