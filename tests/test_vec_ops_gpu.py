@@ -204,7 +204,7 @@ def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, s
 
 @pytest.mark.parametrize("unaligned", [0, 1])
 @pytest.mark.parametrize("n,count,pre,tickets", [(1, 1, 1, -1), (513, 1, 0, -1), (4099, 4, 1, -1), (100003, 21, 1, -1),
-                                                 (100003, 24, 0, -1), (300007, 7, 1, 1), (1100003, 21, 1, 2),
+                                                 (100003, 24, 0, -1), (100003, 25, 1, -1), (300007, 7, 1, 1), (1100003, 21, 1, 2),
                                                  (777, 23, 1, -1)])
 def test_deferred_normalisation_equals_the_storing_stages(ws, n, count, pre, tickets, unaligned):
     """The scale-and-dot stage as a pure read (dot_pair_many_scaled) followed by a
