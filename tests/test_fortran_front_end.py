@@ -50,7 +50,8 @@ def test_config1_through_fortran_front_end_on_gpu(fortran_build, args, key, flav
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("compact", [0, 1])
-@pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45)])
+@pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45),
+                                                     (4, 25003, 30, 50)])   # (lists beyond one launch: the stages store)
 def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, tmp_path, nfield, nper, mvec, ncalls,
                                                         compact):
     """vector_class hooks on a device-resident block vector, driven by the
@@ -69,6 +70,29 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
         assert nv == ora.num_vec(), (t, nv, ora.num_vec())
         P.check(S.rel_err(got, f, x), ora.state(),
                 f"abstract vector {nfield}x{nper} m={mvec} compact={compact} vs oracle F08-vector", where=t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("mode,dims,mvec,ncalls", [("check", (4, 2503), 20, 45), ("check", (4, 25003), 30, 50),
+                                                   ("checkgrid", (33, 17), 20, 45), ("checkgrid", (7, 5), 3, 14)])
+def test_deferred_normalisation_through_the_front_end_is_bit_identical(fortran_build, tmp_path, mode, dims, mvec, ncalls,
+                                                                       compact):
+    """The block vector's scale-and-dot stage as a pure read with the combine stage
+    normalising the new pair (the default) against the storing stages
+    (NKA_HIP_VEC_DEFER_SCALE=0): the vector flavour of the accelerator must return
+    the same bits call after call -- block vector and grid vector (whose ghost ring
+    takes the tail path), lists within and beyond one launch."""
+    outs = []
+    for defer in ("0", "1"):
+        out = tmp_path / f"defer{defer}.bin"
+        env = dict(os.environ, NKA_HIP_VEC_DEFER_SCALE=defer)
+        p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), mode, str(dims[0]), str(dims[1]),
+                            str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300,
+                           env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
 
 
 @pytest.mark.gpu
