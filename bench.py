@@ -26,12 +26,20 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  `contract_bytes_ratio` / `contract_GBps`, never as a fraction.
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
                  oracle port timed on this box's host on a bounded sample.
+                 `device_time_stats_ms`: mean / median / min / max of the per-update
+                 device times; `probe_ceiling`: the repo's own streaming
+                 probe (tools/hbm_probe: pure read, pure write, PB's read/write mixes)
+                 run as a child process after the timed region of the SAME run.
+  value        : the flavour the drop-in front ends run BY DEFAULT (`call a%init(vlen,
+                 mvec)` of the Fortran module, nka_init of the F95 one, nka().init in
+                 Python: NKA_HIP_FLAVOR_DEFAULT = compact storage, the src-C statement of
+                 the combine; include/nka_hip.h).  `config.flavor_is_front_end_default`
+                 says so; --flavor / NKA_HIP_FLAVOR select another one.
   also_f08_rounding : the same workload and protocol measured a second time in
-                 the same run with the src-F08 rounding and two stored vectors per
-                 pair.  The headline `value` mirrors the src-C rounding of the
-                 combine with compact storage; both are checked
-                 against the compiled src-F08 reference in tests/ (decisions exact,
-                 values within the stated tolerance).
+                 the same run with the src-F08 statement bit for bit (flavor=F08: two
+                 stored vectors per pair).  Both are checked against the compiled
+                 src-F08 reference in tests/ (decisions exact, values within the stated
+                 tolerance).
   config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
                  src-F08-vector abstract path through the Fortran vector flavour on
                  the device block vector, measured by nka_vector_driver in a child
@@ -67,8 +75,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the abstract-vector (BASELINE configs[4]) extra")
     ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")
-    ap.add_argument("--flavor", choices=["c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "c"),
-                    help="which reference rounding is mirrored; 'c' (src-C) uses compact storage")
+    ap.add_argument("--flavor", choices=["default", "c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "default"),
+                    help="'default' = what `call a%%init(vlen, mvec)` of the drop-in Fortran module runs (compact storage "
+                         "unless NKA_HIP_FLAVOR says otherwise); or name the reference rounding mirrored")
     ap.add_argument("--allreduce", choices=["rccl", "torch"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
     return ap.parse_args()
 
@@ -138,13 +147,46 @@ def config5_abstract_vector(steps: int = 20):
             moved = 8.0 * n * words
             out[key] = {"value": ups, "ms_per_step": ms, "bytes_moved_per_update": moved,
                         "achieved_GBps": moved / (ms * 1e-3) / 1e9, "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                        "contract_frac": 8.0 * n * (11 + 3 * m) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "contract_GBps": 8.0 * n * (11 + 3 * m) / (ms * 1e-3) / 1e9,   # B_alg / time: a rate of useful work
+                        "contract_bytes_ratio": 8.0 * n * (11 + 3 * m) / moved,
                         "byte_model": ("8n(10+3m)" if compact == "0" else "8n(11+2m)")
                                       + ": update_norm2 2 (store deferred), scale_dot_pair_many 2+m (pure read: the "
                                       "normalisation of the new pair deferred to the combine), update/axpy_many_keep "
                                       + ("6+2m" if compact == "0" else "7+m")}
         except Exception as exc:   # an extra, never the measured path
             out[key] = {"value": None, "error": repr(exc)}
+    return out
+
+
+def probe_ceilings(n: int = 10**8, timeout: int = 240):
+    """The repo's own streaming probe (tools/hbm_probe mode `cr`: no arithmetic, random
+    data, one block per CU) run as a CHILD process after the timed region, on the same
+    box in the same run: what this memory system gives a pure read of 22 streams (PA's
+    shape), a pure write, and the 22-read / 5-write and 42-read / 5-write mixes of PB
+    with tile tickets.  These -- not the 8 TB/s spec figure -- are the ceilings the
+    kernels' `achieved` figures can be read against."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "hbm_probe")
+    if not os.path.exists(exe):
+        return {"error": "tools/hbm_probe not built"}
+    try:
+        p = subprocess.run([exe, str(n), "0", "cr"], capture_output=True, text=True, timeout=timeout)
+    except Exception as exc:      # an extra, never the measured path
+        return {"error": repr(exc)}
+    if p.returncode != 0:
+        return {"error": (p.stdout + p.stderr)[-300:]}
+    names = {"window S=22 W=0": "pure_read_22_streams_GBps", "S=0 W=4": "pure_write_4_streams_GBps",
+             "tickets S=22 W=5": "mix_22R_5W_GBps", "tickets S=42 W=5": "mix_42R_5W_GBps"}
+    out = {}
+    for line in p.stdout.splitlines():
+        mt = re.search(r"([0-9.]+) GB/s", line)
+        if not mt:
+            continue
+        for prefix, key in names.items():
+            if line.startswith(prefix):
+                out[key] = max(out.get(key, 0.0), float(mt.group(1)))
+    out["source"] = f"tools/hbm_probe {n} 0 cr (child process of this run, after the timed region; best of 2)"
     return out
 
 
@@ -178,7 +220,7 @@ def pmc_traffic(flavor: str, n_local: int, m: int):
     return None, None
 
 
-def roofline_block(flavor: str, n_local: int, m: int, mean, copy_gbps):
+def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None):
     """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
     PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
     PMC counters) / mean launch duration (HIP events on the kernel stream during
@@ -225,7 +267,8 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, copy_gbps):
         "contract_bytes_per_update": b_alg,
         "contract_bytes_ratio": b_alg / moved,
         "contract_GBps": (b_alg / upd_s / 1e9) if upd_s > 0 else None,
-        "copy_ceiling_GBps": copy_gbps,
+        "probe_ceiling": probe,
+        "device_time_stats_ms": stats,
     }
 
 
@@ -270,7 +313,9 @@ def main():
     prime = max(0, (m + 2) - W)
     W_all = prime + W
 
-    FLAVORS = {"f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR, "c": nka_amd.FLAVOR_C}
+    FLAVORS = {"default": nka_amd.FLAVOR_DEFAULT, "f08": nka_amd.FLAVOR_F08, "f08vec": nka_amd.FLAVOR_F08_VECTOR,
+               "c": nka_amd.FLAVOR_C}
+    FLAVOR_NAMES = {nka_amd.FLAVOR_F08: "f08", nka_amd.FLAVOR_F08_VECTOR: "f08vec", nka_amd.FLAVOR_C: "c"}
     hook_box = ["none"]
 
     def make_acc(flavor_name):
@@ -299,6 +344,8 @@ def main():
         return {"where": where, "ranks": len(digs), "digest": f"{digs[0]:016x}", "identical": True}
 
     acc = make_acc(args.flavor)
+    flavor = FLAVOR_NAMES[acc.flavor()]      # "default" resolved by the library, like every front end's init
+    is_default = FLAVOR_NAMES[nka_amd.nka.default_flavor()] == flavor
 
     # ---- inputs: resident in HBM before the timed region ----------------------
     free_b, _ = torch.cuda.mem_get_info(dev)
@@ -354,46 +401,35 @@ def main():
         nrec = min(-(-K // ev_stride), 4096)
         ph = [acc.timing_ms(b) for b in range(nrec)]
         mean = [sum(p[i] for p in ph) / nrec for i in range(4)]
+        # device events around each update; median and min next to the mean
+        stats = {}
+        for i, name in enumerate(("PA_k_dots", "k_solve", "PB_k_combine", "whole_update")):
+            col = sorted(p[i] for p in ph)
+            stats[name] = {"mean": mean[i], "median": (col[(nrec - 1) // 2] + col[nrec // 2]) / 2.0, "min": col[0],
+                           "max": col[-1]}
+        stats["samples"] = nrec
         if checks:
             checks.append(check_replicas(acc, "after the timed steps"))
-        return elapsed, mean, nv0, acc.num_vec(), checks
+        return elapsed, mean, nv0, acc.num_vec(), checks, stats
 
-    elapsed, mean, nv, nv_end, replica_check = measure(acc)
+    elapsed, mean, nv, nv_end, replica_check, stats = measure(acc)
     steady = (nv == m)
-
-    # device-copy ceiling measured in the same run
-    csz = min(n_local, 1 << 27)
-    if csz > 0:
-        src = torch.empty(csz, dtype=torch.float64, device=dev).normal_()
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        copy_gbps = 5 * 2 * 8 * csz / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
-    else:
-        copy_gbps = None
 
     # Secondary figure in the same run: the src-F08 rounding (two stored vectors
     # per pair, bit-faithful to F08:397), same workload, same protocol.
     also = None
-    if args.flavor == "c" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+    if flavor == "c" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
         acc.delete()
         acc = make_acc("f08")
-        e2, mean2, nv2, nv2_end, _ = measure(acc)
+        e2, mean2, nv2, nv2_end, _, stats2 = measure(acc)
         also = {"flavor": FLAVOR_TEXT["f08"],
                 "value": K / e2, "unit": "updates/s", "ms_per_step": 1e3 * e2 / K,
                 "steady_state": bool(nv2 == m and nv2_end == m),
-                "roofline": roofline_block("f08", n_local, m, mean2, None)}
+                "roofline": roofline_block("f08", n_local, m, mean2, None, stats2)}
 
     if rank == 0:
         L = k = m
-        rl = roofline_block(args.flavor, n_local, m, mean, copy_gbps)
+        rl = roofline_block(flavor, n_local, m, mean, None, stats)
         out = {
             "metric": ("NKA updates/sec + achieved HBM GB/s at n=1e8, m=20 fp64; 1/2/4/8 GPUs"   # BASELINE.json
                        if (n_global, m) == (10**8, 20) else
@@ -404,7 +440,11 @@ def main():
             "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction "
                                    f"vectors, n={n_global} (global), mvec={m}, fp64, subspace full (num_vec={nv})",
                        "n_global": n_global, "n_local": n_local, "mvec": m,
-                       "flavor": FLAVOR_TEXT[args.flavor],
+                       "flavor": FLAVOR_TEXT[flavor],
+                       "flavor_is_front_end_default": bool(is_default),
+                       "flavor_note": "the flavour `call a%init(vlen, mvec)` (Fortran), nka_init (F95) and nka().init "
+                                      "(Python) run when the caller names none (include/nka_hip.h: NKA_HIP_FLAVOR_DEFAULT)"
+                                      if is_default else "NOT the front ends' default: selected on the command line",
                        "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}",
                        "steady_state": bool(steady and nv_end == m), "prime_steps": prime,
                        "phase_events": f"HIP events recorded on every {ev_stride}{'st' if ev_stride == 1 else 'th'} timed update",
@@ -426,12 +466,16 @@ def main():
                     out["cpu_baseline"]["value"] * int(args.cpu_n) / n_global
             except Exception as exc:  # the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
-        if world == 1 and not (args.no_config5 or args.no_cpu_baseline) and (n_global, m) == (10**8, 20):   # lean runs skip both extras
-            del pool, pool_store           # release HBM for the child process
+        if world == 1 and not args.no_cpu_baseline:                # lean runs skip the child-process extras
+            del pool, pool_store           # release HBM for the child processes
             acc.delete()
             torch.cuda.empty_cache()
-            out["config5_abstract_vector"] = config5_abstract_vector()
             pool = pool_store = None
+            rl["probe_ceiling"] = probe_ceilings(min(n_local, 10**8))
+            if also is not None:
+                also["roofline"]["probe_ceiling"] = rl["probe_ceiling"]
+            if not args.no_config5 and (n_global, m) == (10**8, 20):
+                out["config5_abstract_vector"] = config5_abstract_vector()
         print(json.dumps(out), flush=True)
 
     # tear down in a fixed order on every rank: the library's RCCL communicator first,

@@ -54,6 +54,17 @@ enum {
  * vector per pair instead of two.  (nka_hip_get_v on a normalised slot returns
  * v_k - w_k in this flavour; the pending slot holds the raw update.) */
 enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2 };
+/* NKA_HIP_FLAVOR_DEFAULT: what every front end of this build passes unless the caller
+ * names a flavour (Fortran `call a%init(vlen, mvec)`, F95 nka_init, Python init, the C
+ * compatibility header).  It resolves to the environment variable NKA_HIP_FLAVOR
+ * ("f08" | "f08vec" | "c", or 0 | 1 | 2) if set, else to NKA_HIP_FLAVOR_C: compact
+ * storage moves 8n(9+L+k) bytes per update instead of 8n(8+L+2k) and is held to the
+ * compiled src-F08 reference in tests/ at the stated tolerance with exact decisions;
+ * it differs from NKA_HIP_FLAVOR_F08 only in the association of the combine
+ * (f + c*(v-w) against (f - c*w) + c*v: last-bit differences).  A caller that wants
+ * the F08 statement bit for bit passes NKA_HIP_FLAVOR_F08 (or sets NKA_HIP_FLAVOR=f08).
+ * nka_hip_flavor() reports the flavour a handle runs. */
+enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
 
 /* ---- lifecycle --------------------------------------------------------- */
 
@@ -108,6 +119,7 @@ int nka_hip_max_vec(nka_hip_t a);      /* F08:233-236, C .h:10 */
 int64_t nka_hip_vec_len(nka_hip_t a);  /* F08:238-241, C .h:11 (local length) */
 double nka_hip_vec_tol(nka_hip_t a);   /* F08:243-246, C .h:12 ; -1 (and last_error) on a NULL handle */
 int nka_hip_defined(nka_hip_t a);      /* F08:460-524 ; 1 = well defined */
+int nka_hip_flavor(nka_hip_t a);       /* NKA_HIP_FLAVOR_* this handle runs (DEFAULT resolved) ; <0 on error */
 
 /* List / factor state for parity tests (the reference keeps these private,
  * F08:155-168).  next, prev: mvec+1 ints (entry k-1 is slot k); h: (mvec+1)^2
@@ -318,6 +330,39 @@ int nka_hip_vec_update_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z,
 int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                                     const double *const *xs, int32_t count, double *keep_in, double *keep_out,
                                     double *pend_w, double pend_a, int32_t pend_pre, double pend_pre_a);
+/* ---- parallel-aware reductions of the device vector types ----------------
+ * The vector flavour of the reference is distributed THROUGH the vector class: "the
+ * implementation of the vector base class reduction methods will necessarily be
+ * parallel-aware" (src-F08-vector/README.md:16-22).  For the device vector types of this
+ * build (hip_block_vector, hip_grid_vector) that means: every sum a reduction hands back
+ * to the host -- dot_, norm2 (before its square root), dot_many, dot_pair_many and the 1
+ * resp. 2L+1 sums of the fused stages update_norm2 / scale_dot_pair_many -- is first
+ * summed over all ranks.  The hooks hang on the WORKSPACE the vectors share:
+ *   nka_hip_vec_set_allreduce       fn sums `count` doubles at a DEVICE address in place,
+ *                                   ordered on the given hipStream_t (the type of
+ *                                   nka_hip_set_allreduce); the sums are written there in a
+ *                                   layout that depends only on the list length, never on
+ *                                   the kernel variant a rank happened to take
+ *   nka_hip_vec_comm_init_rank      built-in: an RCCL all-reduce on the workspace stream
+ *                                   (unique id from nka_hip_comm_unique_id)
+ *   nka_hip_vec_set_host_allreduce  fn sums `count` doubles in HOST memory in place, after
+ *                                   the stream has been synchronised -- the natural place
+ *                                   for an MPI_Allreduce of a caller that has no device-
+ *                                   aware communication library
+ * Either kind, both, or none may be installed (device hook first, then the host hook).
+ * The result must carry the same bits on every rank: the Gram/Cholesky matrix and the
+ * lists of the vector flavour live on the host of each rank and take the drop decisions
+ * independently (F08V:269-321).  A rank whose slice is empty (n = 0) still takes part in
+ * every collective.  A failing hook makes the reduction return NKA_HIP_ECOMM.
+ * nka_hip_vec_allreduce_now runs the installed hooks once on `count` host values
+ * (count <= 49), so that a launcher can prove the communicator before the first update. */
+typedef int (*nka_hip_host_allreduce_fn)(void *ctx, double *host_vals, int32_t count);
+int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx);
+int nka_hip_vec_set_host_allreduce(nka_hip_vec_ws_t ws, nka_hip_host_allreduce_fn fn, void *ctx);
+int nka_hip_vec_comm_init_rank(nka_hip_vec_ws_t ws, const void *id128, int32_t nranks, int32_t rank);
+int nka_hip_vec_comm_destroy(nka_hip_vec_ws_t ws);
+int nka_hip_vec_allreduce_now(nka_hip_vec_ws_t ws, double *host_vals, int32_t count);
+
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
 int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 

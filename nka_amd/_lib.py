@@ -29,6 +29,7 @@ SIGNATURES = {
     "nka_hip_vec_len": (C.c_int64, [C.c_void_p]),
     "nka_hip_vec_tol": (C.c_double, [C.c_void_p]),
     "nka_hip_defined": (C.c_int, [C.c_void_p]),
+    "nka_hip_flavor": (C.c_int, [C.c_void_p]),
     "nka_hip_get_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp, _dp]),
     "nka_hip_get_reductions": (C.c_int, [C.c_void_p, _dp]),
     "nka_hip_get_stamps": (C.c_int, [C.c_void_p, _dp]),

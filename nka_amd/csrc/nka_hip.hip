@@ -11,7 +11,7 @@
 #include "nka_kernels.hpp"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "rccl_dl.hpp"
 
 #include <dlfcn.h>
 
@@ -101,55 +101,7 @@ int env_int(const char *name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-// RCCL is bound at first use, not at link time, so that a process holds exactly
-// ONE copy of it: if a librccl.so.1 is already mapped (PyTorch ships its own and
-// loads it with `import torch`), that copy is used -- two RCCLs in one process
-// would each bring their own communicator state and kernels --, otherwise the
-// ROCm installation's (library RUNPATH /opt/rocm/lib).  NKA_HIP_RCCL_LIB names
-// another file.  Single-GPU users never load the 570 MB library at all.
-struct Rccl {
-  void *handle = nullptr;
-  std::string path, err;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclAllReduce) AllReduce = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  Rccl() {
-    const char *user = getenv("NKA_HIP_RCCL_LIB");
-    if (user && *user) {
-      handle = dlopen(user, RTLD_NOW | RTLD_LOCAL);
-    } else {
-      handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);   // the copy already in this process
-      if (!handle) handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-      if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    }
-    if (!handle) {
-      const char *e = dlerror();
-      err = std::string("cannot load RCCL: ") + (e ? e : "unknown dlopen error");
-      return;
-    }
-#define NKA_SYM(name) name = reinterpret_cast<decltype(name)>(dlsym(handle, "nccl" #name))
-    NKA_SYM(GetUniqueId);
-    NKA_SYM(CommInitRank);
-    NKA_SYM(CommDestroy);
-    NKA_SYM(AllReduce);
-    NKA_SYM(GetErrorString);
-#undef NKA_SYM
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
-      err = "the loaded RCCL lacks a required ncclXxx symbol";
-      handle = nullptr;
-      return;
-    }
-    Dl_info info;
-    if (dladdr(reinterpret_cast<void *>(AllReduce), &info) && info.dli_fname) path = info.dli_fname;
-  }
-  bool ok() const { return handle != nullptr; }
-};
-const Rccl &rccl() {
-  static const Rccl r;
-  return r;
-}
+using nka_detail::rccl;   // rccl_dl.hpp: RCCL bound at first use, one copy per process
 
 }  // namespace
 
@@ -441,6 +393,17 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   if (mvec <= 0) return fail(NKA_HIP_EINVAL, "nka_hip_create: mvec must be > 0");
   if (vlen_local < 0) return fail(NKA_HIP_EINVAL, "nka_hip_create: vlen must be >= 0");
   if (!(vtol > 0.0)) return fail(NKA_HIP_EINVAL, "nka_hip_create: vtol must be > 0");
+  if (flavor == NKA_HIP_FLAVOR_DEFAULT) {
+    // one rule for every front end: NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
+    flavor = NKA_HIP_FLAVOR_C;
+    if (const char *e = getenv("NKA_HIP_FLAVOR")) {
+      const std::string v(e);
+      if (v == "f08" || v == "F08" || v == "0") flavor = NKA_HIP_FLAVOR_F08;
+      else if (v == "f08vec" || v == "F08VEC" || v == "f08_vector" || v == "1") flavor = NKA_HIP_FLAVOR_F08_VECTOR;
+      else if (v == "c" || v == "C" || v == "compact" || v == "2") flavor = NKA_HIP_FLAVOR_C;
+      else if (!v.empty()) return fail(NKA_HIP_EINVAL, "NKA_HIP_FLAVOR: expected f08, f08vec or c, got '" + v + "'");
+    }
+  }
   if (flavor < 0 || flavor > 2) return fail(NKA_HIP_EINVAL, "nka_hip_create: unknown flavor");
   // The list-scan kernels keep h, c and the links of all mvec+1 slots in LDS
   // (8*(mvec+2)^2 bytes and change): gfx950's 160 KiB per workgroup bound mvec.
@@ -849,6 +812,7 @@ int nka_hip_num_vec(nka_hip_t a) {
 }
 
 int nka_hip_max_vec(nka_hip_t a) { return a ? a->mvec : fail(NKA_HIP_EINVAL, "null handle"); }
+int nka_hip_flavor(nka_hip_t a) { return a ? a->flavor : fail(NKA_HIP_EINVAL, "null handle"); }
 int64_t nka_hip_vec_len(nka_hip_t a) { return a ? a->n : (int64_t)fail(NKA_HIP_EINVAL, "null handle"); }
 double nka_hip_vec_tol(nka_hip_t a) {
   if (a) return a->vtol;

@@ -10,12 +10,14 @@
 // ((a*x) + (b*y)) + z  does.
 #include "../../include/nka_hip.h"
 #include "nka_kernels.hpp"
+#include "rccl_dl.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 using namespace nka;
@@ -34,10 +36,19 @@ struct nka_hip_vec_ws {
   double *partials = nullptr;  // kMaxGrid
   unsigned *tickets = nullptr; // tile-ticket counters of k_update_many_keep_win (kTicketWords, zero between launches)
   int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning)
-  double *host_result = nullptr;  // pinned
   double *host_results = nullptr; // pinned, 2*kManyMax+1 doubles
-  double *host_result_dev = nullptr;   // device-side addresses of the two pinned buffers: the final-sum
-  double *host_results_dev = nullptr;  // kernel writes straight into host memory (no copy kernel, no staging)
+  double *host_results_dev = nullptr;  // its device-side address: the final-sum kernel writes straight into host
+                                       // memory (no copy kernel, no staging)
+  // parallel-aware reductions ("the vector base class reduction methods will necessarily be
+  // parallel-aware", src-F08-vector/README.md:16-22): every sum a reduction returns to the host is first
+  // summed over the ranks -- on the device by `allreduce` (stream-ordered; built-in: RCCL), and/or on the
+  // host by `host_allreduce` after the stream has been synchronised
+  nka_hip_allreduce_fn allreduce = nullptr;
+  void *allreduce_ctx = nullptr;
+  nka_hip_host_allreduce_fn host_allreduce = nullptr;
+  void *host_allreduce_ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  double *red_dev = nullptr;      // 2*kManyMax+1 doubles: the sums of one reduction in canonical layout
 };
 
 namespace {
@@ -806,6 +817,88 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
   } while (base < count);
   return 0;
 }
+
+// ---- final sums of a reduction -> host, summed over the ranks when hooks are installed ------
+// The reduction kernel just enqueued left per-block partials of `rows` rows of `nv` columns (plus
+// one `cross` column); the first `count` columns of each row are wanted.  One block per column sums
+// its partials in the fixed order of k_finalize (same bits) and writes the CANONICAL layout
+//   out[r*count + j] = row r, column j   ;   out[rows*count] = cross
+// which depends only on (rows, count) -- never on the padded width nv of the kernel variant a rank
+// happened to take (alignment of its pointers) --, so the ranks of a sharded run always reduce
+// the same number of values in the same places.
+static __global__ __launch_bounds__(kBlock) void k_finalize_rows(const double *__restrict__ partials, int G, int rows,
+                                                                 int nv, int count, double *__restrict__ out) {
+  __shared__ double sm[kWavesPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x;
+  int dst;
+  if (c < rows * nv) {
+    const int r = c / nv, j = c - r * nv;
+    if (j >= count) return;                     // padding column of the unrolled kernel (whole block leaves)
+    dst = r * count + j;
+  } else {
+    dst = rows * count;                         // the cross column
+  }
+  double r = 0.0;
+  for (int b = threadIdx.x; b < G; b += kBlock) r += partials[(size_t)c * G + b];
+  r = wave_sum(r);
+  if (lane == 0) sm[wv] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sm[0];
+#pragma unroll
+    for (int q = 1; q < kWavesPerBlock; q++) t += sm[q];
+    out[dst] = t;
+  }
+}
+
+bool ws_parallel(const nka_hip_vec_ws *ws) { return ws->allreduce || ws->host_allreduce; }
+
+int run_host_hook(nka_hip_vec_ws_t ws, double *vals, int total) {
+  if (!ws->host_allreduce || total <= 0) return 0;
+  if (int rc = ws->host_allreduce(ws->host_allreduce_ctx, vals, total))
+    return rc < 0 ? rc : nka_detail::set_error(NKA_HIP_ECOMM, "vector reduction: the host all-reduce hook failed");
+  return 0;
+}
+
+// Results land in ws->host_results (canonical layout).  have == false: this rank's slice is
+// empty, no kernel ran; its contribution is zero but it still takes part in every collective.
+int fetch_sums(nka_hip_vec_ws_t ws, int g, int rows, int nv, int count, bool cross, bool have) {
+  const int total = rows * count + (cross ? 1 : 0);
+  if (total <= 0) return 0;
+  const int ncols = rows * nv + (cross ? 1 : 0);
+  if (!ws->allreduce) {
+    if (have) {
+      // single rank (or host-side hook only): straight into pinned host memory, no copy in between
+      hipLaunchKernelGGL(k_finalize_rows, dim3(ncols), dim3(kBlock), 0, ws->stream, ws->partials, g, rows, nv, count,
+                         ws->host_results_dev);
+      HIP_TRYV(hipGetLastError());
+      HIP_TRYV(hipStreamSynchronize(ws->stream));
+    } else {
+      for (int i = 0; i < total; i++) ws->host_results[i] = 0.0;
+    }
+    return run_host_hook(ws, ws->host_results, total);
+  }
+  if (have) {
+    hipLaunchKernelGGL(k_finalize_rows, dim3(ncols), dim3(kBlock), 0, ws->stream, ws->partials, g, rows, nv, count, ws->red_dev);
+    HIP_TRYV(hipGetLastError());
+  } else {
+    HIP_TRYV(hipMemsetAsync(ws->red_dev, 0, sizeof(double) * (size_t)total, ws->stream));
+  }
+  if (int rc = ws->allreduce(ws->allreduce_ctx, ws->red_dev, total, ws->stream))
+    return rc < 0 ? rc : nka_detail::set_error(NKA_HIP_ECOMM, "vector reduction: the all-reduce hook failed");
+  HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->red_dev, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ws->stream));
+  HIP_TRYV(hipStreamSynchronize(ws->stream));
+  return run_host_hook(ws, ws->host_results, total);
+}
+
+int rccl_vec_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
+  auto *ws = static_cast<nka_hip_vec_ws *>(ctx);
+  const auto &R = nka_detail::rccl();
+  ncclResult_t r = R.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, ws->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return nka_detail::set_error(NKA_HIP_ECOMM, std::string("ncclAllReduce: ") + R.GetErrorString(r));
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -828,9 +921,8 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   if (e == hipSuccess) e = hipMalloc((void **)&ws->tickets, sizeof(unsigned) * kTicketWords);
   if (e == hipSuccess) e = hipMemset(ws->tickets, 0, sizeof(unsigned) * kTicketWords);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_result, sizeof(double), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_result_dev, ws->host_result, 0);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_results_dev, ws->host_results, 0);
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->red_dev, sizeof(double) * (2 * kManyMax + 1));
   if (e != hipSuccess) {   // free whatever was obtained (hipFree / hipHostFree accept NULL)
     nka_hip_vec_workspace_destroy(ws);
     return nka_detail::set_error(e == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,
@@ -847,7 +939,8 @@ int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
   hipFree(ws->tickets);
-  hipHostFree(ws->host_result);
+  if (ws->comm) nka_detail::rccl().CommDestroy(ws->comm);
+  hipFree(ws->red_dev);
   hipHostFree(ws->host_results);
   delete ws;
   return 0;
@@ -914,20 +1007,21 @@ int nka_hip_vec_update4(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, con
 int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result) {
   if (!ws || !host_result || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_result = 0.0;
-  if (n == 0) return 0;
+  if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
-  if (int rc = nka_detail::check_device_span(x, n, "vec_dot: x")) return rc;
-  if (int rc = nka_detail::check_device_span(y, n, "vec_dot: y")) return rc;
-  const bool v2 = al16(x) && al16(y);
-  const int g = grid_for(ws, n, v2 ? 2 : 1);
-  if (v2)
-    hipLaunchKernelGGL((k_dot<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
-  else
-    hipLaunchKernelGGL((k_dot<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->host_result_dev);
-  HIP_TRYV(hipGetLastError());
-  HIP_TRYV(hipStreamSynchronize(ws->stream));
-  *host_result = *ws->host_result;
+  int g = 1;
+  if (n > 0) {
+    if (int rc = nka_detail::check_device_span(x, n, "vec_dot: x")) return rc;
+    if (int rc = nka_detail::check_device_span(y, n, "vec_dot: y")) return rc;
+    const bool v2 = al16(x) && al16(y);
+    g = grid_for(ws, n, v2 ? 2 : 1);
+    if (v2)
+      hipLaunchKernelGGL((k_dot<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
+    else
+      hipLaunchKernelGGL((k_dot<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
+  }
+  if (int rc = fetch_sums(ws, g, 1, 1, 1, false, n > 0)) return rc;
+  *host_result = ws->host_results[0];
   return 0;
 }
 
@@ -943,14 +1037,21 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
                          double *host_vals) {
   if (!ws || n < 0 || count < 0 || (count > 0 && (!ys || !host_vals))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   for (int j = 0; j < count; j++) host_vals[j] = 0.0;
-  if (n == 0 || count == 0) return 0;
+  if (count == 0 || (n == 0 && !ws_parallel(ws))) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
-  if (int rc = nka_detail::check_device_span(x, n, "vec_dot_many: x")) return rc;
-  for (int j = 0; j < count; j++)
-    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_many: ys[j]")) return rc;
+  if (n > 0) {
+    if (int rc = nka_detail::check_device_span(x, n, "vec_dot_many: x")) return rc;
+    for (int j = 0; j < count; j++)
+      if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_many: ys[j]")) return rc;
+  }
   for (int base = 0; base < count; base += kManyMax) {
     ManyArgs m{};
     m.count = std::min(kManyMax, count - base);
+    if (n == 0) {                      // empty slice: zeros, but the collective is still joined
+      if (int rc = fetch_sums(ws, 1, 1, m.count, m.count, false, false)) return rc;
+      for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
+      continue;
+    }
     bool v2 = al16(x);
     for (int j = 0; j < m.count; j++) {
       m.x[j] = ys[base + j];
@@ -963,10 +1064,8 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3(m.count), dim3(kBlock), 0, ws->stream, ws->partials, g, m.count, m.count,
-                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    if (int rc = fetch_sums(ws, g, 1, nv, m.count, false, true)) return rc;
     for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
   }
   return 0;
@@ -981,16 +1080,28 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_cross = 0.0;
   for (int j = 0; j < count; j++) host_vals0[j] = host_vals1[j] = 0.0;
-  if (n == 0) return 0;
+  if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
-  if (int rc = nka_detail::check_device_span(x0, n, "vec_dot_pair_many: x0")) return rc;
-  if (int rc = nka_detail::check_device_span(x1, n, "vec_dot_pair_many: x1")) return rc;
-  for (int j = 0; j < count; j++)
-    if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_pair_many: ys[j]")) return rc;
+  if (n > 0) {
+    if (int rc = nka_detail::check_device_span(x0, n, "vec_dot_pair_many: x0")) return rc;
+    if (int rc = nka_detail::check_device_span(x1, n, "vec_dot_pair_many: x1")) return rc;
+    for (int j = 0; j < count; j++)
+      if (int rc = nka_detail::check_device_span(ys[j], n, "vec_dot_pair_many: ys[j]")) return rc;
+  }
   int base = 0;
   do {  // at least one launch so that <x0,x1> is computed even when count == 0
     ManyArgs m{};
-    m.count = std::min(kManyMax, count - base);
+    m.count = std::max(0, std::min(kManyMax, count - base));
+    if (n == 0) {                      // empty slice: zeros, but the collective is still joined
+      if (int rc = fetch_sums(ws, 1, 2, std::max(m.count, 1), m.count, true, false)) return rc;
+      for (int j = 0; j < m.count; j++) {
+        host_vals0[base + j] = ws->host_results[j];
+        host_vals1[base + j] = ws->host_results[m.count + j];
+      }
+      if (base == 0) *host_cross = ws->host_results[2 * m.count];
+      base += kManyMax;
+      continue;
+    }
     bool v2 = al16(x0) && al16(x1);
     for (int j = 0; j < m.count; j++) {
       m.x[j] = ys[base + j];
@@ -1003,15 +1114,13 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
 #undef LAUNCH2
 #undef LAUNCH1
-    hipLaunchKernelGGL(k_finalize, dim3(2 * nv + 1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1,
-                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    if (int rc = fetch_sums(ws, g, 2, nv, m.count, true, true)) return rc;
     for (int j = 0; j < m.count; j++) {
       host_vals0[base + j] = ws->host_results[j];
-      host_vals1[base + j] = ws->host_results[nv + j];
+      host_vals1[base + j] = ws->host_results[m.count + j];
     }
-    if (base == 0) *host_cross = ws->host_results[2 * nv];
+    if (base == 0) *host_cross = ws->host_results[2 * m.count];
     base += kManyMax;
   } while (base < count);
   return 0;
@@ -1092,8 +1201,13 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
                              double *host_norm) {
   if (!ws || !host_norm || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_norm = 0.0;
-  if (n == 0) return 0;
+  if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (n == 0) {                        // empty slice: zero, but the collective is still joined
+    if (int rc = fetch_sums(ws, 1, 1, 1, 1, false, false)) return rc;
+    *host_norm = std::sqrt(ws->host_results[0]);
+    return 0;
+  }
   if (int rc = nka_detail::check_device_span(z, n, "vec_update_norm2: z")) return rc;
   if (int rc = nka_detail::check_device_span(x, n, "vec_update_norm2: x")) return rc;
   const bool v2 = al16(z) && al16(x);
@@ -1106,10 +1220,9 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
     hipLaunchKernelGGL((k_update_norm2<1, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
   else
     hipLaunchKernelGGL((k_update_norm2<1, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, ws->stream, ws->partials, g, 1, 1, ws->host_result_dev);
   HIP_TRYV(hipGetLastError());
-  HIP_TRYV(hipStreamSynchronize(ws->stream));
-  *host_norm = std::sqrt(*ws->host_result);
+  if (int rc = fetch_sums(ws, g, 1, 1, 1, false, true)) return rc;
+  *host_norm = std::sqrt(ws->host_results[0]);     // the square root of the GLOBAL sum
   return 0;
 }
 
@@ -1144,8 +1257,23 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_cross = 0.0;
   for (int j = 0; j < count; j++) host_vals_w[j] = host_vals_f[j] = 0.0;
-  if (n == 0) return 0;
+  if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
+  if (n == 0) {                        // empty slice: zeros, but every collective is still joined
+    const int c0 = std::min(kManyMax, count);
+    if (int rc = fetch_sums(ws, 1, 2, std::max(c0, 1), c0, true, false)) return rc;
+    for (int j = 0; j < c0; j++) {
+      host_vals_w[j] = ws->host_results[j];
+      host_vals_f[j] = ws->host_results[c0 + j];
+    }
+    *host_cross = ws->host_results[2 * c0];
+    if (count > kManyMax) {
+      double cross_again = 0.0;
+      return nka_hip_vec_dot_pair_many(ws, n, w, f, ys + kManyMax, count - kManyMax, host_vals_w + kManyMax,
+                                       host_vals_f + kManyMax, &cross_again);
+    }
+    return 0;
+  }
   if (int rc = nka_detail::check_device_span(w, n, "vec_scale_dot_pair_many: w")) return rc;
   if (int rc = nka_detail::check_device_span(v, n, "vec_scale_dot_pair_many: v")) return rc;
   if (int rc = nka_detail::check_device_span(f, n, "vec_scale_dot_pair_many: f")) return rc;
@@ -1204,15 +1332,13 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef L1NN
 #undef NKA_SDPM
 #undef NKA_SDPMW
-    hipLaunchKernelGGL(k_finalize, dim3(2 * nv + 1), dim3(kBlock), 0, ws->stream, ws->partials, g, 2 * nv + 1, 2 * nv + 1,
-                       ws->host_results_dev);
     HIP_TRYV(hipGetLastError());
-    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    if (int rc = fetch_sums(ws, g, 2, nv, m.count, true, true)) return rc;
     for (int j = 0; j < m.count; j++) {
       host_vals_w[j] = ws->host_results[j];
-      host_vals_f[j] = ws->host_results[nv + j];
+      host_vals_f[j] = ws->host_results[m.count + j];
     }
-    *host_cross = ws->host_results[2 * nv];
+    *host_cross = ws->host_results[2 * m.count];
   }
   if (count > kManyMax) {   // the rest of a long list: plain two-row dots against the already scaled w
     double cross_again = 0.0;
@@ -1260,6 +1386,72 @@ int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, c
   pd.pre_a = pend_pre_a;
   pd.flags = 1 | (pend_pre ? 2 : 0) | 4;
   return update_many_keep<false>(ws, n, z, a, xs, nullptr, nullptr, count, keep_in, keep_out, "vec_axpy_many_keep_pend", pd);
+}
+
+// ---- parallel-aware reductions: hooks on the workspace (include/nka_hip.h) ------------------
+int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx) {
+  if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
+  ws->allreduce = fn;
+  ws->allreduce_ctx = fn ? ctx : nullptr;
+  return 0;
+}
+
+int nka_hip_vec_set_host_allreduce(nka_hip_vec_ws_t ws, nka_hip_host_allreduce_fn fn, void *ctx) {
+  if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
+  ws->host_allreduce = fn;
+  ws->host_allreduce_ctx = fn ? ctx : nullptr;
+  return 0;
+}
+
+int nka_hip_vec_comm_init_rank(nka_hip_vec_ws_t ws, const void *id128, int32_t nranks, int32_t rank) {
+  if (!ws || !id128) return nka_detail::set_error(NKA_HIP_EINVAL, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return nka_detail::set_error(NKA_HIP_EINVAL, "bad rank / nranks");
+  const auto &R = nka_detail::rccl();
+  if (!R.ok()) return nka_detail::set_error(NKA_HIP_ECOMM, R.err);
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (int rc = nka_hip_vec_comm_destroy(ws)) return rc;
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t r = R.CommInitRank(&ws->comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    ws->comm = nullptr;
+    return nka_detail::set_error(NKA_HIP_ECOMM, std::string("ncclCommInitRank: ") + R.GetErrorString(r));
+  }
+  ws->allreduce = rccl_vec_allreduce;
+  ws->allreduce_ctx = ws;
+  return 0;
+}
+
+int nka_hip_vec_comm_destroy(nka_hip_vec_ws_t ws) {
+  if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
+  if (ws->comm) {
+    HIP_TRYV(hipSetDevice(ws->device));
+    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    nka_detail::rccl().CommDestroy(ws->comm);
+    ws->comm = nullptr;
+  }
+  if (ws->allreduce == rccl_vec_allreduce) {
+    ws->allreduce = nullptr;
+    ws->allreduce_ctx = nullptr;
+  }
+  return 0;
+}
+
+int nka_hip_vec_allreduce_now(nka_hip_vec_ws_t ws, double *host_vals, int32_t count) {
+  if (!ws || count < 0 || count > 2 * kManyMax + 1 || (count > 0 && !host_vals))
+    return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if (count == 0) return 0;
+  HIP_TRYV(hipSetDevice(ws->device));
+  if (ws->allreduce) {
+    HIP_TRYV(hipMemcpyAsync(ws->red_dev, host_vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ws->stream));
+    if (int rc = ws->allreduce(ws->allreduce_ctx, ws->red_dev, count, ws->stream))
+      return rc < 0 ? rc : nka_detail::set_error(NKA_HIP_ECOMM, "vector reduction: the all-reduce hook failed");
+    HIP_TRYV(hipMemcpyAsync(ws->host_results, ws->red_dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRYV(hipStreamSynchronize(ws->stream));
+    for (int i = 0; i < count; i++) host_vals[i] = ws->host_results[i];
+  }
+  return run_host_hook(ws, host_vals, count);
 }
 
 int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host) {

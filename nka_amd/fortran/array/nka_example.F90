@@ -120,7 +120,7 @@ program nka_example
   use nka_type
   implicit none
 
-  integer :: nx = 50, nsweep = 2, mvec = 0, flavor = NKA_HIP_FLAVOR_F08
+  integer :: nx = 50, nsweep = 2, mvec = 0, flavor = NKA_HIP_FLAVOR_DEFAULT
   real(r8) :: a = 0.02_r8, omega = 1.4_r8
 
   call read_options

@@ -56,7 +56,7 @@ program nka_example_dev
   use nka_type
   implicit none
 
-  integer :: nx = 50, nsweep = 2, mvec = 0, flavor = NKA_HIP_FLAVOR_F08, maxitr = 999
+  integer :: nx = 50, nsweep = 2, mvec = 0, flavor = NKA_HIP_FLAVOR_DEFAULT, maxitr = 999
   real(r8) :: a = 0.02_r8, omega = 1.4_r8
 
   call read_options

@@ -26,7 +26,13 @@
 !!  * the object is a HANDLE and cannot be copied: intrinsic assignment of one
 !!    nka to another would duplicate the handle (double free); the defined
 !!    assignment below stops with a message instead.  Pass objects by reference.
-!!  * init takes optional flavor / device / stream arguments.
+!!  * init takes optional flavor / device / stream arguments.  Without `flavor` the
+!!    object runs the build's DEFAULT: compact storage (the v slot of a normalised
+!!    pair keeps v - w, the combine is f + c*(v - w), the src-C statement), which
+!!    differs from F08:397 in the association of the combine only (last bits; held
+!!    to the compiled src-F08 reference in tests/) and moves 8n(9+L+k) instead of
+!!    8n(8+L+2k) bytes per update.  flavor=NKA_HIP_FLAVOR_F08 or the environment
+!!    variable NKA_HIP_FLAVOR=f08 selects the F08 statement bit for bit.
 
 module nka_type
 
@@ -69,6 +75,7 @@ module nka_type
     procedure :: relax
     procedure :: restart
     procedure :: defined
+    procedure :: flavor => get_flavor
     procedure :: set_timing
     procedure :: get_timing
     procedure, private :: no_copy
@@ -76,7 +83,7 @@ module nka_type
     final :: nka_delete
   end type nka
 
-  public :: NKA_HIP_FLAVOR_F08, NKA_HIP_FLAVOR_F08_VECTOR, NKA_HIP_FLAVOR_C
+  public :: NKA_HIP_FLAVOR_F08, NKA_HIP_FLAVOR_F08_VECTOR, NKA_HIP_FLAVOR_C, NKA_HIP_FLAVOR_DEFAULT
 
 contains
 
@@ -89,7 +96,7 @@ contains
     integer(c_int32_t) :: fl, dev
     type(c_ptr) :: st
     call nka_delete_handle(this)       ! intent(out) semantics: a re-init starts afresh
-    fl = NKA_HIP_FLAVOR_F08
+    fl = NKA_HIP_FLAVOR_DEFAULT        ! NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
     dev = 0
     st = c_null_ptr
     if (present(flavor)) fl = int(flavor, c_int32_t)
@@ -220,6 +227,12 @@ contains
     class(nka), intent(in) :: this
     defined = .false.
     if (c_associated(this%handle)) defined = (nka_hip_defined(this%handle) == 1)
+  end function
+
+  !! which NKA_HIP_FLAVOR_* this object runs (the default resolved)
+  integer function get_flavor(this)
+    class(nka), intent(in) :: this
+    get_flavor = nka_hip_flavor(this%handle)
   end function
 
   subroutine set_timing(this, capacity)

@@ -9,6 +9,8 @@ module nka_hip_c
   public
 
   integer(c_int), parameter :: NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2
+  !! resolved by nka_hip_create: environment NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
+  integer(c_int), parameter :: NKA_HIP_FLAVOR_DEFAULT = -1
 
   interface
     integer(c_int) function nka_hip_create(handle, vlen_local, mvec, vtol, flavor, device, stream) bind(C)
@@ -50,6 +52,10 @@ module nka_hip_c
       type(c_ptr), value :: handle
     end function
     integer(c_int) function nka_hip_max_vec(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_flavor(handle) bind(C)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle
     end function

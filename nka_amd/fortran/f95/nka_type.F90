@@ -50,7 +50,7 @@ contains
     integer, intent(in) :: vlen, mvec
     call nka_delete(this)
     call nka_hip_check(nka_hip_create(this%handle, int(vlen, c_int64_t), int(mvec, c_int32_t), 0.01_c_double, &
-                                      NKA_HIP_FLAVOR_F08, 0_c_int32_t, c_null_ptr), 'nka_init')
+                                      NKA_HIP_FLAVOR_DEFAULT, 0_c_int32_t, c_null_ptr), 'nka_init')
   end subroutine
 
   subroutine nka_delete(this)                                 ! :266-275

@@ -16,6 +16,7 @@ import numpy as np
 from . import _lib
 
 FLAVOR_F08, FLAVOR_F08_VECTOR, FLAVOR_C = 0, 1, 2
+FLAVOR_DEFAULT = -1     # resolved by the library: NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
 
 
 class NKAError(RuntimeError):
@@ -61,11 +62,14 @@ class nka:  # noqa: N801  (the reference's type name)
         self._hd = None
 
     # -- call a%init(vlen, mvec)                      F08:185-200
-    def init(self, vlen: int, mvec: int, *, flavor: int = FLAVOR_F08, device: int | None = None,
+    def init(self, vlen: int, mvec: int, *, flavor: int = FLAVOR_DEFAULT, device: int | None = None,
              stream: int | None = None):
         """vlen is THIS rank's slice length.  Like the Fortran intent(out) dummy,
         init resets vtol (0.01) and the dot-product hook.  `stream` is a raw
-        hipStream_t (default: torch's current stream on `device`)."""
+        hipStream_t (default: torch's current stream on `device`).  Without
+        `flavor` the object runs the build's default -- the same one the Fortran
+        `call a%init(vlen, mvec)` runs: compact storage unless NKA_HIP_FLAVOR
+        says otherwise (include/nka_hip.h); flavor() reports it."""
         import torch
 
         self.delete()
@@ -156,6 +160,15 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy")
 
     @staticmethod
+    def default_flavor() -> int:
+        """What FLAVOR_DEFAULT resolves to in this process (the library's rule, mirrored:
+        NKA_HIP_FLAVOR if set, else compact storage)."""
+        import os
+        v = os.environ.get("NKA_HIP_FLAVOR", "").strip().lower()
+        return {"f08": FLAVOR_F08, "0": FLAVOR_F08, "f08vec": FLAVOR_F08_VECTOR, "f08_vector": FLAVOR_F08_VECTOR,
+                "1": FLAVOR_F08_VECTOR}.get(v, FLAVOR_C)
+
+    @staticmethod
     def rccl_library() -> str:
         """Path of the RCCL shared object the library bound (one copy per process)."""
         buf = C.create_string_buffer(1024)
@@ -226,6 +239,10 @@ class nka:  # noqa: N801  (the reference's type name)
         if n < 0:
             _check(n, "num_vec")
         return n
+
+    def flavor(self) -> int:
+        """FLAVOR_* this object runs (the default resolved)."""
+        return self._L.nka_hip_flavor(self._handle())
 
     def max_vec(self) -> int:
         return self._L.nka_hip_max_vec(self._handle())

@@ -32,7 +32,7 @@ def test_byte_model_matches_the_schedule(bench):
 def test_roofline_block_is_physical(bench, flavor, pa_ms, pb_ms):
     n, m = 10**8, 20
     mean = [pa_ms, 0.03, pb_ms, pa_ms + 0.03 + pb_ms + 0.01]
-    r = bench.roofline_block(flavor, n, m, mean, 5000.0)
+    r = bench.roofline_block(flavor, n, m, mean, {"pure_read_22_streams_GBps": 7100.0})
     w = bench.words_moved(flavor, m, m)
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     dom = "PB_k_combine" if pb_ms >= pa_ms else "PA_k_dots"

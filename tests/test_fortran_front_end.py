@@ -178,12 +178,24 @@ def _lcg_scenario_oracle(oracle, flavor, vtol=0.05, dot=None, with_outputs=False
     return (rows, np.array(outs)) if with_outputs else rows
 
 
+def _env_flavor(env_flavor):
+    """The front ends pass NKA_HIP_FLAVOR_DEFAULT: compact storage (the C statement) unless
+    the environment variable NKA_HIP_FLAVOR names another flavour (include/nka_hip.h)."""
+    env = dict(os.environ)
+    env.pop("NKA_HIP_FLAVOR", None)
+    if env_flavor:
+        env["NKA_HIP_FLAVOR"] = env_flavor
+    return env
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("exe,flavor_name", [("nka_f95_driver", "F08"), ("nka_c_driver", "C_FLAVOR")])
-def test_f95_wrappers_and_c_compat_header_on_gpu(fortran_build, oracle, exe, flavor_name):
+@pytest.mark.parametrize("exe,env_flavor,flavor_name", [("nka_f95_driver", None, "C_FLAVOR"), ("nka_f95_driver", "f08", "F08"),
+                                                        ("nka_c_driver", None, "C_FLAVOR")])
+def test_f95_wrappers_and_c_compat_header_on_gpu(fortran_build, oracle, exe, env_flavor, flavor_name):
     """Rows f2/f3: the reference's C API names (include/nka_c_compat.h) and its F95
     procedural API (nka_amd/fortran/f95) over the same HIP library."""
-    p = subprocess.run([os.path.join(fortran_build, exe)], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([os.path.join(fortran_build, exe)], capture_output=True, text=True, timeout=300,
+                       env=_env_flavor(env_flavor))
     assert p.returncode == 0, p.stdout + p.stderr
     want = _lcg_scenario_oracle(oracle, getattr(oracle, flavor_name))
     got = [ln.split() for ln in p.stdout.splitlines() if ln.strip()]
@@ -195,9 +207,11 @@ def test_f95_wrappers_and_c_compat_header_on_gpu(fortran_build, oracle, exe, fla
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exe,args,flavor_name", [("nka_dp_driver", [], "F08"), ("nka_f95_driver", ["dp"], "F08"),
-                                                  ("nka_c_driver", ["dp"], "C_FLAVOR")])
-def test_user_dot_product_through_every_front_end(fortran_build, oracle, tmp_path, exe, args, flavor_name):
+@pytest.mark.parametrize("exe,args,env_flavor,flavor_name",
+                         [("nka_dp_driver", [], "f08", "F08"), ("nka_dp_driver", [], None, "C_FLAVOR"),
+                          ("nka_f95_driver", ["dp"], "f08", "F08"), ("nka_f95_driver", ["dp"], None, "C_FLAVOR"),
+                          ("nka_c_driver", ["dp"], None, "C_FLAVOR")])
+def test_user_dot_product_through_every_front_end(fortran_build, oracle, tmp_path, exe, args, env_flavor, flavor_name):
     """Rows a14 / f2 / f3: a caller's own dot product, installed the reference's way
     -- call a%set_dot_prod(dp) (F08:209-214), the optional dp of the F95
     nka_accel_update (src-F95:278-291), the dp argument of the C nka_init
@@ -207,7 +221,7 @@ def test_user_dot_product_through_every_front_end(fortran_build, oracle, tmp_pat
     statements are bit-exact."""
     raw = tmp_path / "out.bin"
     p = subprocess.run([os.path.join(fortran_build, exe)] + args + [str(raw)], capture_output=True, text=True,
-                       timeout=300)
+                       timeout=300, env=_env_flavor(env_flavor))
     assert p.returncode == 0, p.stdout + p.stderr
     want, outs = _lcg_scenario_oracle(oracle, getattr(oracle, flavor_name), dot=_reverse_dot, with_outputs=True)
     _, plain = _lcg_scenario_oracle(oracle, getattr(oracle, flavor_name), with_outputs=True)

@@ -860,6 +860,16 @@ int main(int argc, char **argv) {
       }
     return 0;
   }
+  if (argc > 3 && argv[3][0] == 'c') {   // the ceilings bench.py quotes in its JSON line ("c" zeros, "cr" random): pure read,
+                                         // pure write, and the read/write mixes of PB (compact: 22 R + 5 W, two-vector: 42 R + 5 W)
+    for (int rep = 0; rep < 2; rep++) {
+      RW(22, 0, 4, 1, cu);
+      R(0, 4, 1, true, 2, 0, cu);
+      RT(22, 5, 4, 1, 1, 0, cu, 1);
+      RT(42, 5, 4, 1, 1, 0, cu, 1);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'w') {   // pure-write study: store policy x tiles per iteration x blocks per CU
     for (int g : {cu * 1, cu * 2, cu * 4, cu * 8}) {
       R(0, 4, 1, true, 0, 0, g); R(0, 4, 1, true, 1, 0, g); R(0, 4, 1, true, 2, 0, g); R(0, 4, 1, true, 3, 0, g); R(0, 4, 1, true, 4, 0, g);
