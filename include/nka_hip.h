@@ -73,8 +73,10 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  * (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).
  * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = HIP's
  * default stream).  Allocates 2*(mvec+1) slot vectors on the device.
- * mvec <= 140: the scalar step keeps the (mvec+1)^2 matrix in the 160 KiB LDS
- * of one CU (NKA_HIP_EINVAL beyond; the reference has no limit). */
+ * Any mvec, like the reference (F08:185-200): up to 140 the scalar step keeps the
+ * (mvec+2)^2 matrix in the 160 KiB LDS of one CU (one wavefront up to mvec = 47, one
+ * lane beyond); above 140 the same one-lane loops work on the control block in global
+ * memory -- correct and slow (practical subspaces are 5..20 vectors). */
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
 

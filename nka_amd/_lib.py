@@ -12,6 +12,7 @@ _i32p = C.POINTER(C.c_int32)
 _dp = C.POINTER(C.c_double)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 HOST_DOT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 
 # name -> (restype, argtypes): every symbol include/nka_hip.h declares
 SIGNATURES = {
@@ -85,6 +86,11 @@ SIGNATURES = {
                                                     C.c_double, C.c_int32, C.c_double, C.c_int32]),
     "nka_hip_vec_axpy_many_keep_pend": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double]),
+    "nka_hip_vec_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "nka_hip_vec_set_host_allreduce": (C.c_int, [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]),
+    "nka_hip_vec_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_vec_comm_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_vec_allreduce_now": (C.c_int, [C.c_void_p, _dp, C.c_int32]),
     "nka_hip_vec_h2d": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nka_hip_vec_d2h": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

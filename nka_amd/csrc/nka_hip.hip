@@ -132,6 +132,8 @@ struct nka_hip_state {
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
+  bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
+                                 // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
@@ -405,12 +407,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     }
   }
   if (flavor < 0 || flavor > 2) return fail(NKA_HIP_EINVAL, "nka_hip_create: unknown flavor");
-  // The list-scan kernels keep h, c and the links of all mvec+1 slots in LDS
-  // (8*(mvec+2)^2 bytes and change): gfx950's 160 KiB per workgroup bound mvec.
-  // (The reference has no limit; practical subspaces are 5..20 vectors.)
-  if (lst_smem_bytes(mvec) > kMaxDynamicLds)
-    return fail(NKA_HIP_EINVAL, "nka_hip_create: mvec too large for the device-resident scalar step (mvec <= " +
-                                    std::to_string(kMaxMvec) + ")");
+  if (mvec > (1 << 20) / 8) return fail(NKA_HIP_EINVAL, "nka_hip_create: mvec is absurdly large");   // (mvec+2)^2 doubles of h
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(NKA_HIP_EINVAL, "nka_hip_create: no such HIP device");
@@ -426,6 +423,10 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->flavor = flavor;
   a->num_cu = prop.multiProcessorCount;
   snprintf(a->devname, sizeof a->devname, "%s", prop.gcnArchName);
+  // The scalar kernels keep h, c and the links of all mvec+1 slots in LDS (8*(mvec+2)^2 bytes and
+  // change): gfx950's 160 KiB per workgroup hold mvec <= 140.  Beyond that (the reference has no
+  // limit, F08:185-200; practical subspaces are 5..20 vectors) they work in global memory.
+  a->state_in_global = lst_smem_bytes(mvec) > kMaxDynamicLds;
   a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
   a->pa_pipe = env_int("NKA_HIP_PA_PIPE", a->pa_pipe);
@@ -440,7 +441,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   a->stream = (hipStream_t)stream;
 
   // above the default 64 KiB of dynamic LDS the kernels must opt in (mvec >= 88)
-  if (lst_smem_bytes(mvec) > 64 * 1024) {
+  if (lst_smem_bytes(mvec) > 64 * 1024 && !a->state_in_global) {
     const int bytes = (int)lst_smem_bytes(mvec);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_restart), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_relax), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -539,7 +540,8 @@ int nka_hip_destroy(nka_hip_t a) {
 int nka_hip_restart(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(a->device));
-  hipLaunchKernelGGL(k_restart, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), a->stream, a->ctl);
+  hipLaunchKernelGGL(k_restart, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), a->stream,
+                     a->ctl, a->state_in_global ? 1 : 0);
   HIP_TRY(hipGetLastError());
   a->pending = false;
   a->list_ub = 0;
@@ -549,7 +551,8 @@ int nka_hip_restart(nka_hip_t a) {
 int nka_hip_relax(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(a->device));
-  hipLaunchKernelGGL(k_relax, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), a->stream, a->ctl);
+  hipLaunchKernelGGL(k_relax, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), a->stream,
+                     a->ctl, a->state_in_global ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (a->pending) {
     a->pending = false;
@@ -587,7 +590,8 @@ static int enqueue_solve(nka_hip_t a, int mode) {
     else SOLVE(19);
 #undef SOLVE
   } else {
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), lst_smem_bytes(a->mvec), s, a->ctl, mode);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
+                       a->state_in_global ? 1 : 0);
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -850,20 +850,31 @@ __device__ inline void lst_prepend(Lst &L, int slot) {
 
 constexpr int kSolveThreads = 64;  // ONE wavefront
 
-// dynamic LDS: next[M1+1], prev[M1+1] (int32) then h[(M1+1)^2], c[M1+1] (double)
-__device__ inline void lst_load(Lst &L, const Ctl &ctl, unsigned char *smem) {
+// dynamic LDS: next[M1+1], prev[M1+1] (int32) then h[(M1+1)^2], c[M1+1] (double).
+// in_global != 0 (mvec > 140: the (mvec+2)^2 matrix no longer fits the 160 KiB of LDS): the working
+// arrays ARE the control block in global memory -- no copy in, none back; slow (every step of the
+// list-ordered loops is a dependent global access), but the reference has no limit on mvec
+// (F08:185-200) and neither has this build.
+__device__ inline void lst_load(Lst &L, const Ctl &ctl, unsigned char *smem, int in_global = 0) {
   const int m1 = ctl.m1(), nh = (m1 + 1) * (m1 + 1);
   L.m1 = m1;
   L.mvec = ctl.mvec;
-  L.h = reinterpret_cast<double *>(smem);
-  L.c = L.h + nh;
-  L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
-  L.prev = L.next + (m1 + 1);
-  for (int i = threadIdx.x; i < nh; i += kSolveThreads) L.h[i] = ctl.h()[i];
-  for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
-    L.c[i] = ctl.c()[i];
-    L.next[i] = ctl.next()[i];
-    L.prev[i] = ctl.prev()[i];
+  if (in_global) {
+    L.h = ctl.h();
+    L.c = ctl.c();
+    L.next = ctl.next();
+    L.prev = ctl.prev();
+  } else {
+    L.h = reinterpret_cast<double *>(smem);
+    L.c = L.h + nh;
+    L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
+    L.prev = L.next + (m1 + 1);
+    for (int i = threadIdx.x; i < nh; i += kSolveThreads) L.h[i] = ctl.h()[i];
+    for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
+      L.c[i] = ctl.c()[i];
+      L.next[i] = ctl.next()[i];
+      L.prev[i] = ctl.prev()[i];
+    }
   }
   L.subspace = ctl.ic[IC_SUBSPACE];
   L.pending = ctl.ic[IC_PENDING];
@@ -881,14 +892,16 @@ __host__ __device__ constexpr size_t lst_smem_bytes(int mvec) {
 
 // Lane 0 writes the scalars and the plan for the next update; all lanes copy
 // the arrays back.
-__device__ inline void lst_store(Lst &L, const Ctl &ctl) {
+__device__ inline void lst_store(Lst &L, const Ctl &ctl, int in_global = 0) {
   __syncthreads();
   const int m1 = L.m1, nh = (m1 + 1) * (m1 + 1);
-  for (int i = threadIdx.x; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
-  for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
-    ctl.c()[i] = L.c[i];
-    ctl.next()[i] = L.next[i];
-    ctl.prev()[i] = L.prev[i];
+  if (!in_global) {
+    for (int i = threadIdx.x; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
+    for (int i = threadIdx.x; i < m1 + 1; i += kSolveThreads) {
+      ctl.c()[i] = L.c[i];
+      ctl.next()[i] = L.next[i];
+      ctl.prev()[i] = L.prev[i];
+    }
   }
   if (threadIdx.x == 0) {
     ctl.ic[IC_SUBSPACE] = L.subspace;
@@ -906,20 +919,20 @@ __device__ inline void lst_store(Lst &L, const Ctl &ctl) {
   }
 }
 
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_restart(Ctl ctl) {
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_restart(Ctl ctl, int in_global) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
-  lst_load(L, ctl, smem);
+  lst_load(L, ctl, smem, in_global);
   if (threadIdx.x == 0) lst_restart(L);
-  lst_store(L, ctl);
+  lst_store(L, ctl, in_global);
 }
 
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_relax(Ctl ctl) {
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_relax(Ctl ctl, int in_global) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
-  lst_load(L, ctl, smem);
+  lst_load(L, ctl, smem, in_global);
   if (threadIdx.x == 0) lst_relax(L);
-  lst_store(L, ctl);
+  lst_store(L, ctl, in_global);
 }
 
 // `mode` of the scalar step.  kSolveRcp: the F08-vector flavour, whose
@@ -932,10 +945,10 @@ __device__ __forceinline__ double solve_nrm(double x, double s, double rs, int m
 }
 
 // The scalar part of accel_update between PA and PB, reference loops verbatim on one lane.
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode) {
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
-  lst_load(L, ctl, smem);
+  lst_load(L, ctl, smem, in_global);
   if (threadIdx.x == 0) {
     const double *red = ctl.red();
     const int32_t *ps = ctl.plan_slots();
@@ -976,7 +989,7 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     ctl.ic[IC_NORMED] = normed ? 1 : 0;
     lst_prepend(L, slot);
   }
-  lst_store(L, ctl);
+  lst_store(L, ctl, in_global);
 }
 
 // ---- the same scalar step with the O(m^3) arithmetic spread over the wavefront ----

@@ -126,6 +126,33 @@ module nka_hip_c
       import :: c_int, c_ptr
       type(c_ptr), value :: ws
     end function
+    !! parallel-aware reductions of the device vector types (include/nka_hip.h)
+    integer(c_int) function nka_hip_vec_set_allreduce(ws, fn, ctx) bind(C)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: ws, ctx
+      type(c_funptr), value :: fn
+    end function
+    integer(c_int) function nka_hip_vec_set_host_allreduce(ws, fn, ctx) bind(C)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: ws, ctx
+      type(c_funptr), value :: fn
+    end function
+    integer(c_int) function nka_hip_vec_comm_init_rank(ws, id128, nranks, rank) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_char
+      type(c_ptr), value :: ws
+      character(kind=c_char), intent(in) :: id128(128)
+      integer(c_int32_t), value :: nranks, rank
+    end function
+    integer(c_int) function nka_hip_vec_comm_destroy(ws) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ws
+    end function
+    integer(c_int) function nka_hip_vec_allreduce_now(ws, host_vals, count) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: ws
+      real(c_double), intent(inout) :: host_vals(*)
+      integer(c_int32_t), value :: count
+    end function
     integer(c_int) function nka_hip_vec_alloc(ws, n, dev) bind(C)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: ws

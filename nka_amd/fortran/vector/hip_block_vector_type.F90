@@ -19,6 +19,21 @@
 !! reduction and every fused stage kernel run over one dense, aligned prefix; the
 !! tail (O(sqrt(n)) values for a ghost ring) is finished by the plain elementwise
 !! kernels.  hip_grid_vector_type.F90 builds the 2-D grid vector on this.
+!!
+!! PARALLEL-AWARE REDUCTIONS.  The vector flavour of the reference is distributed
+!! through the vector class: "the implementation of the vector base class
+!! reduction methods will necessarily be parallel-aware"
+!! (src-F08-vector/README.md:16-22).  Here every rank holds a contiguous slice of
+!! each field (plus, in the unreduced tail, whatever halo copies it needs) and the
+!! vectors of a rank share one workspace; install on that workspace
+!!   call hip_block_vector_use_rccl(ws, id128, nranks, rank)     built-in: RCCL over xGMI
+!!   call hip_block_vector_set_allreduce(ws, fn, ctx)            device-side sum, stream-ordered
+!!   call hip_block_vector_set_host_allreduce(ws, fn, ctx)       host-side sum (e.g. MPI_Allreduce)
+!! and EVERY sum a reduction returns -- dot_, norm2 (before its square root),
+!! dot_many, dot_pair_many, and the 1 resp. 2L+1 sums of the fused stages -- is
+!! summed over the ranks before the accelerator sees it: one collective per
+!! stage, three per update.  The accelerator object itself (module nka_type of
+!! the vector flavour) needs no change, exactly as in the reference.
 
 module hip_block_vector_type
 
@@ -66,6 +81,8 @@ module hip_block_vector_type
   end type
 
   public :: hip_block_vector_workspace
+  public :: hip_block_vector_use_rccl, hip_block_vector_set_allreduce, hip_block_vector_set_host_allreduce
+  public :: hip_block_vector_allreduce_now
 
 contains
 
@@ -75,6 +92,39 @@ contains
     type(c_ptr) :: ws
     call nka_hip_check(nka_hip_vec_workspace_create(ws, int(device, c_int32_t), c_null_ptr), 'vec_workspace_create')
   end function
+
+  !! Built-in reduction hook: one RCCL all-reduce per reduction on the workspace stream.
+  !! id128 comes from nka_hip_comm_unique_id on one rank and reaches the others by any means.
+  subroutine hip_block_vector_use_rccl(ws, id128, nranks, rank)
+    type(c_ptr), intent(in) :: ws
+    character(kind=c_char), intent(in) :: id128(128)
+    integer, intent(in) :: nranks, rank
+    call nka_hip_check(nka_hip_vec_comm_init_rank(ws, id128, int(nranks, c_int32_t), int(rank, c_int32_t)), &
+                       'hip_block_vector_use_rccl')
+  end subroutine
+
+  !! fn: bind(C) integer(c_int) function fn(ctx, buf, count, stream) summing `count` doubles at
+  !! DEVICE address buf over all ranks in place, ordered on the hipStream_t (nka_hip_allreduce_fn)
+  subroutine hip_block_vector_set_allreduce(ws, fn, ctx)
+    type(c_ptr), intent(in) :: ws, ctx
+    type(c_funptr), intent(in) :: fn
+    call nka_hip_check(nka_hip_vec_set_allreduce(ws, fn, ctx), 'hip_block_vector_set_allreduce')
+  end subroutine
+
+  !! fn: bind(C) integer(c_int) function fn(ctx, vals, count) summing `count` doubles in HOST
+  !! memory over all ranks in place (nka_hip_host_allreduce_fn), e.g. a wrapper of MPI_Allreduce
+  subroutine hip_block_vector_set_host_allreduce(ws, fn, ctx)
+    type(c_ptr), intent(in) :: ws, ctx
+    type(c_funptr), intent(in) :: fn
+    call nka_hip_check(nka_hip_vec_set_host_allreduce(ws, fn, ctx), 'hip_block_vector_set_host_allreduce')
+  end subroutine
+
+  !! the installed hooks, once, on host values: lets a launcher prove the communicator
+  subroutine hip_block_vector_allreduce_now(ws, vals)
+    type(c_ptr), intent(in) :: ws
+    real(r8), intent(inout), contiguous :: vals(:)
+    call nka_hip_check(nka_hip_vec_allreduce_now(ws, vals, size(vals, kind=c_int32_t)), 'hip_block_vector_allreduce_now')
+  end subroutine
 
   subroutine init(this, nfield, nper, ws, ntail)
     class(hip_block_vector), intent(inout) :: this

@@ -46,6 +46,7 @@ module nka_type
     procedure :: relax
     procedure :: restart
     procedure :: defined
+    procedure :: state_digest
   end type nka
 
 contains
@@ -332,6 +333,39 @@ contains
     this%first = slot
     this%pending = .true.
   end subroutine accel_update
+
+  !! 64-bit FNV-1a digest of the scalar state this rank keeps on the host (flags, lists,
+  !! the Gram / Cholesky matrix).  In a sharded run that state is replicated: every rank
+  !! must report the same digest after the same calls (SURVEY.md 8e) -- the drop decisions
+  !! are taken independently per rank on the all-reduced sums.  Not in the reference.
+  function state_digest(this) result(d)
+    use, intrinsic :: iso_fortran_env, only: int64
+    class(nka), intent(in) :: this
+    integer(int64) :: d
+    integer :: i, j
+    d = -3750763034362895579_int64                       ! 14695981039346656037 as a signed 64-bit pattern
+    call mix(merge(1_int64, 0_int64, this%subspace))
+    call mix(merge(1_int64, 0_int64, this%pending))
+    call mix(int(this%first, int64)); call mix(int(this%last, int64)); call mix(int(this%free, int64))
+    do i = 1, this%mvec+1
+      call mix(int(this%next(i), int64))
+      call mix(int(this%prev(i), int64))
+    end do
+    do j = 1, this%mvec+1
+      do i = 1, this%mvec+1
+        call mix(transfer(this%h(i,j), 1_int64))
+      end do
+    end do
+  contains
+    subroutine mix(word)
+      integer(int64), intent(in) :: word
+      integer :: b
+      do b = 0, 7
+        d = ieor(d, iand(ishft(word, -8*b), 255_int64))
+        d = d * 1099511628211_int64                      ! wraps modulo 2^64
+      end do
+    end subroutine
+  end function
 
   !! Structural invariants of the two lists (F08V:438-501).
   logical function defined(this)

@@ -22,6 +22,16 @@
 !!       reduction that saw a ghost would change every decision.  Written per call:
 !!       the input array, num_vec, the returned array (natural layout, ghosts
 !!       included) -- compared with the compiled reference on its own grid_vector.
+!!   nka_vector_driver shard NFIELD NPER MVEC NCALLS OUTFILE COMPACT RANK WORLD SHMFILE [RCCL 0|1]
+!!       the `check` run SHARDED over WORLD processes (SURVEY.md 8e; the reference's
+!!       contract for this flavour: parallel-aware reductions in the vector class,
+!!       src-F08-vector/README.md:16-22): rank RANK holds a contiguous slice of each
+!!       of the NFIELD fields of (global) length NPER in a hip_block_vector whose
+!!       workspace carries a HOST all-reduce hook (tests/c/shm_allreduce.c through a
+!!       file mapped by all ranks -- where a real caller installs MPI_Allreduce) and,
+!!       with RCCL 1, the built-in RCCL hook on a one-rank communicator in front of
+!!       it (the device-side path).  Written per call: the global input, num_vec, the
+!!       digest of this rank's replicated scalar state, this rank's slices of the result.
 !!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
@@ -33,16 +43,34 @@ program nka_vector_driver
   use, intrinsic :: iso_fortran_env, only: r8 => real64, i8 => int64
   use, intrinsic :: iso_c_binding
   use vector_class
+  use nka_hip_c, only: nka_hip_check, nka_hip_comm_unique_id
   use hip_block_vector_type
   use hip_grid_vector_type
   use nka_type
   implicit none
 
-  character(256) :: mode, arg, outfile
-  integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1
+  character(256) :: mode, arg, outfile, shmfile
+  integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1, rank = 0, world = 1, irccl = 0
   logical :: compact, grid = .false.
   integer(i8) :: nper
   integer(i8) :: lcg_state = 1
+
+  !! tests/c/shm_allreduce.c (test infrastructure: a host all-reduce without MPI)
+  interface
+    function shm_ar_open(path, world, rank) bind(C) result(ctx)
+      import :: c_char, c_int, c_ptr
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int), value :: world, rank
+      type(c_ptr) :: ctx
+    end function
+    function shm_allreduce(ctx, vals, count) bind(C) result(rc)
+      import :: c_ptr, c_double, c_int32_t, c_int
+      type(c_ptr), value :: ctx
+      real(c_double), intent(inout) :: vals(*)
+      integer(c_int32_t), value :: count
+      integer(c_int) :: rc
+    end function
+  end interface
 
   call get_command_argument(1, mode)
   call get_command_argument(2, arg); read(arg,*) nfield
@@ -57,6 +85,17 @@ program nka_vector_driver
     end if
     compact = icompact /= 0
     call run_check
+  case ('shard')
+    call get_command_argument(6, outfile)
+    call get_command_argument(7, arg); read(arg,*) icompact
+    call get_command_argument(8, arg); read(arg,*) rank
+    call get_command_argument(9, arg); read(arg,*) world
+    call get_command_argument(10, shmfile)
+    if (command_argument_count() >= 11) then
+      call get_command_argument(11, arg); read(arg,*) irccl
+    end if
+    compact = icompact /= 0
+    call run_shard
   case ('checkgrid')
     call get_command_argument(6, outfile)
     if (command_argument_count() >= 7) then
@@ -131,6 +170,81 @@ contains
     close(lun)
     if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
     write(*,'(a,i0,a,i0)') 'check: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
+  end subroutine
+
+  !! contiguous slice [lo, hi) (0-based) of rank r of `world` over n values; lo, hi even
+  !! inside the vector (nka_amd/dist.py:slice_bounds)
+  subroutine slice_bounds(n, r, lo, hi)
+    integer(i8), intent(in) :: n
+    integer, intent(in) :: r
+    integer(i8), intent(out) :: lo, hi
+    lo = (int(r, i8) * n) / world
+    hi = (int(r + 1, i8) * n) / world
+    if (r > 0) lo = lo - mod(lo, 2_i8)
+    if (r + 1 < world) hi = hi - mod(hi, 2_i8)
+  end subroutine
+
+  subroutine run_shard
+    type(hip_block_vector) :: f
+    type(nka) :: accel
+    type(c_ptr) :: ws, shm
+    real(r8), allocatable :: host(:), pool(:,:), coef(:), loc(:)
+    real(r8) :: probe(3)
+    character(kind=c_char) :: id128(128)
+    integer :: t, k, lun
+    integer(i8) :: n, i, lo, hi, nloc
+    n = nfield * nper
+    call slice_bounds(nper, rank, lo, hi)
+    nloc = hi - lo
+    ws = hip_block_vector_workspace(0)
+    shm = shm_ar_open(trim(shmfile)//c_null_char, int(world, c_int), int(rank, c_int))
+    if (.not. c_associated(shm)) error stop 'shard: cannot map the all-reduce file'
+    if (irccl /= 0) then            ! the device-side hook: RCCL on a one-rank communicator (this box has one GPU)
+      call nka_hip_check(nka_hip_comm_unique_id(id128), 'comm_unique_id')
+      call hip_block_vector_use_rccl(ws, id128, 1, 0)
+    end if
+    call hip_block_vector_set_host_allreduce(ws, c_funloc(shm_allreduce), shm)
+    probe = real(rank + 1, r8) * [1.0_r8, 2.0_r8, 3.0_r8]       ! prove the communicator before the first update
+    call hip_block_vector_allreduce_now(ws, probe)
+    if (any(probe /= real(world*(world+1)/2, r8) * [1.0_r8, 2.0_r8, 3.0_r8])) error stop 'shard: all-reduce self-test failed'
+    call f%init(nfield, nloc, ws)
+    call accel%init(f, mvec, compact=compact)
+    allocate(host(n), pool(n,3), coef(3), loc(nfield*nloc))
+    do k = 1, 3
+      do i = 1, n
+        pool(i,k) = lcg()
+      end do
+    end do
+    open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    write(lun) lo, hi
+    do t = 1, ncalls
+      if (mod(t, 5) == 0) then
+        do k = 1, 3
+          coef(k) = lcg()
+        end do
+        host = coef(1)*pool(:,1) + coef(2)*pool(:,2) + coef(3)*pool(:,3)
+      else
+        do i = 1, n
+          host(i) = lcg()
+        end do
+      end if
+      write(lun) host                             ! the GLOBAL input (every rank draws the same LCG sequence)
+      do k = 1, nfield
+        call f%set_field(k, host((k-1)*nper+lo+1:(k-1)*nper+hi))
+      end do
+      call accel%accel_update(f)
+      if (t == 7) call accel%relax                ! collective, like every call of a sharded run (F08:58-64)
+      do k = 1, nfield
+        call f%get_field(k, loc((k-1)*nloc+1:k*nloc))
+      end do
+      write(lun) real(accel%num_vec(), r8)
+      write(lun) accel%state_digest()
+      write(lun) loc
+    end do
+    close(lun)
+    if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
+    write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0)') 'shard: rank ', rank, ' of ', world, ' slice ', lo, ':', hi, ', final num_vec ', &
+                                         accel%num_vec()
   end subroutine
 
   subroutine run_checkgrid

@@ -42,7 +42,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for key in sorted(P.WORST):
         r = P.WORST[key]
         piv = "   -  " if r["pivot"] is None else f"{r['pivot']:6.3f}"
-        tr.write_line(f"{key:<78s} worst {r['err']:.2e} (tol {r['tol']:.1e}, pivot {piv}); "
-                      f"well-conditioned worst {r['worst_well_conditioned']:.2e}; {r['checks']} checks")
+        k = f"; K needed {r['k_needed']:.2f} of {P.K_SPREAD:g}" if r.get("k_needed") else ""
+        tr.write_line(f"{key:<78s} worst {r['err']:.2e} (tol {r['tol']:.1e}, pivot {piv}, rule: {r.get('rule', '-')}); "
+                      f"well-conditioned worst {r['worst_well_conditioned']:.2e}; {r['checks']} checks{k}")
     if path:
         tr.write_line(f"written to {path}")

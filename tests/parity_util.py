@@ -1,19 +1,94 @@
 """Shared tolerance rule and worst-error bookkeeping of the GPU parity tests.
 
-The bar: ||f_hip - f_ref||_2 / ||f_in||_2 <= 1e-12 for n <= 1e5.
-That figure is asserted UNSCALED whenever the subspace is well conditioned
-(smallest Cholesky pivot of the live list > 0.5).  Below that the coefficients
-solve (L L^T) z = W^T f and rounding differences of the inner products are
-amplified by up to 1/pivot^2 -- the drop rule lets pivots get as small as vtol
-(F08:326), and on the rank-deficient fixture S8_n7_m8 (pivots ~ 0.01) the
-reference's OWN two Fortran flavours differ by 1.3e-10 -- so the bound becomes
-1e-12 / pivot^2 there.  Every check records the error it saw; the worst per
-test is printed at the end of the run and written to gpurun_out/parity_worst.json.
+The bar: ||f_hip - f_ref||_2 / ||f_in||_2 <= 1e-12 for n <= 1e5
+(1e-10 at BASELINE sizes).  That figure is asserted UNSCALED whenever the subspace
+is well conditioned (smallest Cholesky pivot of the live list > 0.5).
+
+Below that the coefficients solve (L L^T) z = W^T f and last-bit differences of the
+inner products are amplified -- the drop rule lets pivots get as small as vtol
+(F08:326).  How much is NOT taken from a formula but from the REFERENCE ITSELF: its
+three flavours (src-F08, src-F08-vector, src-C) differ from one another only in the
+rounding of elementwise statements, so the largest pairwise
+difference of their outputs on the same calls -- the `spread`, taken from the three
+reference outputs the fixtures hold for every call (tests/golden/scenario_*.npz:
+f_out_f08, f_out_f08vec, f_out_c) or, for inputs without a fixture, from the oracle's
+three flavours in lock step (the oracle is pinned to those references bit for bit,
+tests/test_oracle_golden.py) plus the src-F08 flavour with a user dot product that adds
+the same products in another order (class Spread) -- is what the reference's own
+arithmetic does with rounding-level perturbations on THIS input.  The bound in the ill-conditioned branch is
+        max(base, K_SPREAD * spread)          (spread cumulative over the calls so far)
+e.g. 1e-9 on fixture S8 (spread 1.3e-10) and 2e-9 on S9 (2.5e-10) where the former
+1/pivot^2 rule allowed 1.5e-9 and 2.8e-7.  The K actually needed (err / spread) is
+recorded per test and printed.  A test that supplies no spread falls back to
+base / pivot^2 and is labelled so.  Every check records the error it saw; the worst
+per test is printed at the end of the run and written to gpurun_out/parity_worst.json.
 """
 import json
 import os
 
+import numpy as np
+
 WORST = {}     # key -> dict(err=..., tol=..., pivot=..., n=count)
+K_SPREAD = 4.0
+
+
+def _reordered_dot(x, y):
+    """The same rounded products as the reference's dot_product (no FMA in its build here,
+    SURVEY.md 7.2), summed pairwise from the far end instead of sequentially from the front."""
+    return float(np.add.reduce((x * y)[::-1]))
+
+
+class Spread:
+    """The reference's own spread on a call sequence without a fixture: the oracle's three
+    flavours (each bit-identical to its reference flavour) PLUS the src-F08 flavour with its
+    user dot product (set_dot_prod, F08:209-219) set to one that adds the same products in
+    another order -- the order of the sums is the one thing the device path deliberately does
+    differently (blocked), and Fortran leaves the order of dot_product to the
+    compiler anyway -- driven in lock step;
+    .value = largest pairwise ||out_a - out_b|| / ||f_in|| over the calls so far."""
+
+    def __init__(self, oracle, n, m, vtol=None):
+        self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR, oracle.F08)]
+        self.accs[3].set_dot_prod(_reordered_dot)
+        if vtol is not None:
+            self.set_vec_tol(vtol)
+        self.value = 0.0
+
+    def update(self, x):
+        outs = []
+        for a in self.accs:
+            f = np.array(x, dtype=np.float64, copy=True)
+            a.accel_update(f)
+            outs.append(f)
+        nx = max(np.linalg.norm(x), 1e-300)
+        d = max(np.linalg.norm(outs[i] - outs[j]) for i in range(len(outs)) for j in range(i)) / nx
+        self.value = max(self.value, float(d))
+        return self.value
+
+    def relax(self):
+        for a in self.accs:
+            a.relax()
+
+    def restart(self):
+        for a in self.accs:
+            a.restart()
+
+    def set_vec_tol(self, v):
+        for a in self.accs:
+            a.set_vec_tol(v)
+
+
+def fixture_spreads(g):
+    """Cumulative spread per update of a scenario fixture, from the three reference
+    outputs it holds (written by oracle/make_golden.py from the compiled reference)."""
+    ups = [int(i) for op, i, _ in g["ops"] if int(op) == 0]
+    out, cur = [], 0.0
+    for u, idx in enumerate(ups):
+        o = [g[k][u] for k in ("f_out_f08", "f_out_f08vec", "f_out_c")]
+        nx = max(np.linalg.norm(g["inputs"][idx]), 1e-300)
+        cur = max(cur, max(float(np.linalg.norm(o[i] - o[j])) for i in range(3) for j in range(i)) / nx)
+        out.append(cur)
+    return out
 
 
 def pivot_min(state):
@@ -21,27 +96,37 @@ def pivot_min(state):
     return min([abs(state.h[k - 1, k - 1]) for k in live] + [1.0])
 
 
-def tolerance(state, base=1e-12):
+def tolerance(state, base=1e-12, spread=None):
+    """-> (tol, pivot, rule)"""
     piv = pivot_min(state)
-    return (base if piv > 0.5 else base / (piv * piv)), piv
+    if piv > 0.5:
+        return base, piv, "stated"
+    if spread is not None:
+        return max(base, K_SPREAD * spread), piv, "reference spread"
+    return base / (piv * piv), piv, "conditioning (no spread supplied)"
 
 
-def check(err, state, key, base=1e-12, where=None):
-    """Assert err against the rule above and record it under `key`."""
-    tol, piv = tolerance(state, base)
-    rec = WORST.setdefault(key, {"err": 0.0, "tol": tol, "pivot": piv, "checks": 0, "worst_well_conditioned": 0.0})
+def check(err, state, key, base=1e-12, where=None, spread=None):
+    """Assert err against the rule above and record it under `key`.  `spread`: the reference's
+    inter-flavour spread on these calls (Spread.value / fixture_spreads); 0.0 = never loosen."""
+    tol, piv, rule = tolerance(state, base, spread)
+    rec = WORST.setdefault(key, {"err": 0.0, "tol": tol, "pivot": piv, "checks": 0, "worst_well_conditioned": 0.0,
+                                 "rule": rule, "k_needed": 0.0})
     rec["checks"] += 1
     if piv > 0.5:
         rec["worst_well_conditioned"] = max(rec["worst_well_conditioned"], float(err))
+    elif spread and err > base:
+        rec["k_needed"] = max(rec["k_needed"], float(err) / spread)
     if err >= rec["err"]:
-        rec.update(err=float(err), tol=float(tol), pivot=float(piv))
-    assert err <= tol, (key, where, float(err), float(tol), float(piv))
+        rec.update(err=float(err), tol=float(tol), pivot=float(piv), rule=rule)
+    assert err <= tol, (key, where, float(err), float(tol), float(piv), rule)
     return err
 
 
 def record(err, tol, key):
     """Record an error checked against a fixed tolerance (no conditioning rule)."""
-    rec = WORST.setdefault(key, {"err": 0.0, "tol": tol, "pivot": None, "checks": 0, "worst_well_conditioned": 0.0})
+    rec = WORST.setdefault(key, {"err": 0.0, "tol": tol, "pivot": None, "checks": 0, "worst_well_conditioned": 0.0,
+                                 "rule": "fixed", "k_needed": 0.0})
     rec["checks"] += 1
     rec["worst_well_conditioned"] = max(rec["worst_well_conditioned"], float(err))
     if err >= rec["err"]:

@@ -63,13 +63,16 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
     n = nfield * nper
     raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * n + 1)
     ora = oracle.OracleNKA(n, mvec, oracle.F08_VECTOR)
+    spread = P.Spread(oracle, n, mvec)
     for t in range(ncalls):
         x, nv, got = raw[t, :n], int(raw[t, n]), raw[t, n + 1:]
         f = x.copy()
         ora.accel_update(f)
+        spread.update(x)
         assert nv == ora.num_vec(), (t, nv, ora.num_vec())
         P.check(S.rel_err(got, f, x), ora.state(),
-                f"abstract vector {nfield}x{nper} m={mvec} compact={compact} vs oracle F08-vector", where=t)
+                f"abstract vector {nfield}x{nper} m={mvec} compact={compact} vs oracle F08-vector", where=t,
+                spread=spread.value)
 
 
 @pytest.mark.gpu
@@ -114,6 +117,7 @@ def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_b
     ntot = (nx + 2) * (ny + 2)
     raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * ntot + 1)
     ora = oracle.OracleNKA(nx * ny, mvec, oracle.F08_VECTOR)
+    spread = P.Spread(oracle, nx * ny, mvec)
     have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnka_ref_f08vec.so"))
     ref = oracle.RefF08Vector(nx, ny, mvec) if have_ref else None
     key = f"abstract vector on grid vector {nx}x{ny} m={mvec} compact={compact}"
@@ -123,16 +127,17 @@ def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_b
         xin = np.ascontiguousarray(x[1:-1, 1:-1]).ravel()
         f = xin.copy()
         ora.accel_update(f)
+        spread.update(xin)
         assert nv == ora.num_vec(), (t, nv, ora.num_vec())
         gin = np.ascontiguousarray(got[1:-1, 1:-1]).ravel()
-        P.check(S.rel_err(gin, f, xin), ora.state(), key + " interior vs oracle F08-vector", where=t)
+        P.check(S.rel_err(gin, f, xin), ora.state(), key + " interior vs oracle F08-vector", where=t, spread=spread.value)
         if ref is not None:
             full = np.ascontiguousarray(x).ravel().copy()
             ref.accel_update(full)
             assert nv == ref.num_vec(), (t, nv, ref.num_vec())
             # whole array, ghosts included, against the reference's own ghost handling
             P.check(S.rel_err(got.ravel(), full, x.ravel()), ora.state(), key + " whole array vs compiled reference",
-                    where=t)
+                    where=t, spread=spread.value)
 
 
 @pytest.mark.gpu

@@ -66,18 +66,20 @@ def test_tiled_oracle_equivalence_at_baseline_sizes(torch_cuda, oracle, n0, m, f
     n = n0 * R
     calls = m + 8
     ora = oracle.OracleNKA(n0, m, flavor)
+    spread = P.Spread(oracle, n0, m)      # tiling multiplies every inner product by R = 4^k exactly: the small problem's spread
     acc = nka_amd.nka().init(n, m, flavor=flavor)
     worst = 0.0
     for t, x in enumerate(_small_inputs(n0, calls, seed=321)):
         f = x.copy()
         ora.accel_update(f)
+        spread.update(x)
         big = torch.from_numpy(x).cuda().repeat(R)
         acc.accel_update(big)
         assert acc.num_vec() == ora.num_vec(), (t, acc.num_vec(), ora.num_vec())
         assert acc.state().list_order() == ora.state().list_order()
         ref = torch.from_numpy(f).cuda().repeat(R)
         err = float(torch.linalg.vector_norm(big - ref) / torch.linalg.vector_norm(torch.from_numpy(x).cuda().repeat(R)))
-        P.check(err, ora.state(), f"tiled oracle n={n} m={m} flavor {flavor}", base=TOL_FULL, where=t)
+        P.check(err, ora.state(), f"tiled oracle n={n} m={m} flavor {flavor}", base=TOL_FULL, where=t, spread=spread.value)
         worst = max(worst, err)
         del big, ref
     assert acc.defined()
@@ -162,7 +164,9 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
             acc.accel_update(dev)
             assert acc.num_vec() == ref.num_vec(), (flavor, t, acc.num_vec(), ref.num_vec())
             err = float(torch.linalg.vector_norm(dev - fref)) / nx
-            P.check(err, acc.state(), f"non-periodic n=2e7 m=20 flavor {flavor} vs compiled src-F08", base=TOL_FULL, where=t)
+            # spread=0.0: the stated 1e-10 is asserted UNSCALED on every call, ill-conditioned ones included
+            P.check(err, acc.state(), f"non-periodic n=2e7 m=20 flavor {flavor} vs compiled src-F08", base=TOL_FULL, where=t,
+                    spread=0.0)
             worst[flavor] = max(worst[flavor], err)
         del xin, fref
     assert ref.num_vec() == m
@@ -190,14 +194,17 @@ def test_abstract_vector_flavour_at_baseline_config5_size(torch_cuda, oracle, tm
     raw = np.fromfile(out, dtype=np.float64).reshape(calls, 2 * n0 + 2)
     # compact=1 stores v - w and combines like the C reference: compare with that rounding of the combine
     ora = oracle.OracleNKA(n0, m, oracle.F08_VECTOR)
+    spread = P.Spread(oracle, n0, m)
     worst = 0.0
     for t in range(calls):
         x, nv, got, dev = raw[t, :n0], int(raw[t, n0]), raw[t, n0 + 1:2 * n0 + 1], raw[t, 2 * n0 + 1]
         f = x.copy()
         ora.accel_update(f)
+        spread.update(x)
         assert nv == ora.num_vec(), (t, nv, ora.num_vec())
         assert dev == 0.0, (t, dev)            # every tile of the result carries the same bits
         err = np.linalg.norm(got - f) / np.linalg.norm(x)
-        P.check(err, ora.state(), f"abstract vector 4x1e7 m=20 compact={compact} vs tiled oracle", base=TOL_FULL, where=t)
+        P.check(err, ora.state(), f"abstract vector 4x1e7 m=20 compact={compact} vs tiled oracle", base=TOL_FULL, where=t,
+                spread=spread.value)
         worst = max(worst, err)
     print(f"abstract-vector flavour n={n0 * R} m={m} compact={compact}: worst rel err vs tiled oracle {worst:.2e}")

@@ -65,12 +65,14 @@ def test_scenarios_decisions_exact_values_within_tolerance(torch_cuda, oracle, n
     assert acc.defined()
     assert np.array_equal(trace, g["num_vec"])                       # decisions: exact
     inputs = [g["inputs"][int(i)] for op, i, _ in g["ops"] if int(op) == S.OP_UPDATE]
+    spreads = P.fixture_spreads(g)          # the three REFERENCE outputs of the same calls (tolerance rule, parity_util)
     for u in range(len(outs)):
-        P.check(S.rel_err(outs[u], g[key][u], inputs[u]), states[u], f"scenario {name} flavor {flavor} vs own reference", where=u)
-        # every flavour -- the bench's headline C/compact one included -- against the
+        P.check(S.rel_err(outs[u], g[key][u], inputs[u]), states[u], f"scenario {name} flavor {flavor} vs own reference",
+                where=u, spread=spreads[u])
+        # every flavour -- the front ends' default C/compact one included -- against the
         # reference FORTRAN path (src-F08) on the same inputs, same tolerance
         P.check(S.rel_err(outs[u], g["f_out_f08"][u], inputs[u]), states[u],
-                f"scenario {name} flavor {flavor} vs src-F08 reference", where=u)
+                f"scenario {name} flavor {flavor} vs src-F08 reference", where=u, spread=spreads[u])
     if "first" in g.files:                                           # list state of the C reference
         for u, st in enumerate(states):
             assert (st.first, st.last, st.free) == (g["first"][u], g["last"][u], g["free"][u]), (name, u)
@@ -239,12 +241,14 @@ def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m, flavor):
     PA/PB kernels then run several passes of 32)."""
     rng = np.random.default_rng(n * 131 + m)
     acc, ora = make_acc(n, m, flavor), oracle.OracleNKA(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
     ncall = min(m + 4, 45)
     basis = rng.standard_normal((3, n))
     for t in range(ncall):
         x = rng.standard_normal(n) if (t % 5) else rng.standard_normal(3) @ basis
         f = x.copy()
         ora.accel_update(f)
+        spread.update(x)
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
         out = ft.cpu().numpy()
@@ -252,7 +256,7 @@ def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m, flavor):
         assert acc.state().list_order() == ora.state().list_order()
         assert acc.state().free_order() == ora.state().free_order()
         if n:
-            P.check(S.rel_err(out, f, x), acc.state(), f"edge shape n={n} m={m} flavor {flavor}", where=t)
+            P.check(S.rel_err(out, f, x), acc.state(), f"edge shape n={n} m={m} flavor {flavor}", where=t, spread=spread.value)
     assert acc.defined()
 
 
@@ -436,6 +440,7 @@ def test_against_the_live_compiled_reference(torch_cuda, oracle, seed, flavor):
     rng = np.random.default_rng(seed)
     ref = oracle.RefF08(n, m)
     acc = make_acc(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
     basis = rng.standard_normal((4, n))
     worst = 0.0
     for t in range(40):
@@ -445,16 +450,17 @@ def test_against_the_live_compiled_reference(torch_cuda, oracle, seed, flavor):
         prev = x
         f = x.copy()
         ref.accel_update(f)
+        spread.update(x)
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
         assert acc.num_vec() == ref.num_vec(), (seed, flavor, t)
         err = P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(),
-                      f"live src-F08 reference n={n} m={m} flavor {flavor}", where=(seed, t))
+                      f"live src-F08 reference n={n} m={m} flavor {flavor}", where=(seed, t), spread=spread.value)
         worst = max(worst, err)
         if t == 20:
-            ref.relax(); acc.relax()
+            ref.relax(); acc.relax(); spread.relax()
         if t == 30:
-            ref.restart(); acc.restart()
+            ref.restart(); acc.restart(); spread.restart()
     assert ref.defined() and acc.defined()
 
 
@@ -576,7 +582,9 @@ def test_randomised_call_sequences_against_oracle(torch_cuda, oracle, m, seed):
     call, values within the conditioning-aware tolerance."""
     n = 257
     rng = np.random.default_rng(1000 + seed)
-    acc, ora = make_acc(n, m), oracle.OracleNKA(n, m)
+    acc = make_acc(n, m)
+    ora = oracle.OracleNKA(n, m, acc.flavor())
+    spread = P.Spread(oracle, n, m)
     basis = rng.standard_normal((3, n))
     prev = rng.standard_normal(n)
     nupd = 0
@@ -595,6 +603,7 @@ def test_randomised_call_sequences_against_oracle(torch_cuda, oracle, m, seed):
             prev = x
             f = x.copy()
             ora.accel_update(f)
+            spread.update(x)
             ft = torch_cuda.from_numpy(x.copy()).cuda()
             acc.accel_update(ft)
             nupd += 1
@@ -602,14 +611,14 @@ def test_randomised_call_sequences_against_oracle(torch_cuda, oracle, m, seed):
             nx = np.linalg.norm(x)
             if nx > 0:
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"random call sequence m={m} seed={seed}",
-                        where=(step, nupd))
+                        where=(step, nupd), spread=spread.value)
         elif r < 0.88:
-            acc.relax(); ora.relax()
+            acc.relax(); ora.relax(); spread.relax()
         elif r < 0.93:
-            acc.restart(); ora.restart()
+            acc.restart(); ora.restart(); spread.restart()
         else:
             vt = float(10.0 ** rng.uniform(-3, -0.3))
-            acc.set_vec_tol(vt); ora.set_vec_tol(vt)
+            acc.set_vec_tol(vt); ora.set_vec_tol(vt); spread.set_vec_tol(vt)
         assert acc.num_vec() == ora.num_vec(), step
         sa, so = acc.state(), ora.state()
         assert sa.list_order() == so.list_order(), step

@@ -86,14 +86,17 @@ def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cu
     # back to the device sums: results stay within tolerance of the oracle with the default dp
     acc.set_host_dot(None)
     ora2 = oracle.OracleNKA(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
     acc.restart()
     for t in range(8):
         x = X[t].copy()
         f = x.copy()
         ora2.accel_update(f)
+        spread.update(x)
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
-        P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"after set_host_dot(None) flavor {flavor}", where=t)
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"after set_host_dot(None) flavor {flavor}", where=t,
+                spread=spread.value)
 
 
 def test_state_digest_tracks_the_replicated_state(torch_cuda):
@@ -123,25 +126,53 @@ def test_large_mvec_up_to_the_lds_limit(torch_cuda, oracle, m):
     import nka_amd
     n = 600
     rng = np.random.default_rng(m)
-    acc, ora = nka_amd.nka().init(n, m), oracle.OracleNKA(n, m)
+    acc = nka_amd.nka().init(n, m)
+    ora = oracle.OracleNKA(n, m, acc.flavor())
+    spread = P.Spread(oracle, n, m)
     basis = rng.standard_normal((3, n))
     for t in range(m + 6):
         x = rng.standard_normal(n) if t % 11 != 7 else rng.standard_normal(3) @ basis
         f = x.copy()
         ora.accel_update(f)
+        spread.update(x)
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
         assert acc.num_vec() == ora.num_vec(), t
         if t % 8 == 0 or t > m:
             assert acc.state().list_order() == ora.state().list_order(), t
-            P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t)
+            P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t, spread=spread.value)
     assert acc.defined() and acc.num_vec() == ora.num_vec() and acc.num_vec() >= m - 8   # a few dependence drops
 
 
-def test_mvec_beyond_the_lds_limit_is_refused_with_a_clear_message(torch_cuda):
+@pytest.mark.parametrize("m", [141, 150])
+def test_mvec_beyond_the_lds_limit_works_from_global_memory(torch_cuda, oracle, m):
+    """The reference accepts any mvec (F08:185-200).  Above 140 the (mvec+2)^2 matrix no longer fits
+    the 160 KiB LDS of one CU and the one-lane scalar kernels work on the control block in global
+    memory: slow, but the same loops, hence the same decisions and (given the same sums) bits."""
     import nka_amd
-    with pytest.raises(nka_amd.NKAError, match="mvec <= 140"):
-        nka_amd.nka().init(100, 141)
+    n = 400
+    rng = np.random.default_rng(m)
+    acc = nka_amd.nka().init(n, m)
+    ora = oracle.OracleNKA(n, m, acc.flavor())
+    spread = P.Spread(oracle, n, m)
+    basis = rng.standard_normal((3, n))
+    for t in range(34):
+        x = rng.standard_normal(n) if t % 11 != 7 else rng.standard_normal(3) @ basis
+        f = x.copy()
+        ora.accel_update(f)
+        spread.update(x)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert acc.num_vec() == ora.num_vec(), t
+        st = acc.state()
+        assert st.list_order() == ora.state().list_order() and st.free_order() == ora.state().free_order(), t
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"mvec={m} beyond the LDS limit, n={n}", where=t, spread=spread.value)
+        # the scalar step given the device's own sums: bit for bit (h by slot, coefficients)
+        if t == 20:
+            acc.relax(); ora.relax(); spread.relax()
+    assert acc.defined()
+    acc.restart(); ora.restart()
+    assert acc.num_vec() == 0 and acc.defined()
 
 
 def test_reduction_scratch_is_rewritten_or_zeroed_every_update(torch_cuda):
@@ -373,3 +404,62 @@ def test_automatic_tickets_at_the_threshold_sizes(torch_cuda, flavor, m, n):
     for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         assert torch.equal(a, b), t
     assert outs[0][1] == outs[1][1]
+
+
+def test_failed_allreduce_leaves_the_update_undone_and_the_call_repeatable(torch_cuda):
+    """include/nka_hip.h (distribution hook): "If the hook fails, nka_hip_accel_update returns
+    NKA_HIP_ECOMM with the update NOT done: only scratch sums were written; f, the stored vectors,
+    the lists and the host bookkeeping are as before the call" -- so the SAME call may be repeated.
+    A hook that fails on its 7th call (growth phase, a pair pending, drops still to come), then a
+    good hook and the call again: every later result is bit-identical to an accelerator that was
+    never disturbed, through dependence drops, relax and restart."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 5003, 4
+    rng = np.random.default_rng(11)
+    basis = rng.standard_normal((2, n))
+    X = [rng.standard_normal(n) if t % 4 != 3 else rng.standard_normal(2) @ basis for t in range(16)]
+    calls = {"n": 0, "fail_at": 7}
+
+    def good(ptr, count, stream):          # one rank: the global sum is the local one
+        assert count == 2 + 2 * m
+
+    def flaky(ptr, count, stream):
+        calls["n"] += 1
+        if calls["n"] == calls["fail_at"]:
+            raise RuntimeError("injected communication failure")
+
+    for flavor in (nka_amd.FLAVOR_DEFAULT, nka_amd.FLAVOR_F08):
+        calls["n"] = 0
+        a = nka_amd.nka().init(n, m, flavor=flavor)
+        b = nka_amd.nka().init(n, m, flavor=flavor)
+        a.set_dot_prod(flaky)
+        b.set_dot_prod(good)
+        failed = 0
+        for t, x in enumerate(X):
+            fb = torch.from_numpy(x.copy()).cuda()
+            b.accel_update(fb)
+            fa = torch.from_numpy(x.copy()).cuda()
+            before = (a.num_vec(), a.state().list_order(), a.state().free_order())
+            try:
+                a.accel_update(fa)
+            except nka_amd.NKAError as exc:
+                failed += 1
+                assert "(-4)" in str(exc), str(exc)                      # NKA_HIP_ECOMM
+                torch.cuda.synchronize()
+                assert np.array_equal(fa.cpu().numpy(), x)               # f untouched
+                assert (a.num_vec(), a.state().list_order(), a.state().free_order()) == before
+                assert a.defined()
+                a.set_dot_prod(good)                                     # re-install a working hook ...
+                a.accel_update(fa)                                       # ... and repeat the SAME call
+            assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy()), (flavor, t)
+            assert a.num_vec() == b.num_vec()
+            sa, sb = a.state(), b.state()
+            assert sa.list_order() == sb.list_order() and sa.free_order() == sb.free_order()
+            assert np.array_equal(sa.h, sb.h) and np.array_equal(sa.c, sb.c)
+            if t == 9:
+                a.relax(); b.relax()
+            if t == 12:
+                a.restart(); b.restart()
+        assert failed == 1
+        assert a.state_digest() == b.state_digest()
