@@ -415,6 +415,22 @@ def main():
     elapsed, mean, nv, nv_end, replica_check, stats = measure(acc)
     steady = (nv == m)
 
+    # what every rank saw: which GPU, which RCCL, how many ranks ITS communicator connected, its digest of the
+    # replicated state -- so that a multi-GPU record proves by itself that RCCL reduced over N ranks
+    rank_info = None
+    if world > 1 or hook_box[0] != "none":
+        name, ncu = acc.device_info()
+        mine = {"rank": rank, "local_rank": local_rank, "device": f"{name} ({ncu} CUs)", "hook": hook_box[0],
+                "comm_nranks_rank": list(acc.comm_info()), "state_digest": f"{acc.state_digest():016x}",
+                "n_local": n_local, "slice": [lo, hi]}
+        if hook_box[0] == "rccl":
+            mine["rccl_library"] = nka_amd.nka.rccl_library()
+        if world > 1:
+            rank_info = [None] * world
+            dist.all_gather_object(rank_info, mine)
+        else:
+            rank_info = [mine]
+
     # Secondary figure in the same run: the src-F08 rounding (two stored vectors
     # per pair, bit-faithful to F08:397), same workload, same protocol.
     also = None
@@ -455,6 +471,8 @@ def main():
         }
         if replica_check:
             out["replica_check"] = replica_check
+        if rank_info:
+            out["ranks"] = rank_info
         if hook_box[0] == "rccl":
             out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:

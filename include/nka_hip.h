@@ -96,6 +96,16 @@ int nka_hip_set_stream(nka_hip_t a, void *stream);
 /* Replaces nka_delete (C .h:5, .c:261-282) / automatic deallocation (F08). */
 int nka_hip_destroy(nka_hip_t a);
 
+/* Replaces the intrinsic assignment  b = a  of the reference's type, whose allocatable
+ * components make it a DEEP copy (F08:154-168): *out becomes an independent accelerator
+ * with the same vectors (device-to-device copies of v and w), the same lists, factor and
+ * flags, vtol, flavour, device and stream; afterwards the two objects evolve separately.
+ * The copy is ordered on src's stream.  User hooks (set_allreduce, set_host_dot) are
+ * carried over -- like the procedure pointer component dp of the reference, F08:161 --
+ * but NOT the built-in RCCL communicator, which belongs to src: call
+ * nka_hip_comm_init_rank on the copy.  Timing rings are not copied. */
+int nka_hip_clone(nka_hip_t src, nka_hip_t *out);
+
 /* ---- the hot path ------------------------------------------------------ */
 
 /* Replaces  call a%accel_update(f)  (F08:249-419; F08V:219-397; C .h:6,
@@ -174,6 +184,10 @@ int nka_hip_comm_unique_id(void *id128);
 int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank);
 int nka_hip_comm_destroy(nka_hip_t a);
 int nka_hip_comm_library(char *path, int32_t len);
+/* What the handle's built-in communicator itself reports (ncclCommCount / ncclCommUserRank):
+ * *nranks = 0, *rank = -1 without one.  A launcher prints it so that a multi-GPU record proves
+ * how many ranks RCCL really connected. */
+int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
 
 /* Run the installed all-reduce hook once on `count` doubles at device address
  * buf_dev, on the handle's stream (no-op without a hook): lets a launcher check
@@ -197,7 +211,13 @@ int nka_hip_state_digest(nka_hip_t a, uint64_t *digest);
  * on w1' = d/s the Gram row fn(w1', w_k) and the projections fn(f, w_j) -- while
  * the scalar step, the combine and the ring stores stay on the device.  fn must
  * return the GLOBAL dot product (as in the reference, F08:58-64); the all-reduce
- * hook is not applied on top.  2+L vectors cross PCIe per update and the call
+ * hook is not applied on top.  The calls an update makes are a SUPERSET of the
+ * reference's: fn(f, w_k) is evaluated for every older list entry before the drop
+ * decisions are known, i.e. also for an entry this very update then drops (capacity
+ * F08:301-309 or dependence F08:326-345) -- the reference takes its projection row after
+ * the drops (F08:371).  The extra value is discarded; a dp with side effects (call
+ * counters, per-call message tags) sees up to mvec more calls per update than with the
+ * reference, in this order: (d,d); (f,w1'); then per older entry k: (w1',w_k), (f,w_k).  2+L vectors cross PCIe per update and the call
  * synchronises: a compatibility path, orders of magnitude slower than the
  * device sums.  fn = NULL restores them. */
 typedef double (*nka_hip_host_dot_fn)(void *ctx, int64_t n, const double *x, const double *y);
@@ -241,6 +261,13 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 int nka_hip_debug_time_pa(nka_hip_t a, const double *f_dev, int32_t reps, float *ms_mean);
 
 const char *nka_hip_last_error(void);
+/* Device pointers that cross this ABI are checked against their allocation before any launch
+ * (a kernel reading past a buffer faults the GPU): memory handed out by nka_hip_vec_alloc from a
+ * registry of live allocations, any other pointer with hipMemGetAddressRange on every call.
+ * NKA_HIP_CHECK_POINTERS=cached (opt-in) remembers foreign spans that passed for 100 ms per
+ * thread; a caller that frees such a buffer itself calls this to drop what was remembered.
+ * NKA_HIP_CHECK_POINTERS=0 switches the checks off. */
+void nka_hip_invalidate_pointer_cache(void);
 /* "gfx950"-style name of the device the handle runs on, CU count. */
 int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 

@@ -18,6 +18,7 @@ HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_
 SIGNATURES = {
     "nka_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p]),
     "nka_hip_destroy": (C.c_int, [C.c_void_p]),
+    "nka_hip_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "nka_hip_capture_safe": (C.c_int, [C.c_void_p]),
     "nka_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -41,6 +42,7 @@ SIGNATURES = {
     "nka_hip_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "nka_hip_comm_destroy": (C.c_int, [C.c_void_p]),
     "nka_hip_comm_library": (C.c_int, [C.c_char_p, C.c_int32]),
+    "nka_hip_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "nka_hip_allreduce_now": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "nka_hip_state_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nka_hip_set_host_dot": (C.c_int, [C.c_void_p, HOST_DOT_FN, C.c_void_p]),
@@ -50,6 +52,7 @@ SIGNATURES = {
     "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nka_hip_debug_time_pa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_last_error": (C.c_char_p, []),
+    "nka_hip_invalidate_pointer_cache": (None, []),
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "nka_hip_vec_workspace_destroy": (C.c_int, [C.c_void_p]),

@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,33 +55,68 @@ int set_error(int code, const std::string &msg) { return fail(code, msg); }
 // A kernel reading past a caller's buffer faults the GPU (and can take the node
 // with it), so every device pointer that crosses the ABI is checked on the host
 // against the allocation it lies in before any launch: it must be device
-// memory and hold at least n doubles from p on.  NKA_HIP_CHECK_POINTERS=0
-// switches the check off.
-//
-// hipMemGetAddressRange costs 2-3 us; the abstract-vector path passes ~66 pointers
-// per update (measured: 4 % of its time).  So a span that passed is remembered --
-// per thread, direct-mapped by address, with the bytes available from p to the end
-// of its allocation -- and trusted until (a) anything is freed through this
-// library (generation counter) or (b) 100 ms have passed (buffers freed behind the
-// library's back are noticed at the next re-validation at the latest).
+// memory and hold at least n doubles from p on.
+//   * Memory handed out by this library (nka_hip_vec_alloc: every vector of the
+//     device vector types) is looked up in a registry of live allocations: exact,
+//     deterministic, no HIP call (the abstract-vector path passes ~66 pointers per update).
+//   * Any other pointer is checked with hipMemGetAddressRange on EVERY call (2-3 us,
+//     one pointer per accel_update in the array flavours): a buffer the caller freed
+//     and re-allocated shorter at the same address is caught at once.
+//   * NKA_HIP_CHECK_POINTERS=cached (opt-in) remembers a foreign span that passed for
+//     100 ms per thread (dropped on any free through the library and by
+//     nka_hip_invalidate_pointer_cache()); NKA_HIP_CHECK_POINTERS=0 switches the check off.
 std::atomic<uint64_t> g_span_generation{1};
 void invalidate_span_cache() { g_span_generation.fetch_add(1, std::memory_order_relaxed); }
 
+namespace {
+std::mutex g_reg_mu;
+std::map<uintptr_t, size_t> g_reg;     // base address -> bytes, allocations made through this library
+}  // namespace
+void register_allocation(const void *p, size_t bytes) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_reg[reinterpret_cast<uintptr_t>(p)] = bytes;
+}
+void unregister_allocation(const void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_reg.erase(reinterpret_cast<uintptr_t>(p));
+}
+
 int check_device_span(const void *p, int64_t n, const char *what) {
-  static const bool on = [] {
+  static const int mode = [] {      // 0 off, 1 strict (default), 2 cached
     const char *e = getenv("NKA_HIP_CHECK_POINTERS");
-    return !(e && e[0] == '0');
+    if (e && e[0] == '0') return 0;
+    if (e && std::string(e) == "cached") return 2;
+    return 1;
   }();
-  if (!on || n <= 0) return 0;
+  if (mode == 0 || n <= 0) return 0;
   if (!p) return fail(NKA_HIP_EINVAL, std::string(what) + ": NULL device pointer");
+  const size_t need = (size_t)n * sizeof(double);
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.upper_bound(addr);
+    if (it != g_reg.begin()) {
+      --it;
+      if (addr < it->first + it->second) {            // inside an allocation of this library
+        if (addr + need > it->first + it->second)
+          return fail(NKA_HIP_EINVAL, std::string(what) + ": device buffer shorter than the vector length");
+        return 0;
+      }
+    }
+  }
   struct Entry { const void *p; size_t avail; uint64_t gen; int64_t t_ns; };
   thread_local Entry cache[256] = {};
-  const size_t need = (size_t)n * sizeof(double);
-  const uint64_t gen = g_span_generation.load(std::memory_order_relaxed);
-  const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
-                          std::chrono::steady_clock::now().time_since_epoch()).count();
-  Entry &e = cache[(reinterpret_cast<uintptr_t>(p) >> 8) * 0x9E3779B97F4A7C15ull >> 56];
-  if (e.p == p && e.gen == gen && now - e.t_ns < 100000000 && need <= e.avail) return 0;
+  Entry *e = nullptr;
+  uint64_t gen = 0;
+  int64_t now = 0;
+  if (mode == 2) {
+    gen = g_span_generation.load(std::memory_order_relaxed);
+    now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    e = &cache[(addr >> 8) * 0x9E3779B97F4A7C15ull >> 56];
+    if (e->p == p && e->gen == gen && now - e->t_ns < 100000000 && need <= e->avail) return 0;
+  }
   hipDeviceptr_t base = nullptr;
   size_t size = 0;
   if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) {
@@ -89,7 +126,7 @@ int check_device_span(const void *p, int64_t n, const char *what) {
   const char *lo = static_cast<const char *>(p), *end = static_cast<const char *>(base) + size;
   if (lo < static_cast<const char *>(base) || lo + need > end)
     return fail(NKA_HIP_EINVAL, std::string(what) + ": device buffer shorter than the vector length");
-  e = Entry{p, (size_t)(end - lo), gen, now};
+  if (e) *e = Entry{p, (size_t)(end - lo), gen, now};
   return 0;
 }
 }  // namespace nka_detail
@@ -205,6 +242,8 @@ int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
   hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  // (Round 3 measured forming these sums -- and the scalar step -- in the tail of the PA launch, by the block that
+  //  finishes last: 2-4 us SLOWER per update than the launches it saves, profiles/r03/ab_small_pa_tail_not_kept.txt.)
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
                      a->partials, (int)g, 0, MAXL);
   return (int)g;
@@ -387,6 +426,8 @@ extern "C" {
 
 const char *nka_hip_last_error(void) { return g_err.c_str(); }
 
+void nka_hip_invalidate_pointer_cache(void) { nka_detail::invalidate_span_cache(); }
+
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol, int32_t flavor,
                    int32_t device, void *stream) {
   if (!out) return fail(NKA_HIP_EINVAL, "nka_hip_create: out is NULL");
@@ -534,6 +575,47 @@ int nka_hip_destroy(nka_hip_t a) {
     if (e) hipEventDestroy(e);
   a->ev.clear();
   delete a;
+  return 0;
+}
+
+int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
+  if (!src || !out) return fail(NKA_HIP_EINVAL, "nka_hip_clone: null argument");
+  *out = nullptr;
+  nka_hip_t b = nullptr;
+  if (int rc = nka_hip_create(&b, src->n, src->mvec, src->vtol, src->flavor, src->device, (void *)src->stream)) return rc;
+  // same storage geometry by construction (n, mvec and NKA_HIP_SLOT_PAD_BYTES decide it)
+  if (b->vs.stride != src->vs.stride || b->ctl.ic_count() != src->ctl.ic_count() || b->ctl.dc_count() != src->ctl.dc_count()) {
+    nka_hip_destroy(b);
+    return fail(NKA_HIP_ESTATE, "nka_hip_clone: storage geometry differs");
+  }
+  const size_t slot_bytes = (size_t)src->vs.stride * sizeof(double) * (size_t)(src->mvec + 1);
+  hipStream_t s = src->stream;
+  hipError_t e = hipMemcpyAsync(b->vs.v, src->vs.v, slot_bytes, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->vs.w, src->vs.w, slot_bytes, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->ctl.ic, src->ctl.ic, sizeof(int32_t) * src->ctl.ic_count(), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->ctl.dc, src->ctl.dc, sizeof(double) * src->ctl.dc_count(), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) {
+    nka_hip_destroy(b);
+    return fail(NKA_HIP_EHIP, std::string("nka_hip_clone: ") + hipGetErrorString(e));
+  }
+  // what the host knows without looking, and the caller's choices
+  b->pending = src->pending;
+  b->list_ub = src->list_ub;
+  b->bpc[0] = src->bpc[0];
+  b->bpc[1] = src->bpc[1];
+  b->pa_pipe = src->pa_pipe;
+  b->pb_pipe = src->pb_pipe;
+  b->pb_tile = src->pb_tile;
+  b->pb_tickets = src->pb_tickets;
+  b->serial_solve = src->serial_solve;
+  b->debug = src->debug;
+  if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
+    b->allreduce = src->allreduce;
+    b->allreduce_ctx = src->allreduce_ctx;
+  }
+  b->host_dot = src->host_dot;
+  b->host_dot_ctx = src->host_dot_ctx;
+  *out = b;
   return 0;
 }
 
@@ -980,6 +1062,20 @@ int nka_hip_comm_destroy(nka_hip_t a) {
   return 0;
 }
 
+int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (nranks) *nranks = 0;
+  if (rank) *rank = -1;
+  if (!a->comm) return 0;                       // no built-in communicator on this handle
+  int n = 0, r = -1;
+  ncclResult_t e = rccl().CommCount(a->comm, &n);
+  if (e == ncclSuccess) e = rccl().CommUserRank(a->comm, &r);
+  if (e != ncclSuccess) return fail(NKA_HIP_ECOMM, std::string("ncclCommCount/UserRank: ") + rccl().GetErrorString(e));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  return 0;
+}
+
 int nka_hip_comm_library(char *path, int32_t len) {
   if (!path || len <= 0) return fail(NKA_HIP_EINVAL, "bad buffer");
   if (!rccl().ok()) return fail(NKA_HIP_ECOMM, rccl().err);
@@ -1110,6 +1206,7 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
+
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);
   }

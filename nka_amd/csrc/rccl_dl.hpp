@@ -26,6 +26,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   Rccl() {
@@ -47,10 +48,11 @@ struct Rccl {
     NKA_SYM(CommInitRank);
     NKA_SYM(CommDestroy);
     NKA_SYM(CommCount);
+    NKA_SYM(CommUserRank);
     NKA_SYM(AllReduce);
     NKA_SYM(GetErrorString);
 #undef NKA_SYM
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !CommCount || !AllReduce || !GetErrorString) {
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !CommCount || !CommUserRank || !AllReduce || !GetErrorString) {
       err = "the loaded RCCL lacks a required ncclXxx symbol";
       handle = nullptr;
       return;

@@ -27,6 +27,8 @@ namespace nka_detail {
 int set_error(int code, const std::string &msg);
 int check_device_span(const void *p, int64_t n, const char *what);
 void invalidate_span_cache();
+void register_allocation(const void *p, size_t bytes);
+void unregister_allocation(const void *p);
 }
 
 struct nka_hip_vec_ws {
@@ -961,6 +963,7 @@ int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev) {
   if (!ws || !out_dev || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   HIP_TRYV(hipSetDevice(ws->device));
   HIP_TRYV(hipMalloc((void **)out_dev, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  nka_detail::register_allocation(*out_dev, sizeof(double) * (size_t)std::max<int64_t>(n, 1));   // exact pointer checks, no HIP call
   return 0;
 }
 
@@ -969,6 +972,7 @@ int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev) {
   HIP_TRYV(hipSetDevice(ws->device));
   HIP_TRYV(hipStreamSynchronize(ws->stream));
   nka_detail::invalidate_span_cache();
+  nka_detail::unregister_allocation(dev);
   HIP_TRYV(hipFree(dev));
   return 0;
 }

@@ -44,12 +44,16 @@ def broadcast_unique_id(make_id, rank: int, group=None):
     return payload
 
 
-def all_agree(ok: bool, group=None) -> bool:
+def all_agree(ok: bool, group=None, device=None) -> bool:
     """True iff `ok` holds on EVERY rank (a collective MIN through
-    torch.distributed), so that a fallback decision is the same everywhere."""
+    torch.distributed), so that a fallback decision is the same everywhere.
+    `device`: CUDA device index of this rank (nccl backend; default: torch's current)."""
     import torch
     import torch.distributed as dist
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    if dist.get_backend(group) == "nccl":
+        dev = f"cuda:{torch.cuda.current_device() if device is None else device}"
+    else:
+        dev = "cpu"
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return bool(int(t.item()) == 1)
@@ -69,8 +73,24 @@ def check_allreduce(acc, rank: int, world_size: int) -> bool:
         return False
 
 
+def rccl_preflight(acc) -> bool:
+    """Everything nka_hip_comm_init_rank can fail on BEFORE its blocking rendezvous
+    (ncclCommInitRank waits for all ranks): RCCL can be bound in this process and the
+    accelerator's device can be selected.  Local, never blocks."""
+    import torch
+    from .nka import nka
+    try:
+        nka.rccl_library()
+        torch.cuda.set_device(acc._device)
+        return True
+    except Exception:     # noqa: BLE001 -- reported through all_agree by the caller
+        return False
+
+
 def attach_rccl(acc, rank: int, world_size: int, group=None):
-    """Give accelerator `acc` (nka_amd.nka) its own RCCL communicator."""
+    """Give accelerator `acc` (nka_amd.nka) its own RCCL communicator.  Callers that want a
+    collective fallback go through attach_allreduce, which runs rccl_preflight on every rank
+    first: a rank that cannot even reach ncclCommInitRank would leave the others blocked in it."""
     from .nka import nka
     uid = broadcast_unique_id(nka.rccl_unique_id, rank, group)
     acc.use_rccl(uid, world_size, rank)
@@ -83,20 +103,27 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
     (lowest latency); if creating it or the test all-reduce fails on ANY rank,
     every rank drops it and installs the torch.distributed hook instead -- the
     decision is collective, so ranks can never disagree about who reduces with
-    whom.  Returns the hook in use ("rccl" or "torch").  Raises if the torch
-    hook fails its test as well."""
+    whom.  The order matters: ncclCommInitRank is a BLOCKING rendezvous, so what a
+    rank can fail on before reaching it (binding RCCL, selecting its device) is
+    checked locally and agreed on first (rccl_preflight + all_agree) -- an
+    asymmetric early failure then moves every rank to the torch hook instead of
+    leaving the healthy ones waiting in the rendezvous.  Returns the hook in use
+    ("rccl" or "torch").  Raises if the torch hook fails its test as well."""
     import sys
     hook = prefer
     if hook == "rccl":
-        ok = True
-        try:
-            attach_rccl(acc, rank, world_size, group)
-        except Exception as exc:      # noqa: BLE001
-            print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr)
-            ok = False
-        ok = all_agree(ok, group)
+        ok = all_agree(rccl_preflight(acc), group, acc._device)
         if ok:
-            ok = all_agree(check_allreduce(acc, rank, world_size), group)
+            try:
+                attach_rccl(acc, rank, world_size, group)
+            except Exception as exc:      # noqa: BLE001
+                print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr)
+                ok = False
+            ok = all_agree(ok, group, acc._device)
+        elif rank == 0:
+            print("[nka_amd.dist] RCCL pre-flight failed on at least one rank", file=sys.stderr)
+        if ok:
+            ok = all_agree(check_allreduce(acc, rank, world_size), group, acc._device)
         if not ok:
             if rank == 0:
                 print("[nka_amd.dist] RCCL hook unusable on at least one rank; every rank switches to the "
@@ -108,7 +135,7 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
             hook = "torch"
     if hook == "torch":
         attach_torch_allreduce(acc, group)
-        if not all_agree(check_allreduce(acc, rank, world_size), group):
+        if not all_agree(check_allreduce(acc, rank, world_size), group, acc._device):
             raise RuntimeError("the torch.distributed all-reduce hook failed its self-test")
     return hook
 

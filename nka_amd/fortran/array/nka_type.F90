@@ -23,9 +23,10 @@
 !!    PCIe per update; the scalar step, the combine and the stores stay on the
 !!    device) -- a slow path for callers that cannot change, see
 !!    nka_hip_set_host_dot in include/nka_hip.h.
-!!  * the object is a HANDLE and cannot be copied: intrinsic assignment of one
-!!    nka to another would duplicate the handle (double free); the defined
-!!    assignment below stops with a message instead.  Pass objects by reference.
+!!  * b = a is a DEEP copy, as for the reference's type with its allocatable
+!!    components (F08:154-168): the defined assignment below clones the device
+!!    object (nka_hip_clone: device-to-device copies of v, w, lists, factor) and
+!!    carries a user dot product over; the two objects then evolve separately.
 !!  * init takes optional flavor / device / stream arguments.  Without `flavor` the
 !!    object runs the build's DEFAULT: compact storage (the v slot of a normalised
 !!    pair keeps v - w, the combine is f + c*(v - w), the src-C statement), which
@@ -78,8 +79,8 @@ module nka_type
     procedure :: flavor => get_flavor
     procedure :: set_timing
     procedure :: get_timing
-    procedure, private :: no_copy
-    generic :: assignment(=) => no_copy
+    procedure, private :: deep_copy
+    generic :: assignment(=) => deep_copy
     final :: nka_delete
   end type nka
 
@@ -114,12 +115,22 @@ contains
     if (associated(this%user_dp)) deallocate(this%user_dp)
   end subroutine
 
-  !! The reference type has allocatable components and copies deeply; this one is
-  !! a device handle.  A copy would alias it and free it twice.
-  subroutine no_copy(lhs, rhs)
+  !! b = a.  The reference type has allocatable components and copies deeply
+  !! (F08:154-168); this one is a device handle, so the defined assignment clones
+  !! the device object: afterwards lhs and rhs are independent accelerators.
+  subroutine deep_copy(lhs, rhs)
     class(nka), intent(inout) :: lhs
     class(nka), intent(in) :: rhs
-    error stop 'nka (device handle) cannot be copied by assignment; pass the object by reference'
+    if (c_associated(lhs%handle, rhs%handle)) return           ! a = a
+    call nka_delete_handle(lhs)
+    if (.not. c_associated(rhs%handle)) return                 ! copy of an object that was never initialised
+    call nka_hip_check(nka_hip_clone(rhs%handle, lhs%handle), 'nka assignment (deep copy)')
+    if (associated(rhs%user_dp)) then                          ! the dp pointer component travels too (F08:161)
+      allocate(lhs%user_dp)
+      lhs%user_dp%fn => rhs%user_dp%fn
+      call nka_hip_check(nka_hip_set_host_dot(lhs%handle, c_funloc(host_dot_trampoline), c_loc(lhs%user_dp)), &
+                         'nka assignment (deep copy)')
+    end if
   end subroutine
 
   !! call a%set_dot_prod(dot_prod)                             F08:209-214

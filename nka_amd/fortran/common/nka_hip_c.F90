@@ -25,6 +25,11 @@ module nka_hip_c
       import :: c_int, c_ptr
       type(c_ptr), value :: handle
     end function
+    integer(c_int) function nka_hip_clone(src, out) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: src
+      type(c_ptr), intent(out) :: out
+    end function
     integer(c_int) function nka_hip_accel_update(handle, f_dev) bind(C)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle, f_dev

@@ -479,12 +479,12 @@ contains
   subroutine update_many_keep_fused(this, a, xs, b, ys, idx, keep_in, keep_out, pend_a, pend_pre_a, pend_subtract)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a(:), b(:)
-    class(vector), intent(in) :: xs(:), ys(:)
+    class(vector), intent(inout) :: xs(:), ys(:)
     integer, intent(in) :: idx(:)
-    class(vector), intent(inout) :: keep_in, keep_out
+    integer, intent(in) :: keep_in, keep_out     ! xs(keep_in) <- this before, ys(keep_out) <- this after the combine
     real(r8), intent(in), optional :: pend_a, pend_pre_a
     logical, intent(in), optional :: pend_subtract
-    type(c_ptr) :: xp(max(size(idx),1)), yp(max(size(idx),1))
+    type(c_ptr) :: xp(max(size(idx),1)), yp(max(size(idx),1)), kin, kout, kin_tail, kout_tail
     integer :: j
     integer(c_int32_t) :: ppre, psub
     real(r8) :: ppa
@@ -500,54 +500,51 @@ contains
     class is (hip_block_vector)
       select type (ys)
       class is (hip_block_vector)
-        select type (keep_in)
-        class is (hip_block_vector)
-          select type (keep_out)
-          class is (hip_block_vector)
-            do j = 1, size(idx)
-              xp(j) = xs(idx(j))%base
-              yp(j) = ys(idx(j))%base
-            end do
-            if (present(pend_a)) then      ! entry 1 is the raw new pair: normalised on the way
-              call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%nred, this%base, a, xp, b, yp, &
-                                 size(idx, kind=c_int32_t), keep_in%base, keep_out%base, pend_a, ppre, ppa, psub), &
-                                 'vec_update_many_keep_pend')
-            else
-              call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%nred, this%base, a, xp, b, yp, &
-                                 size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_update_many_keep')
-            end if
-            if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
-              do j = 1, size(idx)
-                xp(j) = tail_ptr(xs(idx(j)))
-                yp(j) = tail_ptr(ys(idx(j)))
-              end do
-              if (present(pend_a)) then
-                call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
-                                   b, yp, size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out), pend_a, ppre, &
-                                   ppa, psub), 'vec_update_many_keep_pend')
-              else
-                call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, b, &
-                                   yp, size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), &
-                                   'vec_update_many_keep')
-              end if
-            end if
-            return
-          end select
-        end select
+        kin = xs(keep_in)%base
+        kout = ys(keep_out)%base
+        kin_tail = tail_ptr(xs(keep_in))
+        kout_tail = tail_ptr(ys(keep_out))
+        do j = 1, size(idx)
+          xp(j) = xs(idx(j))%base
+          yp(j) = ys(idx(j))%base
+        end do
+        if (present(pend_a)) then      ! entry 1 is the raw new pair: normalised on the way
+          call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%nred, this%base, a, xp, b, yp, &
+                             size(idx, kind=c_int32_t), kin, kout, pend_a, ppre, ppa, psub), &
+                             'vec_update_many_keep_pend')
+        else
+          call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%nred, this%base, a, xp, b, yp, &
+                             size(idx, kind=c_int32_t), kin, kout), 'vec_update_many_keep')
+        end if
+        if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
+          do j = 1, size(idx)
+            xp(j) = tail_ptr(xs(idx(j)))
+            yp(j) = tail_ptr(ys(idx(j)))
+          end do
+          if (present(pend_a)) then
+            call nka_hip_check(nka_hip_vec_update_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                               b, yp, size(idx, kind=c_int32_t), kin_tail, kout_tail, pend_a, ppre, &
+                               ppa, psub), 'vec_update_many_keep_pend')
+          else
+            call nka_hip_check(nka_hip_vec_update_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, b, &
+                               yp, size(idx, kind=c_int32_t), kin_tail, kout_tail), &
+                               'vec_update_many_keep')
+          end if
+        end if
+        return
       end select
     end select
     error stop 'incompatible arguments to VECTOR%UPDATE_MANY_KEEP'
   end subroutine
 
-  subroutine axpy_many_keep_fused(this, a, xs, idx, keep_in, keep_out, pend_w, pend_a, pend_pre_a)
+  subroutine axpy_many_keep_fused(this, a, xs, idx, ws, keep_in, keep_out, pend_a, pend_pre_a)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a(:)
-    class(vector), intent(in) :: xs(:)
+    class(vector), intent(inout) :: xs(:), ws(:)
     integer, intent(in) :: idx(:)
-    class(vector), intent(inout) :: keep_in, keep_out
-    class(vector), intent(in), optional :: pend_w
+    integer, intent(in) :: keep_in, keep_out     ! ws(keep_in) <- this before, xs(keep_out) <- this after the combine
     real(r8), intent(in), optional :: pend_a, pend_pre_a
-    type(c_ptr) :: xp(max(size(idx),1)), pw, pwt
+    type(c_ptr) :: xp(max(size(idx),1)), pw, pwt, kin, kout, kin_tail, kout_tail
     integer :: j
     integer(c_int32_t) :: ppre
     real(r8) :: ppa
@@ -557,49 +554,45 @@ contains
       ppre = 1
       ppa = pend_pre_a
     end if
-    pw = c_null_ptr
-    pwt = c_null_ptr
-    if (present(pend_w)) then
-      select type (pend_w)
-      class is (hip_block_vector)
-        pw = pend_w%base
-        pwt = tail_ptr(pend_w)
-      class default
-        error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
-      end select
-    end if
     select type (xs)
     class is (hip_block_vector)
-      select type (keep_in)
+      select type (ws)
       class is (hip_block_vector)
-        select type (keep_out)
-        class is (hip_block_vector)
+        kin = ws(keep_in)%base
+        kout = xs(keep_out)%base
+        kin_tail = tail_ptr(ws(keep_in))
+        kout_tail = tail_ptr(xs(keep_out))
+        pw = c_null_ptr
+        pwt = c_null_ptr
+        if (present(pend_a)) then              ! entry 1 is the raw v of the new pair, ws(idx(1)) its raw w
+          pw = ws(idx(1))%base
+          pwt = tail_ptr(ws(idx(1)))
+        end if
+        do j = 1, size(idx)
+          xp(j) = xs(idx(j))%base
+        end do
+        if (present(pend_a)) then
+          call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%nred, this%base, a, xp, &
+                             size(idx, kind=c_int32_t), kin, kout, pw, pend_a, ppre, ppa), &
+                             'vec_axpy_many_keep_pend')
+        else
+          call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%nred, this%base, a, xp, &
+                             size(idx, kind=c_int32_t), kin, kout), 'vec_axpy_many_keep')
+        end if
+        if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
           do j = 1, size(idx)
-            xp(j) = xs(idx(j))%base
+            xp(j) = tail_ptr(xs(idx(j)))
           end do
-          if (present(pend_w) .and. present(pend_a)) then   ! entry 1 is the raw v of the new pair, pend_w its raw w
-            call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%nred, this%base, a, xp, &
-                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base, pw, pend_a, ppre, ppa), &
+          if (present(pend_a)) then
+            call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                               size(idx, kind=c_int32_t), kin_tail, kout_tail, pwt, pend_a, ppre, ppa), &
                                'vec_axpy_many_keep_pend')
           else
-            call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%nred, this%base, a, xp, &
-                               size(idx, kind=c_int32_t), keep_in%base, keep_out%base), 'vec_axpy_many_keep')
+            call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
+                               size(idx, kind=c_int32_t), kin_tail, kout_tail), 'vec_axpy_many_keep')
           end if
-          if (this%ntot > this%nred) then   ! the same statements on the unreduced tail
-            do j = 1, size(idx)
-              xp(j) = tail_ptr(xs(idx(j)))
-            end do
-            if (present(pend_w) .and. present(pend_a)) then
-              call nka_hip_check(nka_hip_vec_axpy_many_keep_pend(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
-                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out), pwt, pend_a, ppre, ppa), &
-                                 'vec_axpy_many_keep_pend')
-            else
-              call nka_hip_check(nka_hip_vec_axpy_many_keep(this%ws, this%ntot - this%nred, tail_ptr(this), a, xp, &
-                                 size(idx, kind=c_int32_t), tail_ptr(keep_in), tail_ptr(keep_out)), 'vec_axpy_many_keep')
-            end if
-          end if
-          return
-        end select
+        end if
+        return
       end select
     end select
     error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'

@@ -295,26 +295,24 @@ contains
         vals(j) = c(idx(j))
       end do
       !! w_new <- f (F08V:336) ; f <- f - c w + c v for every k in list order (F08V:374) ;
-      !! v_new <- f (F08V:382): one stage
+      !! v_new <- f (F08V:382): one stage; the two ring stores are named by slot index
       !! (a pair left un-normalised above is entry 1 = this%first of the lists: never dropped)
       if (this%compact) then                                 ! v slots hold v - w: f <- f + c*(v - w)
         if (scaled) then
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot)
         else if (stored) then
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
-                                pend_w=this%w(idx(1)), pend_a=1.0_r8/s)
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s)
         else
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
-                                pend_w=this%w(idx(1)), pend_a=1.0_r8/s, pend_pre_a=-1.0_r8)
+          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s, pend_pre_a=-1.0_r8)
         end if
       else
         if (scaled) then
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot))
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot)
         else if (stored) then
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
                                   pend_a=1.0_r8/s, pend_subtract=.false.)
         else
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), this%w(slot), this%v(slot), &
+          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
                                   pend_a=1.0_r8/s, pend_pre_a=-1.0_r8, pend_subtract=.false.)
         end if
       end if

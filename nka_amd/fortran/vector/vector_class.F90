@@ -298,42 +298,45 @@ contains
     if (present(scaled)) scaled = .true.
   end subroutine
 
-  !! keep_in <- this ; this <- this + sum_j (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) in
-  !! order ; keep_out <- this  (F08V:336, 374, 382).
+  !! xs(keep_in) <- this ; this <- this + sum_j (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) in
+  !! order ; ys(keep_out) <- this  (F08V:336, 374, 382).
+  !! The two ring stores are named by their INDEX into the arrays the stage already receives
+  !! (and may therefore modify: intent(inout)), never as separate dummies aliasing an element of
+  !! an intent(in) array -- Fortran's argument-aliasing rules would make that undefined for a
+  !! vector type that lives in host memory.  keep_in / keep_out never occur in idx.
   !! pend_a present: xs(idx(1)), ys(idx(1)) are the RAW new pair that a pure-read scale_dot_pair_many
-  !! left untouched; the override normalises them on the way (see there).  Never passed to a type
-  !! whose scale_dot_pair_many stores (this default).
+  !! left untouched; the override normalises them on the way (see there) -- entry idx(1) of xs and
+  !! ys is then MODIFIED.  Never passed to a type whose scale_dot_pair_many stores (this default).
   subroutine update_many_keep(this, a, xs, b, ys, idx, keep_in, keep_out, pend_a, pend_pre_a, pend_subtract)
     class(vector), intent(inout) :: this
     real(r8), intent(in) :: a(:), b(:)
-    class(vector), intent(in) :: xs(:), ys(:)
+    class(vector), intent(inout) :: xs(:), ys(:)
     integer, intent(in) :: idx(:)
-    class(vector), intent(inout) :: keep_in, keep_out
+    integer, intent(in) :: keep_in, keep_out
     real(r8), intent(in), optional :: pend_a, pend_pre_a
     logical, intent(in), optional :: pend_subtract
     if (present(pend_a) .or. present(pend_pre_a) .or. present(pend_subtract)) &
       error stop 'VECTOR%UPDATE_MANY_KEEP: a pending normalisation needs an override that applies it'
-    call keep_in%copy(this)
+    call xs(keep_in)%copy(this)
     call this%update_many(a, xs, b, ys, idx)
-    call keep_out%copy(this)
+    call ys(keep_out)%copy(this)
   end subroutine
 
-  !! keep_in <- this ; this <- this + sum_j a(j)*xs(idx(j)) in order ; keep_out <- this.
-  !! (pend_w, pend_a[, pend_pre_a]): the pending normalisation, compact storage -- xs(idx(1)) is the raw v
-  !! of the new pair, pend_w its raw w; see update_many_keep.
-  subroutine axpy_many_keep(this, a, xs, idx, keep_in, keep_out, pend_w, pend_a, pend_pre_a)
+  !! ws(keep_in) <- this ; this <- this + sum_j a(j)*xs(idx(j)) in order ; xs(keep_out) <- this.
+  !! pend_a[, pend_pre_a]: the pending normalisation, compact storage -- xs(idx(1)) is the raw v of the
+  !! new pair, ws(idx(1)) its raw w; both are MODIFIED by an override that applies it; see update_many_keep.
+  subroutine axpy_many_keep(this, a, xs, idx, ws, keep_in, keep_out, pend_a, pend_pre_a)
     class(vector), intent(inout) :: this
     real(r8), intent(in) :: a(:)
-    class(vector), intent(in) :: xs(:)
+    class(vector), intent(inout) :: xs(:), ws(:)
     integer, intent(in) :: idx(:)
-    class(vector), intent(inout) :: keep_in, keep_out
-    class(vector), intent(in), optional :: pend_w
+    integer, intent(in) :: keep_in, keep_out
     real(r8), intent(in), optional :: pend_a, pend_pre_a
-    if (present(pend_w) .or. present(pend_a) .or. present(pend_pre_a)) &
+    if (present(pend_a) .or. present(pend_pre_a)) &
       error stop 'VECTOR%AXPY_MANY_KEEP: a pending normalisation needs an override that applies it'
-    call keep_in%copy(this)
+    call ws(keep_in)%copy(this)
     call this%axpy_many(a, xs, idx)
-    call keep_out%copy(this)
+    call xs(keep_out)%copy(this)
   end subroutine
 
 end module vector_class

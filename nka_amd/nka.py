@@ -87,6 +87,25 @@ class nka:  # noqa: N801  (the reference's type name)
         self._stream, self._follow_torch_stream = int(stream), explicit_stream is None
         return self
 
+    def copy(self):
+        """b = a of the reference's type is a DEEP copy (allocatable components,
+        F08:154-168): an independent accelerator with the same stored vectors, lists,
+        factor and tolerance; the two then evolve separately.  Python-level hooks
+        (set_dot_prod, set_host_dot) are carried over; the built-in RCCL communicator
+        is not (nka_hip_clone)."""
+        other = nka()
+        h = C.c_void_p()
+        _check(self._L.nka_hip_clone(self._handle(), C.byref(h)), "nka_hip_clone")
+        other._h, other._device, other._vlen, other._mvec = h, self._device, self._vlen, self._mvec
+        other._stream, other._follow_torch_stream = self._stream, self._follow_torch_stream
+        other._cb, other._hd = self._cb, self._hd          # keep the ctypes trampolines alive
+        return other
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
     def delete(self):
         if self._h is not None:
             self._L.nka_hip_destroy(self._h)
@@ -155,6 +174,12 @@ class nka:  # noqa: N801  (the reference's type name)
         """Built-in hook: ONE RCCL all-reduce per update on the object's stream."""
         buf = C.create_string_buffer(unique_id, 128)
         _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank")
+
+    def comm_info(self):
+        """(nranks, rank) as the handle's built-in RCCL communicator reports them; (0, -1) without one."""
+        n, r = C.c_int32(), C.c_int32()
+        _check(self._L.nka_hip_comm_info(self._handle(), C.byref(n), C.byref(r)), "comm_info")
+        return int(n.value), int(r.value)
 
     def drop_rccl(self):
         _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy")

@@ -44,6 +44,32 @@ def main():
     assert nd.all_agree(rank != world - 1) is False
     assert nd.all_agree(False) is False
 
+    # An ASYMMETRIC early failure -- one rank cannot bind RCCL / select its device and so would never
+    # reach the blocking rendezvous ncclCommInitRank -- must move EVERY rank to the torch hook before
+    # anyone enters that rendezvous (attach_allreduce: pre-flight, agree, only then use_rccl).
+    class FakeAcc:
+        _device = 0
+
+        def __init__(self):
+            self.log = []
+
+        def use_rccl(self, *a):
+            raise AssertionError("the blocking RCCL rendezvous was entered although a rank failed its pre-flight")
+
+        def drop_rccl(self):
+            self.log.append("drop")
+
+    saved = nd.rccl_preflight, nd.check_allreduce, nd.attach_torch_allreduce
+    try:
+        nd.rccl_preflight = lambda acc: rank != world - 1            # the last rank fails early
+        nd.check_allreduce = lambda acc, r, w: True
+        nd.attach_torch_allreduce = lambda acc, group=None: acc.log.append("torch")
+        fake = FakeAcc()
+        assert nd.attach_allreduce(fake, rank, world, prefer="rccl") == "torch"
+        assert "torch" in fake.log
+    finally:
+        nd.rccl_preflight, nd.check_allreduce, nd.attach_torch_allreduce = saved
+
     def global_dot(x, y):
         t = torch.tensor([float(np.dot(x, y))], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

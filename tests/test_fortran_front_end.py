@@ -273,3 +273,50 @@ def test_reference_array_caller_against_our_module_on_gpu(tmp_path, args, key):
                        text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.splitlines() == _tables()[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_flavor,flavor_name", [(None, "C_FLAVOR"), ("f08", "F08")])
+def test_assignment_is_a_deep_copy_like_the_reference_type(fortran_build, oracle, tmp_path, env_flavor, flavor_name):
+    """`b = a` of the reference's type copies deeply (allocatable components, F08:154-168).  The
+    drop-in module clones the device object: copied in mid-stream (after call 5, a pair pending, a
+    user dot product installed), `a` and `b` then follow TWO different input streams and each must
+    reproduce its own oracle bit for bit (the user dot product makes the sums bit-identical)."""
+    raw = tmp_path / "copy.bin"
+    p = subprocess.run([os.path.join(fortran_build, "nka_dp_driver"), "copy", str(raw)], capture_output=True, text=True,
+                       timeout=300, env=_env_flavor(env_flavor))
+    assert p.returncode == 0, p.stdout + p.stderr
+    n, m = 501, 4
+    fl = getattr(oracle, flavor_name)
+    XA = oracle.lcg_vectors(12, n, seed=1)
+    XB = oracle.lcg_vectors(7, n, seed=7)
+    a = oracle.OracleNKA(n, m, fl)
+    a.set_vec_tol(0.05)
+    a.set_dot_prod(_reverse_dot)
+    b = oracle.OracleNKA(n, m, fl)        # the oracle has no copy: b replays a's first five calls
+    b.set_vec_tol(0.05)
+    b.set_dot_prod(_reverse_dot)
+    want, rows = [], []
+    for t in range(1, 13):
+        f = XA[t - 1].copy()
+        a.accel_update(f)
+        want.append(f.copy())
+        if t <= 5:
+            g = XA[t - 1].copy()
+            b.accel_update(g)
+        else:
+            g = XB[t - 6].copy()
+            b.accel_update(g)
+            want.append(g.copy())
+            if t == 8:
+                b.relax()
+            rows.append((-t, b.num_vec()))
+        if t == 6:
+            a.relax()
+        if t == 9:
+            a.restart()
+        rows.append((t, a.num_vec()))
+    got_rows = [(int(ln.split()[0]), int(ln.split()[1])) for ln in p.stdout.splitlines() if ln.strip()]
+    assert got_rows == rows
+    dev = np.fromfile(raw, dtype=np.float64).reshape(len(want), n)
+    assert np.array_equal(dev, np.array(want)), np.abs(dev - np.array(want)).max()

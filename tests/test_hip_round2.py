@@ -463,3 +463,53 @@ def test_failed_allreduce_leaves_the_update_undone_and_the_call_repeatable(torch
                 a.restart(); b.restart()
         assert failed == 1
         assert a.state_digest() == b.state_digest()
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+def test_copy_in_mid_stream_gives_two_independent_accelerators(torch_cuda, oracle, flavor):
+    """nka_hip_clone / nka.copy(): the reference's `b = a` is a deep copy (F08:154-168).  Copied in
+    steady state with a pair pending, the two objects follow different inputs, relax and restart
+    independently, and each tracks its own oracle: decisions exact, values within tolerance; the copy
+    starts from the same bits (state digest, stored vectors)."""
+    import nka_amd
+    n, m = 3001, 5
+    rng = np.random.default_rng(40 + flavor)
+    a = nka_amd.nka().init(n, m, flavor=flavor)
+    oa, ob = oracle.OracleNKA(n, m, flavor), oracle.OracleNKA(n, m, flavor)
+    sa, sb = P.Spread(oracle, n, m), P.Spread(oracle, n, m)
+    basis = rng.standard_normal((2, n))
+
+    def step(acc, ora, spread, x, key, t):
+        f = x.copy()
+        ora.accel_update(f)
+        spread.update(x)
+        ft = torch_cuda.from_numpy(x.copy()).cuda()
+        acc.accel_update(ft)
+        assert acc.num_vec() == ora.num_vec(), (key, t)
+        st = acc.state()
+        assert st.list_order() == ora.state().list_order() and st.free_order() == ora.state().free_order(), (key, t)
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"deep copy flavor {flavor} object {key}", where=t, spread=spread.value)
+
+    for t in range(m + 3):
+        x = rng.standard_normal(n)
+        step(a, oa, sa, x, "a", t)
+        fb = x.copy()
+        ob.accel_update(fb)
+        sb.update(x)
+    b = a.copy()
+    assert b.state_digest() == a.state_digest() and b.defined()
+    for slot in a.state().list_order():
+        assert np.array_equal(a.w(slot), b.w(slot)) and np.array_equal(a.v(slot), b.v(slot))
+    for t in range(m + 3, m + 15):
+        xa = rng.standard_normal(n) if t % 4 else rng.standard_normal(2) @ basis
+        xb = rng.standard_normal(n) if t % 3 else rng.standard_normal(2) @ basis
+        step(a, oa, sa, xa, "a", t)
+        step(b, ob, sb, xb, "b", t)
+        if t == m + 6:
+            a.relax(); oa.relax(); sa.relax()
+        if t == m + 9:
+            b.restart(); ob.restart(); sb.restart()
+    assert a.state_digest() != b.state_digest()
+    a.delete()                                  # the copy owns its storage
+    step(b, ob, sb, rng.standard_normal(n), "b", 99)
+    assert b.defined()

@@ -870,6 +870,13 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (argc > 3 && argv[3][0] == 's') {   // what would ONE store stream less buy PB (an out-of-place update that lends f_out)?  ("s", "sr")
+    for (int rep = 0; rep < 3; rep++) {
+      RT(22, 5, 4, 1, 1, 0, cu, 1); RT(22, 4, 4, 1, 1, 0, cu, 1); RT(22, 3, 4, 1, 1, 0, cu, 1);
+      RT(42, 5, 4, 1, 1, 0, cu, 1); RT(42, 4, 4, 1, 1, 0, cu, 1);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'w') {   // pure-write study: store policy x tiles per iteration x blocks per CU
     for (int g : {cu * 1, cu * 2, cu * 4, cu * 8}) {
       R(0, 4, 1, true, 0, 0, g); R(0, 4, 1, true, 1, 0, g); R(0, 4, 1, true, 2, 0, g); R(0, 4, 1, true, 3, 0, g); R(0, 4, 1, true, 4, 0, g);
