@@ -238,12 +238,13 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */
 int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
 
-/* Kernel-variant switches for A/B measurements inside one process (same
- * allocations, same thermal state).  "pa_pipe" / "pb_pipe" (env NKA_HIP_PA_PIPE /
- * NKA_HIP_PB_PIPE): -1 automatic (default); 0 = every load of a tile in flight
+/* DIAGNOSTIC.  Every choice below is made automatically; the switches exist
+ * for A/B measurements inside one process (same allocations, same thermal state) and for the tests
+ * that hold every kernel variant to the same bits.  No environment variable selects a variant.
+ * "pa_pipe" / "pb_pipe": -1 automatic (default); 0 = every load of a tile in flight
  * (k_dots / k_combine, any list length); 201..204 = rolling window (k_dots_win /
  * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.
- * "pb_tickets" (env NKA_HIP_PB_TICKETS): how the blocks of the rolling-window PB
+ * "pb_tickets": how the blocks of the rolling-window PB
  * get their tiles: -1 automatic (default: tickets from 64 tiles per block), 0 =
  * static mapping (tile t -> block t mod G), 1, 2, 4, 8 = from that many global
  * ticket counters, so that the blocks advance as one compact front.
@@ -280,8 +281,9 @@ int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
 int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
-/* A/B switch like nka_hip_set_tuning: "tickets" (env NKA_HIP_VEC_TICKETS) = -1 automatic, 0 static
- * tile mapping, 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep). */
+/* Diagnostic A/B switches like nka_hip_set_tuning: "tickets" = -1 automatic, 0 static tile mapping,
+ * 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep); "win" = 1 / 0:
+ * rolling-window or all-loads-in-flight form of the two heavy stage kernels. */
 int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value);
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
 int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);

@@ -468,14 +468,10 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   // change): gfx950's 160 KiB per workgroup hold mvec <= 140.  Beyond that (the reference has no
   // limit, F08:185-200; practical subspaces are 5..20 vectors) they work in global memory.
   a->state_in_global = lst_smem_bytes(mvec) > kMaxDynamicLds;
-  a->serial_solve = env_int("NKA_HIP_SERIAL_SOLVE", 0) != 0;
+  // (kernel variants and launch geometry are chosen automatically; the switches of nka_hip_set_tuning /
+  //  nka_hip_set_grid exist for in-process A/B measurements and for the tests that hold every variant to
+  //  the same bits -- since round 3 no environment variable selects a variant)
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
-  a->pa_pipe = env_int("NKA_HIP_PA_PIPE", a->pa_pipe);
-  a->pb_pipe = env_int("NKA_HIP_PB_PIPE", a->pb_pipe);
-  a->pb_tickets = env_int("NKA_HIP_PB_TICKETS", a->pb_tickets);
-  if (a->pb_tickets > 0 && a->pb_tickets != 1 && a->pb_tickets != 2 && a->pb_tickets != 4 && a->pb_tickets != 8) a->pb_tickets = -1;
-  a->bpc[0] = env_int("NKA_HIP_PA_BLOCKS_PER_CU", a->bpc[0]);
-  a->bpc[1] = env_int("NKA_HIP_PB_BLOCKS_PER_CU", a->bpc[1]);
 
   // NULL is HIP's default (null) stream, as everywhere in HIP: work is ordered
   // with whatever else the caller enqueues there.
@@ -494,11 +490,11 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   }
 
   // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
-  // the slot stride is padded to 256 B so every slot base allows 16-B loads,
-  // plus NKA_HIP_SLOT_PAD_BYTES (default 0) to skew slots across HBM channels.
-  const int64_t pad = env_int("NKA_HIP_SLOT_PAD_BYTES", 0) / 8;
+  // the slot stride is padded to 256 B so every slot base allows 16-B loads.
+  // (A skew of the slots across HBM channels was measured in round 2 and has no
+  //  systematic effect, power-of-two lengths included: profiles/r02/ab_slot_pad.txt.)
   a->vs.n = vlen_local;
-  a->vs.stride = ((std::max<int64_t>(vlen_local, 1) + 31) / 32) * 32 + (pad / 32) * 32;
+  a->vs.stride = ((std::max<int64_t>(vlen_local, 1) + 31) / 32) * 32;
   a->ctl.mvec = mvec;
   const size_t slot_bytes = (size_t)a->vs.stride * sizeof(double) * (size_t)(mvec + 1);
   int rc = 0;
@@ -583,7 +579,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   *out = nullptr;
   nka_hip_t b = nullptr;
   if (int rc = nka_hip_create(&b, src->n, src->mvec, src->vtol, src->flavor, src->device, (void *)src->stream)) return rc;
-  // same storage geometry by construction (n, mvec and NKA_HIP_SLOT_PAD_BYTES decide it)
+  // same storage geometry by construction (n and mvec decide it)
   if (b->vs.stride != src->vs.stride || b->ctl.ic_count() != src->ctl.ic_count() || b->ctl.dc_count() != src->ctl.dc_count()) {
     nka_hip_destroy(b);
     return fail(NKA_HIP_ESTATE, "nka_hip_clone: storage geometry differs");

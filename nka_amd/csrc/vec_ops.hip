@@ -37,7 +37,8 @@ struct nka_hip_vec_ws {
   int num_cu = 256;
   double *partials = nullptr;  // kMaxGrid
   unsigned *tickets = nullptr; // tile-ticket counters of k_update_many_keep_win (kTicketWords, zero between launches)
-  int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning)
+  int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning "tickets")
+  bool use_win = true;         // rolling-window forms of the two heavy stage kernels (nka_hip_vec_set_tuning "win"; A/B aid)
   double *host_results = nullptr; // pinned, 2*kManyMax+1 doubles
   double *host_results_dev = nullptr;  // its device-side address: the final-sum kernel writes straight into host
                                        // memory (no copy kernel, no staging)
@@ -697,22 +698,6 @@ int grid_for(const nka_hip_vec_ws *ws, int64_t n, int vec, int nloads = 2) {
   return (int)std::min<int64_t>(g, kMaxGrid);
 }
 
-// NKA_HIP_VEC_WIN=0: the all-loads-in-flight forms of the two heavy stage kernels (A/B aid)
-bool use_win() {
-  static const bool on = [] {
-    const char *e = getenv("NKA_HIP_VEC_WIN");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// NKA_HIP_VEC_TICKETS: initial value of the workspace's `tickets` tunable (-1 automatic, 0 static, 1, 2, 4, 8)
-int ticket_groups_env() {
-  const char *e = getenv("NKA_HIP_VEC_TICKETS");
-  const int x = (e && *e) ? atoi(e) : -1;
-  return (x == 0 || x == 1 || x == 2 || x == 4 || x == 8) ? x : -1;
-}
-
 int width_for(int count) { return std::max(4, ((count + 3) / 4) * 4); }   // unroll width 4, 8, ..., kManyMax
 
 #define NKA_DISPATCH_NV(nv, CALL) \
@@ -798,7 +783,7 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     }
     Pend pd = (base == 0) ? pend : Pend();     // the pending pair is entry 0 of the first launch
     if ((pd.flags & 1) && !PAIRS) v2 = v2 && al16(pd.w);
-    const bool win = v2 && use_win();
+    const bool win = v2 && ws->use_win;
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernels: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
     // tile tickets (k_combine_win): one counter while a tile carries >= 22 words per element, else two
@@ -915,7 +900,6 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   auto *ws = new nka_hip_vec_ws();
   ws->device = device;
   ws->stream = (hipStream_t)stream;  // NULL = HIP's default stream
-  ws->ticket_groups = ticket_groups_env();
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e == hipSuccess) ws->num_cu = prop.multiProcessorCount;
@@ -954,6 +938,10 @@ int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value) 
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return nka_detail::set_error(NKA_HIP_EINVAL, "tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
     ws->ticket_groups = value;
+    return 0;
+  }
+  if (std::string(key) == "win") {
+    ws->use_win = value != 0;
     return 0;
   }
   return nka_detail::set_error(NKA_HIP_EINVAL, std::string("unknown tuning key: ") + key);
@@ -1291,7 +1279,7 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
       m.x[j] = ys[j];
       v2 = v2 && al16(m.x[j]);
     }
-    const bool win = v2 && use_win();
+    const bool win = v2 && ws->use_win;
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernel: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : nv + 3);   // rolling-window kernel: one block per CU
 #define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
