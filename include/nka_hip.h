@@ -354,6 +354,16 @@ int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const 
 int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre,
                                      double pre_a, const double *f, const double *const *ys, int32_t count,
                                      double *host_vals_w, double *host_vals_f, double *host_cross);
+/* The norm stage and the scale-and-dot stage as ONE pure-read pass (override of
+ * vector%update_norm2_dots): with d = a*x + z formed in registers only,
+ *   *host_dd = <d,d>, vals_z[j] = <d,ys[j]>, vals_x[j] = <x,ys[j]>, *cross = <x,d>     (RAW sums, count <= 24)
+ * The accelerator takes s = sqrt(<d,d>) and scales the d-sums by 1/s itself -- the Gram row of the normalised
+ * pair as fl(<d,w_k>/s) instead of the sum of fl(d_i/s)*w_k,i, like pass PA of the array flavours: last-bit
+ * differences, decisions and tolerance unaffected -- and hands the whole pending normalisation to the combine
+ * stage (update_many_keep_pend / axpy_many_keep_pend with pre): 8n(8+3m) bytes and TWO reductions per update. */
+int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
+                                        const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
+                                        double *host_vals_x, double *host_cross);
 int nka_hip_vec_update_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
                                       const double *const *xs, const double *b, const double *const *ys,
                                       int32_t count, double *keep_in, double *keep_out, double pend_a,
@@ -386,7 +396,7 @@ int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, c
  * independently (F08V:269-321).  A rank whose slice is empty (n = 0) still takes part in
  * every collective.  A failing hook makes the reduction return NKA_HIP_ECOMM.
  * nka_hip_vec_allreduce_now runs the installed hooks once on `count` host values
- * (count <= 49), so that a launcher can prove the communicator before the first update. */
+ * (count <= 50), so that a launcher can prove the communicator before the first update. */
 typedef int (*nka_hip_host_allreduce_fn)(void *ctx, double *host_vals, int32_t count);
 int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx);
 int nka_hip_vec_set_host_allreduce(nka_hip_vec_ws_t ws, nka_hip_host_allreduce_fn fn, void *ctx);

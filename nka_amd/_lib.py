@@ -84,6 +84,8 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p]),
     "nka_hip_vec_dot_pair_many_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_int32, C.c_double,
                                                    C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp]),
+    "nka_hip_vec_diff_norm_dot_pair_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
+                                                      C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp, _dp]),
     "nka_hip_vec_update_many_keep_pend": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), _dp,
                                                     C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p,
                                                     C.c_double, C.c_int32, C.c_double, C.c_int32]),

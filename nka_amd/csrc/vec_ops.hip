@@ -39,7 +39,7 @@ struct nka_hip_vec_ws {
   unsigned *tickets = nullptr; // tile-ticket counters of k_update_many_keep_win (kTicketWords, zero between launches)
   int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning "tickets")
   bool use_win = true;         // rolling-window forms of the two heavy stage kernels (nka_hip_vec_set_tuning "win"; A/B aid)
-  double *host_results = nullptr; // pinned, 2*kManyMax+1 doubles
+  double *host_results = nullptr; // pinned, 2*kManyMax+2 doubles
   double *host_results_dev = nullptr;  // its device-side address: the final-sum kernel writes straight into host
                                        // memory (no copy kernel, no staging)
   // parallel-aware reductions ("the vector base class reduction methods will necessarily be
@@ -51,7 +51,7 @@ struct nka_hip_vec_ws {
   nka_hip_host_allreduce_fn host_allreduce = nullptr;
   void *host_allreduce_ctx = nullptr;
   ncclComm_t comm = nullptr;
-  double *red_dev = nullptr;      // 2*kManyMax+1 doubles: the sums of one reduction in canonical layout
+  double *red_dev = nullptr;      // 2*kManyMax+2 doubles: the sums of one reduction in canonical layout
 };
 
 namespace {
@@ -305,18 +305,21 @@ __global__ __launch_bounds__(kBlock) void k_update_norm2(int64_t n, double *z, c
 // when the norm stage left it undone,] w <- a*w, v <- a*v (scale, grid_vector_type.F90:
 // 117) [SUB: then v <- (-1)*w + v, the compact option's update1_], both stored, and
 // with the NEW w: partials[j] = <w, y_j>, partials[NV+j] = <f, y_j>, partials[2NV] = <f, w>.
-template <int NV, int VEC, bool SUB, bool PRE>
+template <int NV, int VEC, bool SUB, bool PRE, bool DD = false>
 __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, double *w, double *v, double a, double pre_a,
                                                                 const double *__restrict__ f, ManyArgs m,
                                                                 double *__restrict__ partials, int store) {
   // store == 0: a PURE-READ pass -- the same sums, formed with the same a*(pre_a*f + w) in registers, but
   // neither w nor v is written (v is not even read): the combine stage then normalises the pair itself
   // (k_update_many_keep*, `Pend`).
+  // DD: one more sum, partials[2NV+1] = <w', w'> of the new w' = a*(pre_a*f + w): with a = 1 the NORM stage
+  // and this one are a single pure-read pass (nka_hip_vec_diff_norm_dot_pair_many).
   using V = typename VecT<VEC>::type;
   const int G = gridDim.x;
-  double acc[2 * NV + 1];
+  constexpr int NA = 2 * NV + 1 + (DD ? 1 : 0);
+  double acc[NA];
 #pragma unroll
-  for (int j = 0; j < 2 * NV + 1; j++) acc[j] = 0.0;
+  for (int j = 0; j < NA; j++) acc[j] = 0.0;
   const int64_t ntile = n / (kBlock * VEC);
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
       setc(wv, q, wn);
       setc(vv, q, vn);
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+      if (DD) acc[NA - 1] = fma(wn, wn, acc[NA - 1]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
         acc[j] = fma(wn, ex(yv[j], q), acc[j]);
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
         v[i] = vn;
       }
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+      if (DD) acc[NA - 1] = fma(wn, wn, acc[NA - 1]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
         const double y = (j < m.count ? m.x[j] : f)[i];
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many(int64_t n, doubl
         acc[NV + j] = fma(fq, y, acc[NV + j]);
       }
     }
-  block_reduce_store<2 * NV + 1>(acc, partials, G);
+  block_reduce_store<NA>(acc, partials, G);
 }
 
 // F08V:336, 374, 382 in one pass: keep_in <- z (the raw f kept as w_new), then
@@ -476,18 +481,19 @@ constexpr int win_ring() {
   return NV % 4 == 0 ? 4 : NV % 5 == 0 ? 5 : NV % 6 == 0 ? 6 : NV % 3 == 0 ? 3 : NV % 7 == 0 ? 7 : NV;
 }
 
-template <int NV, bool SUB, bool PRE, int kWin = win_ring<NV>()>
+template <int NV, bool SUB, bool PRE, bool DD = false, int kWin = win_ring<NV>()>
 __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, double *w, double *v, double a,
                                                                     double pre_a, const double *__restrict__ f,
                                                                     ManyArgs m, double *__restrict__ partials, int store) {
-  // store == 0: pure read, see k_scale_dot_pair_many
+  // store == 0: pure read; DD: also <w', w'> -- see k_scale_dot_pair_many
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   static_assert(NV % kWin == 0, "the ring must divide the unroll width");
   const int G = gridDim.x;
-  double acc[2 * NV + 1];
+  constexpr int NA = 2 * NV + 1 + (DD ? 1 : 0);
+  double acc[NA];
 #pragma unroll
-  for (int j = 0; j < 2 * NV + 1; j++) acc[j] = 0.0;
+  for (int j = 0; j < NA; j++) acc[j] = 0.0;
   const double *ys[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) ys[j] = (j < m.count) ? m.x[j] : f;
@@ -518,6 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
       setc(wout, q, wn[q]);
       setc(vout, q, vn);
       acc[2 * NV] = fma(fq[q], wn[q], acc[2 * NV]);
+      if (DD) acc[NA - 1] = fma(wn[q], wn[q], acc[NA - 1]);
     }
     if (store) {
       st(w + e, wout);
@@ -555,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
         v[i] = vn;
       }
       acc[2 * NV] = fma(fq, wn, acc[2 * NV]);
+      if (DD) acc[NA - 1] = fma(wn, wn, acc[NA - 1]);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
         const double y = ys[j][i];
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_dot_pair_many_win(int64_t n, d
         acc[NV + j] = fma(fq, y, acc[NV + j]);
       }
     }
-  block_reduce_store<2 * NV + 1>(acc, partials, G);
+  block_reduce_store<NA>(acc, partials, G);
 }
 
 // two vectors per entry: half the ring keeps the same number of loads in flight (nka_hip.hip:win_ring_pairs)
@@ -809,7 +817,7 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
 // The reduction kernel just enqueued left per-block partials of `rows` rows of `nv` columns (plus
 // one `cross` column); the first `count` columns of each row are wanted.  One block per column sums
 // its partials in the fixed order of k_finalize (same bits) and writes the CANONICAL layout
-//   out[r*count + j] = row r, column j   ;   out[rows*count] = cross
+//   out[r*count + j] = row r, column j   ;   out[rows*count + e] = extra scalar column e (cross, <w',w'>)
 // which depends only on (rows, count) -- never on the padded width nv of the kernel variant a rank
 // happened to take (alignment of its pointers) --, so the ranks of a sharded run always reduce
 // the same number of values in the same places.
@@ -824,7 +832,7 @@ static __global__ __launch_bounds__(kBlock) void k_finalize_rows(const double *_
     if (j >= count) return;                     // padding column of the unrolled kernel (whole block leaves)
     dst = r * count + j;
   } else {
-    dst = rows * count;                         // the cross column
+    dst = rows * count + (c - rows * nv);       // the scalar columns behind the rows
   }
   double r = 0.0;
   for (int b = threadIdx.x; b < G; b += kBlock) r += partials[(size_t)c * G + b];
@@ -850,10 +858,10 @@ int run_host_hook(nka_hip_vec_ws_t ws, double *vals, int total) {
 
 // Results land in ws->host_results (canonical layout).  have == false: this rank's slice is
 // empty, no kernel ran; its contribution is zero but it still takes part in every collective.
-int fetch_sums(nka_hip_vec_ws_t ws, int g, int rows, int nv, int count, bool cross, bool have) {
-  const int total = rows * count + (cross ? 1 : 0);
+int fetch_sums(nka_hip_vec_ws_t ws, int g, int rows, int nv, int count, int extra, bool have) {
+  const int total = rows * count + extra;     // `extra` scalar columns behind the rows (0, 1: cross, 2: cross and <w',w'>)
   if (total <= 0) return 0;
-  const int ncols = rows * nv + (cross ? 1 : 0);
+  const int ncols = rows * nv + extra;
   if (!ws->allreduce) {
     if (have) {
       // single rank (or host-side hook only): straight into pinned host memory, no copy in between
@@ -903,12 +911,12 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e == hipSuccess) ws->num_cu = prop.multiProcessorCount;
-  if (e == hipSuccess) e = hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->partials, sizeof(double) * kMaxGrid * (2 * kManyMax + 2));
   if (e == hipSuccess) e = hipMalloc((void **)&ws->tickets, sizeof(unsigned) * kTicketWords);
   if (e == hipSuccess) e = hipMemset(ws->tickets, 0, sizeof(unsigned) * kTicketWords);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 1), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ws->host_results, sizeof(double) * (2 * kManyMax + 2), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_results_dev, ws->host_results, 0);
-  if (e == hipSuccess) e = hipMalloc((void **)&ws->red_dev, sizeof(double) * (2 * kManyMax + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&ws->red_dev, sizeof(double) * (2 * kManyMax + 2));
   if (e != hipSuccess) {   // free whatever was obtained (hipFree / hipHostFree accept NULL)
     nka_hip_vec_workspace_destroy(ws);
     return nka_detail::set_error(e == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,
@@ -1012,7 +1020,7 @@ int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const doubl
     else
       hipLaunchKernelGGL((k_dot<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
   }
-  if (int rc = fetch_sums(ws, g, 1, 1, 1, false, n > 0)) return rc;
+  if (int rc = fetch_sums(ws, g, 1, 1, 1, 0, n > 0)) return rc;
   *host_result = ws->host_results[0];
   return 0;
 }
@@ -1040,7 +1048,7 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
     ManyArgs m{};
     m.count = std::min(kManyMax, count - base);
     if (n == 0) {                      // empty slice: zeros, but the collective is still joined
-      if (int rc = fetch_sums(ws, 1, 1, m.count, m.count, false, false)) return rc;
+      if (int rc = fetch_sums(ws, 1, 1, m.count, m.count, 0, false)) return rc;
       for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
       continue;
     }
@@ -1057,7 +1065,7 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
 #undef LAUNCH2
 #undef LAUNCH1
     HIP_TRYV(hipGetLastError());
-    if (int rc = fetch_sums(ws, g, 1, nv, m.count, false, true)) return rc;
+    if (int rc = fetch_sums(ws, g, 1, nv, m.count, 0, true)) return rc;
     for (int j = 0; j < m.count; j++) host_vals[base + j] = ws->host_results[j];
   }
   return 0;
@@ -1085,7 +1093,7 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     ManyArgs m{};
     m.count = std::max(0, std::min(kManyMax, count - base));
     if (n == 0) {                      // empty slice: zeros, but the collective is still joined
-      if (int rc = fetch_sums(ws, 1, 2, std::max(m.count, 1), m.count, true, false)) return rc;
+      if (int rc = fetch_sums(ws, 1, 2, std::max(m.count, 1), m.count, 1, false)) return rc;
       for (int j = 0; j < m.count; j++) {
         host_vals0[base + j] = ws->host_results[j];
         host_vals1[base + j] = ws->host_results[m.count + j];
@@ -1107,7 +1115,7 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
 #undef LAUNCH2
 #undef LAUNCH1
     HIP_TRYV(hipGetLastError());
-    if (int rc = fetch_sums(ws, g, 2, nv, m.count, true, true)) return rc;
+    if (int rc = fetch_sums(ws, g, 2, nv, m.count, 1, true)) return rc;
     for (int j = 0; j < m.count; j++) {
       host_vals0[base + j] = ws->host_results[j];
       host_vals1[base + j] = ws->host_results[m.count + j];
@@ -1196,7 +1204,7 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
   if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
   if (n == 0) {                        // empty slice: zero, but the collective is still joined
-    if (int rc = fetch_sums(ws, 1, 1, 1, 1, false, false)) return rc;
+    if (int rc = fetch_sums(ws, 1, 1, 1, 1, 0, false)) return rc;
     *host_norm = std::sqrt(ws->host_results[0]);
     return 0;
   }
@@ -1213,7 +1221,7 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
   else
     hipLaunchKernelGGL((k_update_norm2<1, false>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, x, a, ws->partials);
   HIP_TRYV(hipGetLastError());
-  if (int rc = fetch_sums(ws, g, 1, 1, 1, false, true)) return rc;
+  if (int rc = fetch_sums(ws, g, 1, 1, 1, 0, true)) return rc;
   *host_norm = std::sqrt(ws->host_results[0]);     // the square root of the GLOBAL sum
   return 0;
 }
@@ -1223,7 +1231,8 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
 // when count <= 24; longer lists scale in the first launch and only add dots after it.
 static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
-                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store);
+                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store,
+                                    double *host_dd = nullptr);
 
 int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
@@ -1242,23 +1251,41 @@ int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const doubl
                                   host_vals_w, host_vals_f, host_cross, 0);
 }
 
+// The norm stage and the scale-and-dot stage as ONE pure-read pass: with d = a*x + z (nothing stored),
+//   *host_dd = <d,d>, vals_z[j] = <d, ys[j]>, vals_x[j] = <x, ys[j]>, *cross = <x, d>   -- the RAW sums; the caller
+// takes s = sqrt(<d,d>) and scales by 1/s itself (what the array flavour's pass PA does: the Gram row of the
+// normalised pair as fl(<d,w_k>/s) instead of the sum of fl(d_i/s)*w_k,i -- last-bit differences).
+// count <= 24.
+int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
+                                        const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
+                                        double *host_vals_x, double *host_cross) {
+  if (!host_dd) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_diff_norm_dot_pair_many: more than 24 vectors");
+  *host_dd = 0.0;
+  return scale_dot_pair_many_impl(ws, n, const_cast<double *>(z), const_cast<double *>(z), 1.0, 0, 1, a, x, ys, count,
+                                  host_vals_z, host_vals_x, host_cross, 0, host_dd);
+}
+
 static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
-                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store) {
+                                    double *host_vals_w, double *host_vals_f, double *host_cross, int store,
+                                    double *host_dd) {
   if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals_w || !host_vals_f)))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
+  const int extra = host_dd ? 2 : 1;
   *host_cross = 0.0;
   for (int j = 0; j < count; j++) host_vals_w[j] = host_vals_f[j] = 0.0;
   if (n == 0 && !ws_parallel(ws)) return 0;
   HIP_TRYV(hipSetDevice(ws->device));
   if (n == 0) {                        // empty slice: zeros, but every collective is still joined
     const int c0 = std::min(kManyMax, count);
-    if (int rc = fetch_sums(ws, 1, 2, std::max(c0, 1), c0, true, false)) return rc;
+    if (int rc = fetch_sums(ws, 1, 2, std::max(c0, 1), c0, extra, false)) return rc;
     for (int j = 0; j < c0; j++) {
       host_vals_w[j] = ws->host_results[j];
       host_vals_f[j] = ws->host_results[c0 + j];
     }
     *host_cross = ws->host_results[2 * c0];
+    if (host_dd) *host_dd = ws->host_results[2 * c0 + 1];
     if (count > kManyMax) {
       double cross_again = 0.0;
       return nka_hip_vec_dot_pair_many(ws, n, w, f, ys + kManyMax, count - kManyMax, host_vals_w + kManyMax,
@@ -1300,7 +1327,12 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #define L1SN(NV) NKA_SDPM(NV, 1, true, false)
 #define L1NP(NV) NKA_SDPM(NV, 1, false, true)
 #define L1NN(NV) NKA_SDPM(NV, 1, false, false)
-    if (win) {
+#define LWDD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many_win<NV, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
+#define L2DD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
+#define L1DD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
+    if (host_dd) {                       // norm + both rows in one pure-read pass (SUB = false, PRE = true, nothing stored)
+      if (win) { NKA_DISPATCH_EXACT(nv, LWDD) } else if (v2) { NKA_DISPATCH_NV(nv, L2DD) } else { NKA_DISPATCH_NV(nv, L1DD) }
+    } else if (win) {
       if (subtract) { if (pre) { NKA_DISPATCH_EXACT(nv, LWSP) } else { NKA_DISPATCH_EXACT(nv, LWSN) } }
       else          { if (pre) { NKA_DISPATCH_EXACT(nv, LWNP) } else { NKA_DISPATCH_EXACT(nv, LWNN) } }
     } else if (v2) {
@@ -1324,13 +1356,17 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef L1NN
 #undef NKA_SDPM
 #undef NKA_SDPMW
+#undef LWDD
+#undef L2DD
+#undef L1DD
     HIP_TRYV(hipGetLastError());
-    if (int rc = fetch_sums(ws, g, 2, nv, m.count, true, true)) return rc;
+    if (int rc = fetch_sums(ws, g, 2, nv, m.count, extra, true)) return rc;
     for (int j = 0; j < m.count; j++) {
       host_vals_w[j] = ws->host_results[j];
       host_vals_f[j] = ws->host_results[m.count + j];
     }
     *host_cross = ws->host_results[2 * m.count];
+    if (host_dd) *host_dd = ws->host_results[2 * m.count + 1];
   }
   if (count > kManyMax) {   // the rest of a long list: plain two-row dots against the already scaled w
     double cross_again = 0.0;
@@ -1431,7 +1467,7 @@ int nka_hip_vec_comm_destroy(nka_hip_vec_ws_t ws) {
 }
 
 int nka_hip_vec_allreduce_now(nka_hip_vec_ws_t ws, double *host_vals, int32_t count) {
-  if (!ws || count < 0 || count > 2 * kManyMax + 1 || (count > 0 && !host_vals))
+  if (!ws || count < 0 || count > 2 * kManyMax + 2 || (count > 0 && !host_vals))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   if (count == 0) return 0;
   HIP_TRYV(hipSetDevice(ws->device));

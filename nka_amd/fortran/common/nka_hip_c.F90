@@ -297,6 +297,15 @@ module nka_hip_c
       type(c_ptr), intent(in) :: ys(*)
       real(c_double), intent(out) :: vals_w(*), vals_f(*), cross
     end function
+    integer(c_int) function nka_hip_vec_diff_norm_dot_pair_many(ws, n, z, a, x, ys, count, dd, vals_z, vals_x, cross) bind(C)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: ws, z, x
+      integer(c_int64_t), value :: n
+      real(c_double), value :: a
+      integer(c_int32_t), value :: count
+      type(c_ptr), intent(in) :: ys(*)
+      real(c_double), intent(out) :: dd, vals_z(*), vals_x(*), cross
+    end function
     integer(c_int) function nka_hip_vec_update_many_keep_pend(ws, n, z, a, xs, b, ys, count, keep_in, keep_out, &
                                                               pend_a, pend_pre, pend_pre_a, pend_subtract) bind(C)
       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double

@@ -70,6 +70,7 @@ module hip_block_vector_type
     procedure :: axpy_many => axpy_many_fused
     !! fused stage hooks: each group of statements of an update as ONE kernel
     procedure :: update_norm2 => update_norm2_fused
+    procedure :: update_norm2_dots => update_norm2_dots_fused
     procedure :: scale_dot_pair_many => scale_dot_pair_many_fused
     procedure :: update_many_keep => update_many_keep_fused
     procedure :: axpy_many_keep => axpy_many_keep_fused
@@ -413,6 +414,46 @@ contains
     end select
   end function
 
+  !! The norm AND both inner-product rows in one pure-read pass (R (2+L)n): the raw sums of
+  !! d = a*x + this; nothing is stored, the accelerator scales by 1/s and the combine stage
+  !! normalises the pair.  Lists beyond one launch (or NKA_HIP_VEC_FUSE_NORM=0, or the
+  !! deferral switched off) take the separate stages.
+  function update_norm2_dots_fused(this, a, x, ys, idx, vals_this, vals_x, cross, stored, fused) result(s)
+    class(hip_block_vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_x(:), cross
+    logical, intent(out) :: stored, fused
+    real(r8) :: s, dd
+    type(c_ptr) :: ptrs(max(size(idx),1))
+    integer :: j
+    vals_this = 0.0_r8
+    vals_x = 0.0_r8
+    cross = 0.0_r8
+    fused = size(idx) <= 24 .and. defer_scale_enabled() .and. fuse_norm_enabled()
+    if (.not. fused) then
+      s = update_norm2_fused(this, a, x, stored)
+      return
+    end if
+    stored = .false.
+    select type (x)
+    class is (hip_block_vector)
+      select type (ys)
+      class is (hip_block_vector)
+        do j = 1, size(idx)
+          ptrs(j) = ys(idx(j))%base
+        end do
+        call nka_hip_check(nka_hip_vec_diff_norm_dot_pair_many(this%ws, this%nred, this%base, a, x%base, ptrs, &
+                           size(idx, kind=c_int32_t), dd, vals_this, vals_x, cross), 'vec_diff_norm_dot_pair_many')
+        s = sqrt(dd)
+        return
+      end select
+    end select
+    error stop 'incompatible arguments to VECTOR%UPDATE_NORM2_DOTS'
+  end function
+
   !! [apply the deferred update,] scale both members of the new pair and take both
   !! inner-product rows while the stored vectors stream past once (R (3+L)n, W 2n).
   subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled)
@@ -597,6 +638,19 @@ contains
     end select
     error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
   end subroutine
+
+  !! NKA_HIP_VEC_FUSE_NORM=0: the norm stage stays a pass of its own (test / A/B aid; read once)
+  logical function fuse_norm_enabled()
+    logical, save :: known = .false., on = .true.
+    character(len=8) :: val
+    integer :: stat
+    if (.not. known) then
+      call get_environment_variable('NKA_HIP_VEC_FUSE_NORM', val, status=stat)
+      if (stat == 0) on = .not. (val(1:1) == '0')
+      known = .true.
+    end if
+    fuse_norm_enabled = on
+  end function
 
   !! NKA_HIP_VEC_DEFER_SCALE=0: scale_dot_pair_many always stores (A/B aid; read once)
   logical function defer_scale_enabled()

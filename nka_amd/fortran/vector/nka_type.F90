@@ -231,14 +231,29 @@ contains
     class(vector), intent(inout) :: f
     real(r8) :: s, c(this%mvec+1), vals(this%mvec+1), bvals(this%mvec+1), cross
     integer :: k, slot, idx(this%mvec+1), nidx, j
-    logical :: have_rows, stored, scaled
+    logical :: have_rows, have_f_row, stored, scaled, fused
 
     have_rows = .false.
+    have_f_row = .false.
     stored = .true.
     scaled = .true.
+    fused = .false.
+    nidx = 0
     if (this%pending) then
-      s = this%w(this%first)%update_norm2(-1.0_r8, f, stored)   ! s = ||w1 - f|| ; w1 <- w1 - f now or in the next stage   F08V:237-238
-      if (s == 0.0_r8) call this%relax                       ! nothing to learn from a zero difference
+      k = this%next(this%first)                              ! the older entries, in list order
+      do while (k /= 0)
+        nidx = nidx + 1
+        idx(nidx) = k
+        k = this%next(k)
+      end do
+      !! s = ||w1 - f|| ; w1 <- w1 - f now or in a later stage (F08V:237-238).  A vector type may take the RAW
+      !! inner products of d = w1 - f in the same pass (fused): <d,w_k>, <f,w_k>, <f,d>.
+      s = this%w(this%first)%update_norm2_dots(-1.0_r8, f, this%w, idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, &
+                                               stored, fused)
+      if (s == 0.0_r8) then                                  ! nothing to learn from a zero difference
+        call this%relax
+        have_f_row = fused                                   ! <f,w_k> of the list that remains: already taken
+      end if
     end if
 
     if (this%pending) then
@@ -247,16 +262,15 @@ contains
       !! the projection row <f,w_k> (F08V:347) for every older entry, plus <f,w1>.
       !! f is not modified in between, so the values equal the reference's; rows of
       !! entries the factorisation then drops are simply not used.
-      nidx = 0
-      k = this%next(this%first)
-      do while (k /= 0)
-        nidx = nidx + 1
-        idx(nidx) = k
-        k = this%next(k)
-      end do
       !! (`scaled` comes back .false. when the vector type took the rows in a pure-read pass and left
       !!  the normalisation itself to the combine stage below, which reads the pair anyway)
-      if (stored) then
+      if (fused) then                                        ! raw sums of d: scale them, nothing was stored
+        scaled = .false.
+        cross = (1.0_r8/s) * cross
+        do j = 1, nidx
+          vals(j) = (1.0_r8/s) * vals(j)
+        end do
+      else if (stored) then
         call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
                                                     idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, scaled=scaled)
       else                                                   ! the norm stage left w1 <- w1 - f to this one
@@ -271,6 +285,11 @@ contains
       end do
       have_rows = .true.
       call factor_with_drops(this)
+    else if (have_f_row) then
+      do j = 1, nidx
+        c(idx(j)) = bvals(j)
+      end do
+      have_rows = .true.
     end if
 
     slot = this%free

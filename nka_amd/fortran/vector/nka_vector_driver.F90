@@ -402,14 +402,15 @@ contains
                                        ' compact=', compact
     end if
     write(*,'(a,f10.3,a,f10.3,a)') 'updates/s ', 1.0_r8/per, '   ms/update ', 1e3_r8*per, ''
-    !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector (norm stage
-    !! and scale-and-dot stage pure reads, the combine normalising the new pair itself) 8n(10+3m), one
-    !! word per element below the contract figure 8n(11+3m); compact option: 8n(11+2m)
+    !! bytes per update: hook by hook 8n(12+8m); with the stage hooks of hip_block_vector (ONE pure-read
+    !! pass for the norm and both inner-product rows, the combine normalising the new pair itself)
+    !! 8n(8+3m), three words per element below the contract figure 8n(11+3m); compact option: 8n(9+2m)
+    !! (NKA_HIP_VEC_FUSE_NORM=0: the norm stage as its own pass, two words more)
     if (compact) then
-      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks compact (8n(11+2m)) ', 8.0_r8*n*(11+2*mvec)/per/1e9_r8, &
+      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks compact (8n(9+2m)) ', 8.0_r8*n*(9+2*mvec)/per/1e9_r8, &
                                    '   contract GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
     else
-      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks (8n(10+3m)) ', 8.0_r8*n*(10+3*mvec)/per/1e9_r8, &
+      write(*,'(a,f10.1,a,f10.1)') 'moved GB/s, stage hooks (8n(8+3m)) ', 8.0_r8*n*(8+3*mvec)/per/1e9_r8, &
                                    '   contract GB/s (8n(11+3m)) ', 8.0_r8*n*(11+3*mvec)/per/1e9_r8
     end if
     write(*,'(a,f8.4)') 'fraction of the 8 TB/s HBM roofline by contract bytes 8n(11+3m) ', &

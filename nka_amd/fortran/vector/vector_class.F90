@@ -56,6 +56,7 @@ module vector_class
     procedure :: axpy_many
     !! optional stage hooks (overridable, default = the reference's hook sequence)
     procedure :: update_norm2
+    procedure :: update_norm2_dots
     procedure :: scale_dot_pair_many
     procedure :: update_many_keep
     procedure :: axpy_many_keep
@@ -268,6 +269,32 @@ contains
     call this%update(a, x)
     s = this%norm2()
     stored = .true.
+  end function
+
+  !! update_norm2 with an offer: s = || a*x + this ||_2 exactly as update_norm2 (this default body IS
+  !! update_norm2; `fused` = .false.).  A type that can take, in the SAME pure-read pass over `this`, x
+  !! and the ys, the raw inner products of d = a*x + this (nothing stored, `this` left untouched) answers
+  !! fused = .true. and returns
+  !!   vals_this(j) = <d, ys(idx(j))>, vals_x(j) = <x, ys(idx(j))>, cross = <x, d>        (d NOT normalised)
+  !! The accelerator then scales the d-sums by 1/s itself -- the Gram row of the normalised pair as
+  !! fl(<d,w_k>/s) rather than the sum of fl(d_i/s)*w_k,i: last-bit differences -- skips
+  !! scale_dot_pair_many and hands the whole pending normalisation (pend_pre_a = a, pend_a = 1/s) to the
+  !! combine stage, as after update_norm2 with stored = .false. and scale_dot_pair_many with
+  !! scaled = .false.: two reductions per update instead of three.
+  function update_norm2_dots(this, a, x, ys, idx, vals_this, vals_x, cross, stored, fused) result(s)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_x(:), cross
+    logical, intent(out) :: stored, fused
+    real(r8) :: s
+    vals_this = 0.0_r8
+    vals_x = 0.0_r8
+    cross = 0.0_r8
+    fused = .false.
+    s = this%update_norm2(a, x, stored)
   end function
 
   !! Normalise the new pair and take both inner-product rows (F08V:255-264, 347):

@@ -49,16 +49,21 @@ def test_config1_through_fortran_front_end_on_gpu(fortran_build, args, key, flav
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse_norm", [1, 0])
 @pytest.mark.parametrize("compact", [0, 1])
 @pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45),
                                                      (4, 25003, 30, 50)])   # (lists beyond one launch: the stages store)
 def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, tmp_path, nfield, nper, mvec, ncalls,
-                                                        compact):
+                                                        compact, fuse_norm):
     """vector_class hooks on a device-resident block vector, driven by the
-    vector flavour of nka_type, against the oracle's F08-vector flavour."""
+    vector flavour of nka_type, against the oracle's F08-vector flavour.
+    fuse_norm 1 (default): the norm and both inner-product rows in ONE pure-read pass
+    (update_norm2_dots; two passes and two reductions per update); 0: the norm stage as a
+    pass of its own (NKA_HIP_VEC_FUSE_NORM=0; the reference's rounding of the Gram row)."""
     out = tmp_path / "vec.bin"
     p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "check", str(nfield), str(nper),
-                        str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300)
+                        str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, NKA_HIP_VEC_FUSE_NORM=str(fuse_norm)))
     assert p.returncode == 0, p.stdout + p.stderr
     n = nfield * nper
     raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * n + 1)
@@ -71,8 +76,8 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
         spread.update(x)
         assert nv == ora.num_vec(), (t, nv, ora.num_vec())
         P.check(S.rel_err(got, f, x), ora.state(),
-                f"abstract vector {nfield}x{nper} m={mvec} compact={compact} vs oracle F08-vector", where=t,
-                spread=spread.value)
+                f"abstract vector {nfield}x{nper} m={mvec} compact={compact} fuse_norm={fuse_norm} vs oracle F08-vector",
+                where=t, spread=spread.value)
 
 
 @pytest.mark.gpu
@@ -89,7 +94,7 @@ def test_deferred_normalisation_through_the_front_end_is_bit_identical(fortran_b
     outs = []
     for defer in ("0", "1"):
         out = tmp_path / f"defer{defer}.bin"
-        env = dict(os.environ, NKA_HIP_VEC_DEFER_SCALE=defer)
+        env = dict(os.environ, NKA_HIP_VEC_DEFER_SCALE=defer, NKA_HIP_VEC_FUSE_NORM="0")   # (fusing needs the deferral)
         p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), mode, str(dims[0]), str(dims[1]),
                             str(mvec), str(ncalls), str(out), str(compact)], capture_output=True, text=True, timeout=300,
                            env=env)
