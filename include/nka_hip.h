@@ -281,9 +281,8 @@ int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
 int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
-/* Diagnostic A/B switches like nka_hip_set_tuning: "tickets" = -1 automatic, 0 static tile mapping,
- * 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep); "win" = 1 / 0:
- * rolling-window or all-loads-in-flight form of the two heavy stage kernels. */
+/* Diagnostic A/B switch like nka_hip_set_tuning: "tickets" = -1 automatic, 0 static tile mapping,
+ * 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep). */
 int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value);
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
 int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);

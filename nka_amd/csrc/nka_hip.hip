@@ -279,14 +279,12 @@ int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc)
   return 0;
 }
 
+// The all-loads-in-flight PA serves what the rolling-window kernel does not: lists longer than 32 (passes of 32) and an
+// update whose only stored vector is the pending pair (width 4, all padding).  Any other width reaches it only through
+// the diagnostic switch pa_pipe = 0 and is then padded to 32 (same bits; the padding costs time, not correctness).
 int launch_dots_w(int maxl, const nka_hip_state *a, const double *f, int pass, int npass) {
-#define CASE(L) \
-  case L: return launch_dots_1<L, 2>(a, f, pass, npass);
-  switch (maxl) {
-    CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
-  }
-#undef CASE
-  return 0;
+  if (maxl <= 4) return launch_dots_1<4, 2>(a, f, pass, npass);
+  return launch_dots_1<32, 2>(a, f, pass, npass);
 }
 
 template <int MAXK, int VEC, int COMB>
@@ -299,6 +297,13 @@ int launch_combine_1(const nka_hip_state *a, double *f, int pass, int last) {
 
 template <int VEC, int COMB>
 int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int last) {
+  // Compact storage (COMB 2) always takes the rolling-window kernel for lists of <= 32 pairs; the all-loads-in-flight form
+  // serves it beyond that (passes of 32) -- any other width reaches it only through the diagnostic switch pb_pipe = 0
+  // and is padded to 32 (same bits).  The two-vector flavours use every width below the ticket threshold (enqueue_pb).
+  if constexpr (COMB == 2) {
+    if (maxk <= 4) return launch_combine_1<4, VEC, COMB>(a, f, pass, last);
+    return launch_combine_1<32, VEC, COMB>(a, f, pass, last);
+  }
 #define CASE(K) \
   case K: return launch_combine_1<K, VEC, COMB>(a, f, pass, last);
   switch (maxk) {

@@ -38,7 +38,6 @@ struct nka_hip_vec_ws {
   double *partials = nullptr;  // kMaxGrid
   unsigned *tickets = nullptr; // tile-ticket counters of k_update_many_keep_win (kTicketWords, zero between launches)
   int ticket_groups = -1;      // -1 automatic, 0 static tile mapping, 1/2/4/8 counters (nka_hip_vec_set_tuning "tickets")
-  bool use_win = true;         // rolling-window forms of the two heavy stage kernels (nka_hip_vec_set_tuning "win"; A/B aid)
   double *host_results = nullptr; // pinned, 2*kManyMax+2 doubles
   double *host_results_dev = nullptr;  // its device-side address: the final-sum kernel writes straight into host
                                        // memory (no copy kernel, no staging)
@@ -791,7 +790,7 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     }
     Pend pd = (base == 0) ? pend : Pend();     // the pending pair is entry 0 of the first launch
     if ((pd.flags & 1) && !PAIRS) v2 = v2 && al16(pd.w);
-    const bool win = v2 && ws->use_win;
+    const bool win = v2;                                                    // 16-byte path = the rolling-window kernel
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernels: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : (PAIRS ? 2 : 1) * nv + 1);   // rolling-window kernels: one block per CU
     // tile tickets (k_combine_win): one counter while a tile carries >= 22 words per element, else two
@@ -801,11 +800,9 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     if (!win || !ws->tickets || g % std::max(ng, 1) != 0 || n / (kBlock * 2) >= ((int64_t)1 << 31) - 2 * kMaxGrid) ng = 0;
     unsigned *const tix = ng > 0 ? ws->tickets : nullptr;
 #define LAUNCHW(NV) hipLaunchKernelGGL((k_update_many_keep_win<NV, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, tix, std::max(ng, 1), pd)
-#define LAUNCH2(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 2, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, pd)
 #define LAUNCH1(NV) hipLaunchKernelGGL((k_update_many_keep<NV, 1, PAIRS>), dim3(g), dim3(kBlock), 0, ws->stream, n, z, m, kin, kout, pd)
-    if (win) { NKA_DISPATCH_EXACT(nv, LAUNCHW) } else if (v2) { NKA_DISPATCH_NV(nv, LAUNCH2) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }
+    if (win) { NKA_DISPATCH_EXACT(nv, LAUNCHW) } else { NKA_DISPATCH_NV(nv, LAUNCH1) }   // (unaligned operands: 8-byte path)
 #undef LAUNCHW
-#undef LAUNCH2
 #undef LAUNCH1
     HIP_TRYV(hipGetLastError());
     base += kManyMax;
@@ -946,10 +943,6 @@ int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value) 
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return nka_detail::set_error(NKA_HIP_EINVAL, "tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
     ws->ticket_groups = value;
-    return 0;
-  }
-  if (std::string(key) == "win") {
-    ws->use_win = value != 0;
     return 0;
   }
   return nka_detail::set_error(NKA_HIP_EINVAL, std::string("unknown tuning key: ") + key);
@@ -1306,7 +1299,7 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
       m.x[j] = ys[j];
       v2 = v2 && al16(m.x[j]);
     }
-    const bool win = v2 && ws->use_win;
+    const bool win = v2;                                                    // 16-byte path = the rolling-window kernel
     const int nv = win ? std::max(m.count, 1) : width_for(m.count);      // window kernel: exact width, no padding
     const int g = grid_for(ws, n, v2 ? 2 : 1, win ? 22 : nv + 3);   // rolling-window kernel: one block per CU
 #define NKA_SDPM(NV, VEC, SUB, PRE)                                                                              \
@@ -1319,25 +1312,17 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #define LWSN(NV) NKA_SDPMW(NV, true, false)
 #define LWNP(NV) NKA_SDPMW(NV, false, true)
 #define LWNN(NV) NKA_SDPMW(NV, false, false)
-#define L2SP(NV) NKA_SDPM(NV, 2, true, true)
-#define L2SN(NV) NKA_SDPM(NV, 2, true, false)
-#define L2NP(NV) NKA_SDPM(NV, 2, false, true)
-#define L2NN(NV) NKA_SDPM(NV, 2, false, false)
 #define L1SP(NV) NKA_SDPM(NV, 1, true, true)
 #define L1SN(NV) NKA_SDPM(NV, 1, true, false)
 #define L1NP(NV) NKA_SDPM(NV, 1, false, true)
 #define L1NN(NV) NKA_SDPM(NV, 1, false, false)
 #define LWDD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many_win<NV, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
-#define L2DD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 2, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
 #define L1DD(NV) hipLaunchKernelGGL((k_scale_dot_pair_many<NV, 1, false, true, true>), dim3(g), dim3(kBlock), 0, ws->stream, n, w, v, a, pre_a, f, m, ws->partials, store)
     if (host_dd) {                       // norm + both rows in one pure-read pass (SUB = false, PRE = true, nothing stored)
-      if (win) { NKA_DISPATCH_EXACT(nv, LWDD) } else if (v2) { NKA_DISPATCH_NV(nv, L2DD) } else { NKA_DISPATCH_NV(nv, L1DD) }
+      if (win) { NKA_DISPATCH_EXACT(nv, LWDD) } else { NKA_DISPATCH_NV(nv, L1DD) }
     } else if (win) {
       if (subtract) { if (pre) { NKA_DISPATCH_EXACT(nv, LWSP) } else { NKA_DISPATCH_EXACT(nv, LWSN) } }
       else          { if (pre) { NKA_DISPATCH_EXACT(nv, LWNP) } else { NKA_DISPATCH_EXACT(nv, LWNN) } }
-    } else if (v2) {
-      if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L2SP) } else { NKA_DISPATCH_NV(nv, L2SN) } }
-      else          { if (pre) { NKA_DISPATCH_NV(nv, L2NP) } else { NKA_DISPATCH_NV(nv, L2NN) } }
     } else {
       if (subtract) { if (pre) { NKA_DISPATCH_NV(nv, L1SP) } else { NKA_DISPATCH_NV(nv, L1SN) } }
       else          { if (pre) { NKA_DISPATCH_NV(nv, L1NP) } else { NKA_DISPATCH_NV(nv, L1NN) } }
@@ -1346,10 +1331,6 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef LWSN
 #undef LWNP
 #undef LWNN
-#undef L2SP
-#undef L2SN
-#undef L2NP
-#undef L2NN
 #undef L1SP
 #undef L1SN
 #undef L1NP
@@ -1357,7 +1338,6 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 #undef NKA_SDPM
 #undef NKA_SDPMW
 #undef LWDD
-#undef L2DD
 #undef L1DD
     HIP_TRYV(hipGetLastError());
     if (int rc = fetch_sums(ws, g, 2, nv, m.count, extra, true)) return rc;
