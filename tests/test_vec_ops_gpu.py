@@ -283,3 +283,95 @@ def test_deferred_normalisation_equals_the_storing_stages(ws, n, count, pre, tic
             ref = ca[j] * xj + ref if compact else (ca[j] * xj + cb[j] * yj) + ref
         assert np.array_equal(res[1][2], ref) and np.array_equal(res[1][3], f) and np.array_equal(res[1][4], ref)
     assert L.nka_hip_vec_set_tuning(h, b"tickets", -1) == 0
+
+
+def test_reduction_hooks_see_every_sum_in_the_canonical_layout(ws):
+    """Parallel-aware reductions (include/nka_hip.h): with hooks installed on the workspace EVERY
+    sum a reduction returns goes through them -- the device-side hook on a device buffer, ordered on the
+    workspace stream, then the host-side hook on host memory -- in a layout that depends only on the list
+    length: [row 0 (count), row 1 (count), cross, <d,d>].  The hooks here play a second rank that holds the
+    same slice (device hook: x2) and a third one holding zeros (host hook: records what it sees), so every
+    result must double, the norm must grow by sqrt(2), and the recorded layouts must be the canonical ones
+    -- for aligned operands (rolling-window kernels, exact widths) AND unaligned ones (8-byte path, widths
+    padded to a multiple of 4: the padding must not reach the hook)."""
+    import nka_amd
+    from nka_amd import _lib
+    L, h, torch = ws
+    n, count = 70001, 5
+    rng = np.random.default_rng(5)
+    seen = []
+
+    def dev_hook(_ctx, buf, cnt, stream):
+        class _Alias:
+            def __init__(self, ptr, c):
+                self.__cuda_array_interface__ = {"shape": (c,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()):
+            t = torch.as_tensor(_Alias(buf, cnt), device="cuda")
+            t.mul_(2.0)
+        return 0
+
+    def host_hook(_ctx, vals, cnt):
+        seen.append([vals[i] for i in range(cnt)])
+        return 0
+
+    dcb, hcb = _lib.ALLREDUCE_FN(dev_hook), _lib.HOST_ALLREDUCE_FN(host_hook)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    try:
+        for shift in (0, 1):                     # shift 1: operands start 8 bytes off a 16-byte boundary
+            base = [torch.from_numpy(rng.standard_normal(n + 1)).cuda() for _ in range(count + 2)]
+            vecs = [b[shift:shift + n] for b in base]
+            w, f, ys = vecs[0], vecs[1], vecs[2:]
+            ptrs = (C.c_void_p * count)(*[y.data_ptr() for y in ys])
+            wn, fn, yn = w.cpu().numpy(), f.cpu().numpy(), [y.cpu().numpy() for y in ys]
+            d = (-1.0) * fn + wn
+
+            def run():
+                out = {}
+                r = C.c_double()
+                assert L.nka_hip_vec_dot(h, n, P(w), P(f), C.byref(r)) == 0
+                out["dot"] = r.value
+                assert L.nka_hip_vec_norm2(h, n, P(w), C.byref(r)) == 0
+                out["norm2"] = r.value
+                vz, vx = (C.c_double * count)(), (C.c_double * count)()
+                dd, cr = C.c_double(), C.c_double()
+                assert L.nka_hip_vec_diff_norm_dot_pair_many(h, n, P(w), -1.0, P(f), ptrs, count, C.byref(dd), vz, vx,
+                                                             C.byref(cr)) == 0
+                out["fused"] = (dd.value, list(vz), list(vx), cr.value)
+                vm = (C.c_double * count)()
+                assert L.nka_hip_vec_dot_many(h, n, P(f), ptrs, count, vm) == 0
+                out["many"] = list(vm)
+                return out
+
+            plain = run()
+            assert plain["dot"] == pytest.approx(float(np.dot(wn, fn)), rel=1e-12, abs=1e-9)
+            assert plain["fused"][0] == pytest.approx(float(np.dot(d, d)), rel=1e-12)
+            for j in range(count):
+                assert plain["fused"][1][j] == pytest.approx(float(np.dot(d, yn[j])), rel=1e-10, abs=1e-9)
+                assert plain["fused"][2][j] == pytest.approx(float(np.dot(fn, yn[j])), rel=1e-10, abs=1e-9)
+            assert plain["fused"][3] == pytest.approx(float(np.dot(fn, d)), rel=1e-10, abs=1e-9)
+            assert L.nka_hip_vec_set_allreduce(h, dcb, None) == 0
+            assert L.nka_hip_vec_set_host_allreduce(h, hcb, None) == 0
+            seen.clear()
+            hooked = run()
+            assert L.nka_hip_vec_set_allreduce(h, C.cast(None, _lib.ALLREDUCE_FN), None) == 0
+            assert L.nka_hip_vec_set_host_allreduce(h, C.cast(None, _lib.HOST_ALLREDUCE_FN), None) == 0
+            assert hooked["dot"] == 2.0 * plain["dot"]                     # powers of two: exact
+            assert hooked["norm2"] == pytest.approx(np.sqrt(2.0) * plain["norm2"], rel=1e-15)   # sqrt of the GLOBAL sum
+            assert hooked["many"] == [2.0 * v for v in plain["many"]]
+            dd, vz, vx, cr = plain["fused"]
+            assert hooked["fused"] == (2.0 * dd, [2.0 * v for v in vz], [2.0 * v for v in vx], 2.0 * cr)
+            # what the host hook saw, call by call: dot (1), norm2's dot (1), the fused stage (2*count + 2), dot_many (count)
+            assert [len(s) for s in seen] == [1, 1, 2 * count + 2, count], (shift, [len(s) for s in seen])
+            assert seen[2] == [2.0 * v for v in vz] + [2.0 * v for v in vx] + [2.0 * cr, 2.0 * dd]
+
+        # a failing hook fails the reduction with NKA_HIP_ECOMM and leaves the workspace usable
+        bad = _lib.HOST_ALLREDUCE_FN(lambda _c, _v, _n: 1)
+        assert L.nka_hip_vec_set_host_allreduce(h, bad, None) == 0
+        r = C.c_double()
+        assert L.nka_hip_vec_dot(h, n, P(w), P(f), C.byref(r)) == -4
+        assert b"all-reduce hook failed" in L.nka_hip_last_error()
+    finally:
+        L.nka_hip_vec_set_allreduce(h, C.cast(None, _lib.ALLREDUCE_FN), None)
+        L.nka_hip_vec_set_host_allreduce(h, C.cast(None, _lib.HOST_ALLREDUCE_FN), None)
+    r = C.c_double()
+    assert L.nka_hip_vec_dot(h, n, P(w), P(f), C.byref(r)) == 0 and r.value == plain["dot"]
