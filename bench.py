@@ -78,7 +78,10 @@ def parse():
     ap.add_argument("--flavor", choices=["default", "c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "default"),
                     help="'default' = what `call a%%init(vlen, mvec)` of the drop-in Fortran module runs (compact storage "
                          "unless NKA_HIP_FLAVOR says otherwise); or name the reference rounding mirrored")
-    ap.add_argument("--allreduce", choices=["rccl", "torch"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
+    ap.add_argument("--allreduce", choices=["rccl", "torch", "staged"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NKA_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend.  gloo (+ --allreduce staged, NKA_BENCH_SHARE_GPU=1) is a REHEARSAL of the "
+                         "multi-rank logic with all ranks on one GPU (RCCL refuses that); its numbers mean nothing")
     return ap.parse_args()
 
 
@@ -295,12 +298,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    share_gpu = os.environ.get("NKA_BENCH_SHARE_GPU") == "1"      # rehearsal: every rank on cuda:0
+    if share_gpu:
+        local_rank = 0
+    if args.backend == "gloo" and args.allreduce != "staged":
+        raise SystemExit("--backend gloo needs --allreduce staged (a rehearsal of the multi-rank logic, not a measurement)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
 
     n_global, m = int(args.n), args.mvec
     lo, hi = nd.slice_bounds(n_global, world, rank)
@@ -395,7 +406,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         nrec = min(-(-K // ev_stride), 4096)
@@ -461,7 +472,9 @@ def main():
                        "flavor_note": "the flavour `call a%init(vlen, mvec)` (Fortran), nka_init (F95) and nka().init "
                                       "(Python) run when the caller names none (include/nka_hip.h: NKA_HIP_FLAVOR_DEFAULT)"
                                       if is_default else "NOT the front ends' default: selected on the command line",
-                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}",
+                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}"
+                                      + ("; REHEARSAL: ranks share one GPU, all-reduce staged through the host over gloo -- "
+                                         "the numbers of this line mean nothing" if (share_gpu or args.backend == "gloo") else ""),
                        "steady_state": bool(steady and nv_end == m), "prime_steps": prime,
                        "phase_events": f"HIP events recorded on every {ev_stride}{'st' if ev_stride == 1 else 'th'} timed update",
                        "inputs_resident": not refill_in_timed_region},

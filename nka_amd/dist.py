@@ -137,6 +137,10 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
         attach_torch_allreduce(acc, group)
         if not all_agree(check_allreduce(acc, rank, world_size), group, acc._device):
             raise RuntimeError("the torch.distributed all-reduce hook failed its self-test")
+    if hook == "staged":                        # rehearsal only (attach_staged_allreduce)
+        attach_staged_allreduce(acc, group)
+        if not all_agree(check_allreduce(acc, rank, world_size), group, acc._device):
+            raise RuntimeError("the host-staged all-reduce hook failed its self-test")
     return hook
 
 
@@ -161,6 +165,32 @@ def attach_torch_allreduce(acc, group=None):
         with ctx:
             t = torch.as_tensor(_Alias(ptr, count), device=f"cuda:{acc._device}")
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    acc.set_dot_prod(hook)
+    return acc
+
+
+def attach_staged_allreduce(acc, group=None):
+    """REHEARSAL hook: the all-reduce staged through the host over any torch.distributed
+    backend (gloo): device -> host, all_reduce, host -> device, synchronous.  Slow (two PCIe hops
+    and a host collective per update) -- it exists so that the multi-rank logic around the
+    library (slicing, collective decisions, replica checks, bench.py --gpus N) can be executed
+    with several ranks SHARING one GPU, which RCCL refuses."""
+    import torch
+    import torch.distributed as dist
+
+    class _Alias:
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def hook(ptr, count, stream):
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=acc._device)) if stream else \
+            torch.cuda.stream(torch.cuda.default_stream(acc._device))
+        with ctx:
+            dev = torch.as_tensor(_Alias(ptr, count), device=f"cuda:{acc._device}")
+            host = dev.cpu()                       # synchronises the stream
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            dev.copy_(host)
 
     acc.set_dot_prod(hook)
     return acc

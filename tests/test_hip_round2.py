@@ -251,6 +251,34 @@ def test_bench_two_gpus(torch_cuda):
     assert 0.0 < d["roofline"]["frac"] <= 1.0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_logic_rehearsed_with_ranks_sharing_the_gpu(torch_cuda, world):
+    """bench.py --gpus N launched the way the driver launches it, with N ranks on the ONE GPU of the box
+    (NKA_BENCH_SHARE_GPU=1, torch.distributed over gloo, the all-reduce staged through the host: RCCL refuses two
+    ranks on a device).  Everything around the library that only runs with more than one rank -- slicing, the
+    collective choice of the hook and its self-test, max-over-ranks timing, replica digests after warm-up and after
+    the timed steps, the per-rank record gathered on rank 0 -- is executed for real; the numbers mean nothing."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", NKA_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--vlen",
+           "3000001", "--mvec", "6", "--steps", "6", "--backend", "gloo", "--allreduce", "staged", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["config"]["steady_state"] and d["scaling"] == "strong"
+    assert "REHEARSAL" in d["config"]["parallelism"]
+    assert len(d["replica_check"]) == 2 and all(c["identical"] and c["ranks"] == world for c in d["replica_check"])
+    ranks = d["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(world))
+    assert len({r["state_digest"] for r in ranks}) == 1                    # the replicated state: the same bits on every rank
+    assert all(r["hook"] == "staged" for r in ranks)
+    # the slices tile the global vector
+    assert ranks[0]["slice"][0] == 0 and ranks[-1]["slice"][1] == 3000001
+    assert all(a["slice"][1] == b["slice"][0] for a, b in zip(ranks[:-1], ranks[1:]))
+    assert sum(r["n_local"] for r in ranks) == 3000001
+
+
 @pytest.mark.parametrize("flavor", [0, 1, 2])
 @pytest.mark.parametrize("n,m", [(40961, 8), (100003, 20), (5003, 5)])
 def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
