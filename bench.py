@@ -26,6 +26,10 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  `contract_bytes_ratio` / `contract_GBps`, never as a fraction.
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
                  oracle port timed on this box's host on a bounded sample.
+                 `traffic`: HBM bytes of that launch by the PMC counters, measured IN THIS RUN
+                 (two rocprofv3 passes, FETCH_SIZE and WRITE_SIZE, over a short child process of
+                 this script after the timed region; `traffic_source` says so, or names the
+                 committed summary under profiles/ that was used instead).
                  `device_time_stats_ms`: mean / median / min / max of the per-update
                  device times; `probe_ceiling`: the repo's own streaming
                  probe (tools/hbm_probe: pure read, pure write, PB's read/write mixes)
@@ -223,7 +227,54 @@ def pmc_traffic(flavor: str, n_local: int, m: int):
     return None, None
 
 
-def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None):
+def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170):
+    """HBM bytes per launch measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE: separate
+    passes with --kernel-trace only, units and the gfx950 FETCH_SIZE x 2 correction as MI355X_MICROARCH.md prescribes,
+    tools/pmc_summary.py) over a short CHILD process of this very script -- same box, same build, same workload, a few
+    steady-state updates -- after the timed region.  Returns the dict of tools/pmc_summary.py or None (no rocprofv3,
+    a failed pass, a timeout: the committed summary under profiles/ is then used and labelled as such)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or os.environ.get("NKA_BENCH_PMC", "1") == "0":
+        return None
+    try:
+        spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+        ps = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ps)
+        out = tempfile.mkdtemp(prefix="nka_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", NKA_BENCH_SECONDARY="0", NKA_BENCH_PMC="0")
+        for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, sub), "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--flavor", flavor, "--steps", "4",
+                   "--vlen", str(n_local), "--mvec", str(m)]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            if p.returncode != 0:
+                return None
+        fetch = ps.load_counter(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
+        write = ps.load_counter(os.path.join(out, "pmc_write"), "WRITE_SIZE")
+        res = {"n": n_local, "mvec": m, "kernels": {}}
+        total = 0.0
+        for stem in ("k_dots", "k_combine"):
+            kf, kw = ps.widest(fetch, stem), ps.widest(write, stem)
+            if not kf or not kw:
+                return None
+            fv = sorted(fetch[kf])[-max(1, len(fetch[kf]) // 2):]      # steady state: the launches with the most traffic
+            wv = sorted(write[kw])[-max(1, len(write[kw]) // 2):]
+            rb, wb = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
+            res["kernels"][stem] = {"kernel": kf, "read_bytes": rb, "write_bytes": wb, "launches_averaged": len(fv),
+                                    "words_per_element": (rb + wb) / 8.0 / max(n_local, 1)}
+            total += rb + wb
+        res["hbm_bytes_per_update"] = total
+        shutil.rmtree(out, ignore_errors=True)
+        return res
+    except Exception:      # an extra, never the measured path
+        return None
+
+
+def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None):
     """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
     PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
     PMC counters) / mean launch duration (HIP events on the kernel stream during
@@ -236,7 +287,11 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
     L = k = m
     words = words_moved(flavor, L, k)
     ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}
-    pm, pm_src = pmc_traffic(flavor, n_local, m)
+    if pm_live:
+        pm, pm_src = pm_live, ("same run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child process of "
+                               "this script after the timed region; FETCH_SIZE x 2 on gfx950")
+    else:
+        pm, pm_src = pmc_traffic(flavor, n_local, m)
     pmk = {"PA_k_dots": "k_dots", "PB_k_combine": "k_combine"}
     kernels = {}
     for name, w in words.items():
@@ -502,9 +557,13 @@ def main():
             acc.delete()
             torch.cuda.empty_cache()
             pool = pool_store = None
-            rl["probe_ceiling"] = probe_ceilings(min(n_local, 10**8))
+            probe = probe_ceilings(min(n_local, 10**8))
+            # HBM traffic of the dominant kernels by the PMC counters, measured in this run (child process under rocprofv3)
+            pm_live = pmc_same_run(flavor, n_local, m) if (n_global, m) == (10**8, 20) else None
+            rl = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live)
+            out["roofline"] = rl
             if also is not None:
-                also["roofline"]["probe_ceiling"] = rl["probe_ceiling"]
+                also["roofline"]["probe_ceiling"] = probe
             if not args.no_config5 and (n_global, m) == (10**8, 20):
                 out["config5_abstract_vector"] = config5_abstract_vector()
         print(json.dumps(out), flush=True)
