@@ -15,7 +15,7 @@ module host_slice_vector_type
   private
 
   type, extends(vector), public :: host_slice_vector
-    real(r8), allocatable :: x(:)
+    real(r8), pointer :: x(:) => null()       ! this rank's slice (pointer: views handed to slice_of)
     type(c_ptr) :: comm = c_null_ptr           ! shm_ar context shared by all vectors of the rank
   contains
     procedure :: clone1
@@ -86,13 +86,25 @@ contains
     end select
   end subroutine
 
+  !! the slice behind a class(vector) argument of this type (the NVI wrappers of vector_class have
+  !! already checked same_type_as)
+  function slice_of(v) result(p)
+    class(vector), intent(in), target :: v
+    real(r8), pointer :: p(:)
+    p => null()
+    select type (v)
+    class is (host_slice_vector)
+      p => v%x
+    end select
+    if (.not. associated(p)) error stop 'host_slice_vector: foreign vector type'
+  end function
+
   subroutine copy_(dest, src)
     class(host_slice_vector), intent(inout) :: dest
     class(vector), intent(in) :: src
-    select type (src)
-    class is (host_slice_vector)
-      dest%x = src%x
-    end select
+    real(r8), pointer :: s(:)
+    s => slice_of(src)
+    dest%x = s
   end subroutine
 
   subroutine setval(this, val)
@@ -104,64 +116,72 @@ contains
   subroutine scale(this, a)
     class(host_slice_vector), intent(inout) :: this
     real(r8), intent(in) :: a
-    this%x = a * this%x
+    integer :: i
+    do i = 1, size(this%x)
+      this%x(i) = a * this%x(i)
+    end do
   end subroutine
 
+  !! the four update forms of vector_class, element by element, each with the association of the
+  !! reference's expression (a*x + this ; a*x + b*this ; a*x + b*y + this ; a*x + b*y + c*this)
   subroutine update1_(this, a, x)
     class(host_slice_vector), intent(inout) :: this
     real(r8), intent(in) :: a
     class(vector), intent(in) :: x
-    select type (x)
-    class is (host_slice_vector)
-      this%x = a * x%x + this%x
-    end select
+    real(r8), pointer :: xs(:)
+    integer :: i
+    xs => slice_of(x)
+    do i = 1, size(this%x)
+      this%x(i) = a * xs(i) + this%x(i)
+    end do
   end subroutine
 
   subroutine update2_(this, a, x, b)
     class(host_slice_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b
     class(vector), intent(in) :: x
-    select type (x)
-    class is (host_slice_vector)
-      this%x = a * x%x + b * this%x
-    end select
+    real(r8), pointer :: xs(:)
+    integer :: i
+    xs => slice_of(x)
+    do i = 1, size(this%x)
+      this%x(i) = a * xs(i) + b * this%x(i)
+    end do
   end subroutine
 
   subroutine update3_(this, a, x, b, y)
     class(host_slice_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b
     class(vector), intent(in) :: x, y
-    select type (x)
-    class is (host_slice_vector)
-      select type (y)
-      class is (host_slice_vector)
-        this%x = a * x%x + b * y%x + this%x
-      end select
-    end select
+    real(r8), pointer :: xs(:), ys(:)
+    integer :: i
+    xs => slice_of(x)
+    ys => slice_of(y)
+    do i = 1, size(this%x)
+      this%x(i) = a * xs(i) + b * ys(i) + this%x(i)
+    end do
   end subroutine
 
   subroutine update4_(this, a, x, b, y, c)
     class(host_slice_vector), intent(inout) :: this
     real(r8), intent(in) :: a, b, c
     class(vector), intent(in) :: x, y
-    select type (x)
-    class is (host_slice_vector)
-      select type (y)
-      class is (host_slice_vector)
-        this%x = a * x%x + b * y%x + c * this%x
-      end select
-    end select
+    real(r8), pointer :: xs(:), ys(:)
+    integer :: i
+    xs => slice_of(x)
+    ys => slice_of(y)
+    do i = 1, size(this%x)
+      this%x(i) = a * xs(i) + b * ys(i) + c * this%x(i)
+    end do
   end subroutine
 
+  !! parallel-aware: the local partial sum, then the sum over the ranks
   function dot_(x, y) result(val)
     class(host_slice_vector), intent(in) :: x
     class(vector), intent(in) :: y
     real(r8) :: val
-    val = 0.0_r8
-    select type (y)
-    class is (host_slice_vector)
-      val = global_sum(x, dot_product(x%x, y%x))
-    end select
+    real(r8), pointer :: ys(:)
+    ys => slice_of(y)
+    val = global_sum(x, dot_product(x%x, ys))
   end function
 
   function norm2_(this) result(val)
