@@ -13,6 +13,13 @@
  * evaluated by dp on host copies of the operands in the reference's own order
  * (slow compatibility path, see include/nka_hip.h).  Failed preconditions abort
  * like the reference's assert() (.c:216-218).
+ *
+ * Two ways to use it: include this header (everything static inline), or keep the
+ * reference's own nonlinear_krylov_accelerator.h and link libnka_c_compat.so
+ * (nka_amd/csrc/nka_c_compat_lib.c: this header compiled with external linkage,
+ * exporting exactly the nine reference symbols) -- then not even the include line
+ * of a caller changes (oracle/Makefile: dropin_example_c builds the reference's
+ * unchanged src-C/nka_example.c that way).
  */
 #ifndef NKA_C_COMPAT_H
 #define NKA_C_COMPAT_H
@@ -23,6 +30,10 @@
 #include "nka_hip.h"
 
 typedef nka_hip_t NKA;
+
+#ifndef NKA_C_COMPAT_API
+#define NKA_C_COMPAT_API static inline
+#endif
 
 static inline void nka_compat_check_(int rc, const char *what) {
   if (rc != 0) {
@@ -40,7 +51,7 @@ static inline double nka_compat_dp_trampoline_(void *ctx, int64_t n, const doubl
   return u.f((int)n, (double *)x, (double *)y);
 }
 
-static inline NKA nka_init(int vlen, int mvec, double vtol, double (*dp)(int, double *, double *)) {
+NKA_C_COMPAT_API NKA nka_init(int vlen, int mvec, double vtol, double (*dp)(int, double *, double *)) {
   NKA a = 0;
   nka_compat_check_(nka_hip_create(&a, vlen, mvec, vtol, NKA_HIP_FLAVOR_C, 0, 0), "nka_init");
   if (dp != 0) {                                   /* .c:227-231 */
@@ -50,14 +61,14 @@ static inline NKA nka_init(int vlen, int mvec, double vtol, double (*dp)(int, do
   }
   return a;
 }
-static inline void nka_delete(NKA a) { nka_hip_destroy(a); }
-static inline void nka_accel_update(NKA a, double *f) { nka_compat_check_(nka_hip_accel_update_host(a, f), "nka_accel_update"); }
-static inline void nka_accel_update_dev(NKA a, double *f_dev) { nka_compat_check_(nka_hip_accel_update(a, f_dev), "nka_accel_update_dev"); }
-static inline void nka_restart(NKA a) { nka_compat_check_(nka_hip_restart(a), "nka_restart"); }
-static inline void nka_relax(NKA a) { nka_compat_check_(nka_hip_relax(a), "nka_relax"); }
-static inline int nka_num_vec(NKA a) { return nka_hip_num_vec(a); }
-static inline int nka_max_vec(NKA a) { return nka_hip_max_vec(a); }
-static inline int nka_vec_len(NKA a) { return (int)nka_hip_vec_len(a); }
-static inline double nka_vec_tol(NKA a) { return nka_hip_vec_tol(a); }
+NKA_C_COMPAT_API void nka_delete(NKA a) { nka_hip_destroy(a); }
+NKA_C_COMPAT_API void nka_accel_update(NKA a, double *f) { nka_compat_check_(nka_hip_accel_update_host(a, f), "nka_accel_update"); }
+NKA_C_COMPAT_API void nka_accel_update_dev(NKA a, double *f_dev) { nka_compat_check_(nka_hip_accel_update(a, f_dev), "nka_accel_update_dev"); }
+NKA_C_COMPAT_API void nka_restart(NKA a) { nka_compat_check_(nka_hip_restart(a), "nka_restart"); }
+NKA_C_COMPAT_API void nka_relax(NKA a) { nka_compat_check_(nka_hip_relax(a), "nka_relax"); }
+NKA_C_COMPAT_API int nka_num_vec(NKA a) { return nka_hip_num_vec(a); }
+NKA_C_COMPAT_API int nka_max_vec(NKA a) { return nka_hip_max_vec(a); }
+NKA_C_COMPAT_API int nka_vec_len(NKA a) { return (int)nka_hip_vec_len(a); }
+NKA_C_COMPAT_API double nka_vec_tol(NKA a) { return nka_hip_vec_tol(a); }
 
 #endif

@@ -325,3 +325,18 @@ def test_assignment_is_a_deep_copy_like_the_reference_type(fortran_build, oracle
     assert got_rows == rows
     dev = np.fromfile(raw, dtype=np.float64).reshape(len(want), n)
     assert np.array_equal(dev, np.array(want)), np.abs(dev - np.array(want)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin_example_c")), reason="drop-in build absent")
+def test_reference_c_caller_links_unchanged_against_the_c_drop_in_library(tmp_path):
+    """Reference src-C/nka_example.c -- its `#include "nonlinear_krylov_accelerator.h"` and the reference's own
+    header untouched -- linked with libnka_c_compat.so (the nine reference symbols over libnka_hip.so) in place of
+    nonlinear_krylov_accelerator.c: every nka_accel_update runs on the MI355X and the program prints the
+    reference's 403-line reference_output (the accelerated AND the unaccelerated solve) line for line."""
+    p = subprocess.run([os.path.join(REFDIR, "dropin_example_c")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr
+    want = open(os.path.join(S.GOLD, "reference_output_C.txt")).read().splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(want) == 403
+    assert got == want

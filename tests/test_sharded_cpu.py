@@ -61,6 +61,20 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
 
 
+def test_c_drop_in_library_exports_the_nine_reference_symbols():
+    """libnka_c_compat.so: exactly the functions of src-C/nonlinear_krylov_accelerator.h:3-12 (plus the device-
+    pointer variant), loadable without a GPU."""
+    import ctypes
+    import nka_amd
+    nka_amd.load()
+    path = os.path.join(os.path.dirname(nka_amd.lib_path()), "libnka_c_compat.so")
+    assert os.path.exists(path), "build it with __graft_entry__.build()"
+    L = ctypes.CDLL(path)
+    for name in ("nka_init", "nka_delete", "nka_accel_update", "nka_restart", "nka_relax", "nka_num_vec", "nka_max_vec",
+                 "nka_vec_len", "nka_vec_tol", "nka_accel_update_dev"):
+        assert hasattr(L, name), name
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     import nka_amd
