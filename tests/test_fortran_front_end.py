@@ -340,3 +340,17 @@ def test_reference_c_caller_links_unchanged_against_the_c_drop_in_library(tmp_pa
     got = p.stdout.splitlines()
     assert len(got) == len(want) == 403
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin_example_f95")), reason="drop-in build absent")
+def test_reference_f95_caller_against_our_f95_module_on_gpu(tmp_path):
+    """Reference src-F95/nka_example.F90, unchanged, with OUR procedural module nka_type (nka_init,
+    nka_accel_update, nka_delete over libnka_hip.so) in place of the reference's: the program prints
+    src-F95/reference_output (byte-identical to src-C/reference_output: SURVEY.md 4), 403 lines."""
+    p = subprocess.run([os.path.join(REFDIR, "dropin_example_f95")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr
+    want = open(os.path.join(S.GOLD, "reference_output_C.txt")).read().splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(want) == 403
+    assert got == want
