@@ -348,7 +348,8 @@ int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const 
  *                           w <- a*(pre_a*z_in + w) [pre], v <- a*v [, subtract: v <- (-1)*w + v]
  *   axpy_many_keep_pend:    axpy_many_keep for compact storage: xs[0] = v, pend_w = w, subtract implied
  * Same expressions as scale_dot_pair_many, hence the same bits; the new pair is read raw once more by
- * the combine instead of being written and re-read normalised: 8n(10+3m) bytes, the scale-and-dot
+ * the combine instead of being written and re-read normalised: 8n(10+3m) bytes (8n(8+3m) with the fused
+ * norm stage nka_hip_vec_diff_norm_dot_pair_many), the scale-and-dot
  * stage without a store stream. */
 int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre,
                                      double pre_a, const double *f, const double *const *ys, int32_t count,
