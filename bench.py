@@ -44,6 +44,8 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  stored vectors per pair).  Both are checked against the compiled
                  src-F08 reference in tests/ (decisions exact, values within the stated
                  tolerance).
+  config2_n1e7_m10 (N = 1, headline run only): BASELINE configs[1] (n = 1e7, m = 10) measured in the same
+                 run on the first 1e7 elements of the resident inputs (updates/s, whole-update fraction).
   config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
                  src-F08-vector abstract path through the Fortran vector flavour on
                  the device block vector, measured by nka_vector_driver in a child
@@ -497,6 +499,47 @@ def main():
         else:
             rank_info = [mine]
 
+    def config2_line(steps=50):
+        """BASELINE configs[1] (n = 1e7, m = 10, one GPU: "single-GPU plumbing") in the same run, on the first 1e7
+        elements of the resident inputs: default flavour, warm-up m+4, `steps` timed updates by wall clock with the
+        per-phase events on every 4th (fixed costs are 8 % of an update here; four event records would widen it)."""
+        n2, m2 = 10**7, 10
+        if n_local < n2 or P < m2 + 4 + 8:
+            return None
+        a2 = nka_amd.nka().init(n2, m2, flavor=FLAVORS[args.flavor])
+        try:
+            views = [pool[j][:n2] for j in range(P)]
+            for j in range(P):
+                synth.fill_torch(views[j], SEED, 1000 + j, 0, n2)
+            t = 0
+            for _ in range(m2 + 4):
+                a2.accel_update(views[t % P]); t += 1
+            torch.cuda.synchronize(dev)
+            if a2.num_vec() != m2:
+                return {"error": "subspace not full"}
+            a2.set_tuning("timing_stride", 4)
+            a2.set_timing(-(-steps // 4))
+            # (inputs are re-used round robin: an accelerated f is as good an input as a fresh one for the traffic)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                a2.accel_update(views[t % P]); t += 1
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+            nrec = -(-steps // 4)
+            ph = [a2.timing_ms(b) for b in range(nrec)]
+            mean2 = [sum(p[i] for p in ph) / nrec for i in range(4)]
+            fl2 = FLAVOR_NAMES[a2.flavor()]
+            w2 = words_moved(fl2, m2, m2)
+            moved = 8.0 * n2 * sum(w2.values())
+            return {"workload": "BASELINE configs[1]: n=1e7, mvec=10, fp64, 1 GPU, subspace full", "flavor": FLAVOR_TEXT[fl2],
+                    "value": 1.0 / dt, "unit": "updates/s", "us_per_update": 1e6 * dt, "steps": steps,
+                    "steady_state": bool(a2.num_vec() == m2),
+                    "whole_update": {"bytes_moved": moved, "achieved": moved / dt / 1e9, "frac": moved / dt / 1e9 / HBM_PEAK_GBPS,
+                                     "what": "bytes moved / wall time per update / 8 TB/s"},
+                    "phase_us": {"PA_k_dots": 1e3 * mean2[0], "k_solve": 1e3 * mean2[1], "PB_k_combine": 1e3 * mean2[2]}}
+        finally:
+            a2.delete()
+
     # Secondary figure in the same run: the src-F08 rounding (two stored vectors
     # per pair, bit-faithful to F08:397), same workload, same protocol.
     also = None
@@ -545,6 +588,13 @@ def main():
             out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:
             out["also_f08_rounding"] = also
+        if world == 1 and (n_global, m) == (10**8, 20) and not args.no_cpu_baseline:
+            try:
+                c2 = config2_line()
+                if c2:
+                    out["config2_n1e7_m10"] = c2
+            except Exception as exc:       # an extra, never the measured path
+                out["config2_n1e7_m10"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(m, int(args.cpu_n))
