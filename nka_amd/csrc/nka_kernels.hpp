@@ -181,35 +181,6 @@ __device__ __forceinline__ double ex(d2 x, int i) { return x[i]; }
 __device__ __forceinline__ void setc(double &x, int, double val) { x = val; }
 __device__ __forceinline__ void setc(d2 &x, int i, double val) { x[i] = val; }
 
-// ---- fixed-order final sum of per-block partials (vector hooks: dot, norm2) -------
-// out[c] = sum_b partials[c*G + b] for c < ncols ; 0 for ncols <= c < ncols_out.
-// One BLOCK per column (launch ncols_out blocks): thread t sums b = t, t+256, ...
-// sequentially (G <= 4096: at most 16 independent loads a thread), then a butterfly per
-// wave and the four wave sums in order -- the order never depends on timing.
-// `out` may be device-mapped pinned host memory: the host then reads the sums
-// right after synchronising the stream, with no copy in between.
-static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_finalize(
-    const double *__restrict__ partials, int G, int ncols, int ncols_out, double *__restrict__ out) {
-  __shared__ double sm[kWavesPerBlock];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = blockIdx.x; c < ncols_out; c += gridDim.x) {
-    double r = 0.0;
-    if (c < ncols) {
-      for (int b = threadIdx.x; b < G; b += kBlock) r += partials[(size_t)c * G + b];
-      r = wave_sum(r);
-    }
-    if (lane == 0) sm[wv] = r;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = sm[0];
-#pragma unroll
-      for (int q = 1; q < kWavesPerBlock; q++) t += sm[q];
-      out[c] = t;
-    }
-    __syncthreads();
-  }
-}
-
 // ---- PA: every inner product of the update in one pure-read pass --------------------
 // MAXL stored vectors per pass; entries beyond the actual count re-read f (cache
 // hit) into accumulators that are discarded, which keeps every load of a tile

@@ -813,7 +813,8 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
 // ---- final sums of a reduction -> host, summed over the ranks when hooks are installed ------
 // The reduction kernel just enqueued left per-block partials of `rows` rows of `nv` columns (plus
 // one `cross` column); the first `count` columns of each row are wanted.  One block per column sums
-// its partials in the fixed order of k_finalize (same bits) and writes the CANONICAL layout
+// its partials in a fixed order (thread t adds the blocks t, t+256, ... in that order, then the butterfly of its wave,
+// then the four wave sums in order: never depends on timing) and writes the CANONICAL layout
 //   out[r*count + j] = row r, column j   ;   out[rows*count + e] = extra scalar column e (cross, <w',w'>)
 // which depends only on (rows, count) -- never on the padded width nv of the kernel variant a rank
 // happened to take (alignment of its pointers) --, so the ranks of a sharded run always reduce
