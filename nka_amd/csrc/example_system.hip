@@ -199,6 +199,7 @@ int nka_ex_create(nka_ex_t *out, int32_t nx, int32_t ny, double a, int32_t devic
   if (e == hipSuccess) e = hipMalloc((void **)&s->ac, sizeof(double) * (size_t)nx * ny);
   if (e == hipSuccess) e = hipMalloc((void **)&s->z, sizeof(double) * (size_t)(nx + 2) * (ny + 2));
   if (e != hipSuccess) {
+    (void)hipGetLastError();   // reported here: not left for a later hipGetLastError() to find
     nka_ex_destroy(s);
     return nka_detail::set_error(NKA_HIP_ENOMEM, std::string("nka_ex_create: ") + hipGetErrorString(e));
   }

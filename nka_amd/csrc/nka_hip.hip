@@ -41,9 +41,11 @@ int fail(int code, const std::string &msg) {
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
+    if (e_ != hipSuccess) {                                                                 \
+      (void)hipGetLastError(); /* reported here: do not leave it for a later hipGetLastError() to find */ \
       return fail(e_ == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,                \
                   std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    }                                                                                       \
   } while (0)
 
 }  // namespace
@@ -506,8 +508,10 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   auto alloc = [&](void **p, size_t bytes) {
     if (rc) return;
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+      (void)hipGetLastError();   // reported here: the runtime's sticky last error must not fail the NEXT, unrelated call
       rc = fail(NKA_HIP_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    }
   };
   alloc((void **)&a->vs.v, slot_bytes);
   alloc((void **)&a->vs.w, slot_bytes);

@@ -58,9 +58,11 @@ namespace {
 #define HIP_TRYV(expr)                                                                   \
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
-    if (e_ != hipSuccess)                                                                \
+    if (e_ != hipSuccess) {                                                              \
+      (void)hipGetLastError(); /* reported here: not left for a later hipGetLastError() */ \
       return nka_detail::set_error(e_ == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP, \
                                    std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    }                                                                                    \
   } while (0)
 
 // OP: 0 setval  z = a
@@ -916,6 +918,7 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
   if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ws->host_results_dev, ws->host_results, 0);
   if (e == hipSuccess) e = hipMalloc((void **)&ws->red_dev, sizeof(double) * (2 * kManyMax + 2));
   if (e != hipSuccess) {   // free whatever was obtained (hipFree / hipHostFree accept NULL)
+    (void)hipGetLastError();   // reported here: the sticky last error must not fail the next, unrelated call
     nka_hip_vec_workspace_destroy(ws);
     return nka_detail::set_error(e == hipErrorOutOfMemory ? NKA_HIP_ENOMEM : NKA_HIP_EHIP,
                                  std::string("vec_workspace_create: ") + hipGetErrorString(e));

@@ -327,6 +327,34 @@ def test_api_surface_defaults_and_errors(torch_cuda):
     assert big.num_vec() == 0 and big.defined()
     a.init(10, 3)                                     # re-init resets vtol (intent(out), F08:186)
     assert a.vec_tol() == 0.01
+    # an allocation the device cannot satisfy (3 slots x 2 arrays x 160 GB) fails cleanly with NKA_HIP_ENOMEM:
+    # nothing is left allocated, the library stays usable
+    free0 = torch_cuda.cuda.mem_get_info()[0]
+    h = C.c_void_p()
+    assert L.nka_hip_create(C.byref(h), 20_000_000_000, 2, 0.01, nka_amd.FLAVOR_DEFAULT, 0, None) == -3
+    assert not h.value and b"hipMalloc" in L.nka_hip_last_error()
+    assert torch_cuda.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    assert nka_amd.nka().init(10, 3).defined()
+    # the flavour every front end runs by default, and its override
+    assert nka_amd.nka().init(10, 3).flavor() == nka_amd.nka.default_flavor()
+    assert nka_amd.nka().init(10, 3, flavor=nka_amd.FLAVOR_F08).flavor() == nka_amd.FLAVOR_F08
+    assert L.nka_hip_create(C.byref(h), 10, 3, 0.01, 7, 0, None) == -1                   # unknown flavour
+
+
+def test_flavor_environment_variable(torch_cuda):
+    """NKA_HIP_FLAVOR decides what NKA_HIP_FLAVOR_DEFAULT resolves to (include/nka_hip.h); a value that is not a
+    flavour is refused with a message instead of silently running something else."""
+    import subprocess
+    import sys
+    root = os.path.dirname(S.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    code = ("import nka_amd, torch; torch.cuda.set_device(0); a = nka_amd.nka().init(16, 2); print('FLAVOR', a.flavor())")
+    for val, want in (("f08", "FLAVOR 0"), ("f08vec", "FLAVOR 1"), ("c", "FLAVOR 2"), ("", "FLAVOR 2")):
+        env = dict(os.environ, NKA_HIP_FLAVOR=val, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and want in p.stdout, (val, p.stdout[-300:], p.stderr[-600:])
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NKA_HIP_FLAVOR="fortran", PYTHONPATH=root),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "NKA_HIP_FLAVOR" in p.stderr
 
 
 def test_runs_are_bitwise_reproducible(torch_cuda):
