@@ -1,0 +1,122 @@
+"""Edge cases of the C ABI beyond the scenario fixtures (round 3): a copy of an accelerator whose scalar state
+lives in global memory (mvec > 140), a stream change in mid-sequence, the host-array entry at n = 0 / 1 / 3, the
+wrap of the timing ring, storms of relax / restart -- each against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _track(torch, acc, ora, x, tag, tol=1e-9):
+    f = x.copy()
+    ora.accel_update(f)
+    ft = torch.from_numpy(x.copy()).cuda()
+    acc.accel_update(ft)
+    assert acc.num_vec() == ora.num_vec(), (tag, acc.num_vec(), ora.num_vec())
+    assert acc.state().list_order() == ora.state().list_order(), tag
+    err = np.linalg.norm(ft.cpu().numpy() - f) / max(np.linalg.norm(x), 1e-300)
+    assert err < tol, (tag, err)
+
+
+def test_copy_of_an_accelerator_with_its_state_in_global_memory(torch_cuda, oracle):
+    import nka_amd
+    rng = np.random.default_rng(0)
+    n, m = 300, 141
+    a = nka_amd.nka().init(n, m)
+    oa, ob = oracle.OracleNKA(n, m, a.flavor()), oracle.OracleNKA(n, m, a.flavor())
+    for t in range(12):
+        x = rng.standard_normal(n)
+        _track(torch_cuda, a, oa, x, ("fill", t))
+        ob.accel_update(x.copy())
+    b = a.copy()
+    assert b.state_digest() == a.state_digest()
+    for t in range(6):
+        _track(torch_cuda, a, oa, rng.standard_normal(n), ("a", t))
+        _track(torch_cuda, b, ob, rng.standard_normal(n), ("b", t))
+    assert a.defined() and b.defined()
+
+
+def test_stream_change_in_mid_sequence(torch_cuda, oracle):
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(1)
+    n, m = 40001, 6
+    a = nka_amd.nka().init(n, m)
+    oa = oracle.OracleNKA(n, m, a.flavor())
+    side = torch.cuda.Stream()
+    for t in range(20):
+        x = rng.standard_normal(n)
+        if t == 7:
+            a.set_stream(side.cuda_stream)
+            a._follow_torch_stream = False
+        if t == 13:
+            a.set_stream(torch.cuda.current_stream().cuda_stream)
+        if 7 <= t < 13:
+            f = x.copy()
+            oa.accel_update(f)
+            with torch.cuda.stream(side):
+                ft = torch.from_numpy(x.copy()).cuda()
+                a.accel_update(ft)
+                side.synchronize()
+            assert a.num_vec() == oa.num_vec()
+            assert np.linalg.norm(ft.cpu().numpy() - f) / np.linalg.norm(x) < 1e-11
+        else:
+            torch.cuda.synchronize()
+            _track(torch, a, oa, x, ("s", t), tol=1e-11)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3])
+def test_host_array_entry_at_tiny_lengths(torch_cuda, oracle, n):
+    import nka_amd
+    rng = np.random.default_rng(2)
+    a = nka_amd.nka().init(n, 3)
+    oa = oracle.OracleNKA(n, 3, a.flavor())
+    for t in range(7):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        oa.accel_update(f)
+        g = x.copy()
+        a.accel_update(g)                      # numpy array: nka_hip_accel_update_host (the reference's own signature)
+        assert a.num_vec() == oa.num_vec(), (n, t)
+        if n:
+            assert np.linalg.norm(g - f) <= 1e-9 * max(np.linalg.norm(f), np.linalg.norm(x)), (n, t, g, f)
+
+
+def test_timing_ring_wraps(torch_cuda):
+    import nka_amd
+    rng = np.random.default_rng(3)
+    a = nka_amd.nka().init(5000, 4)
+    a.set_timing(3)
+    for _ in range(11):
+        a.accel_update(torch_cuda.from_numpy(rng.standard_normal(5000)).cuda())
+    for back in range(3):
+        ms = a.timing_ms(back)
+        assert all(v >= 0 for v in ms) and ms[3] > 0
+    with pytest.raises(nka_amd.NKAError):
+        a.timing_ms(3)
+
+
+def test_relax_and_restart_storm(torch_cuda, oracle):
+    import nka_amd
+    rng = np.random.default_rng(4)
+    a = nka_amd.nka().init(777, 5)
+    oa = oracle.OracleNKA(777, 5, a.flavor())
+    for t in range(80):
+        r = rng.random()
+        if r < 0.2:
+            a.relax(); oa.relax()
+        elif r < 0.3:
+            a.restart(); oa.restart()
+        elif r < 0.35:
+            a.relax(); a.relax(); oa.relax(); oa.relax()
+        else:
+            _track(torch_cuda, a, oa, rng.standard_normal(777), ("storm", t))
+        assert a.num_vec() == oa.num_vec() and a.defined()
