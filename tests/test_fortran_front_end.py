@@ -354,3 +354,55 @@ def test_reference_f95_caller_against_our_f95_module_on_gpu(tmp_path):
     got = p.stdout.splitlines()
     assert len(got) == len(want) == 403
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "dropin_example_f08")) or
+                    not os.path.exists(os.path.join(REFDIR, "nka_example_f08")), reason="drop-in / reference build absent")
+@pytest.mark.parametrize("args", [["-n", "120", "--nka-vec", "8", "--sweeps", "3"], ["-n", "33", "--nka-vec", "12"],
+                                  ["-n", "200", "--nka-vec", "3", "--omega", "1.2"], ["-a", "0.1", "--nka-vec", "20"]])
+def test_reference_array_caller_at_other_problem_sizes_against_the_compiled_reference(tmp_path, args):
+    """Beyond the three published tables: the reference's unchanged src-F08/nka_example.F90 linked with OUR module
+    (every accel_update on the MI355X) against the SAME program linked with the reference's own nka_type (CPU), at
+    other grids, subspace sizes and parameters: the same number of iterations, and every printed figure (residual
+    norm to 7 digits, reduction, rate) equal to within one unit of its last printed digit (a long run does pass
+    through values like 6.9125005 whose seventh digit a difference in the sixteenth decides)."""
+    ours = subprocess.run([os.path.join(REFDIR, "dropin_example_f08")] + args, cwd=tmp_path, capture_output=True, text=True,
+                          timeout=600)
+    ref = subprocess.run([os.path.join(REFDIR, "nka_example_f08")] + args, cwd=tmp_path, capture_output=True, text=True,
+                         timeout=600)
+    assert ours.returncode == 0 and ref.returncode == 0, ours.stdout[-500:] + ours.stderr + ref.stderr
+    a, b = ours.stdout.splitlines(), ref.stdout.splitlines()
+    assert len(b) > 10 and len(a) == len(b)
+
+    def rows(lines):
+        out = []
+        for ln in lines:
+            t = ln.replace(":", " ").split()
+            out.append([float(v) for v in t] if len(t) == 4 and t[0].isdigit() else None)
+        return out
+
+    # A slowly converging run amplifies last-bit differences (at -n 200 --nka-vec 3, 934 iterations, the reference's
+    # OWN two Fortran flavours print different last digits in 453 lines, up to 1e-5 relative).  So the yardstick is the
+    # reference itself: the same program with the reference's src-F08-vector module.  This build must stay at least as
+    # close to src-F08 as that -- in how many lines differ and in how far -- with one unit of the last printed digit as
+    # the floor.
+    ra, rb = rows(a), rows(b)
+    vec = os.path.join(REFDIR, "nka_example_f08vec")
+    allowed_lines, allowed_rel = 2, 0.0
+    if os.path.exists(vec):
+        rv = subprocess.run([vec] + args, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        lv = rv.stdout.splitlines()
+        if rv.returncode == 0 and len(lv) == len(b):
+            allowed_lines = max(allowed_lines, sum(1 for x, y in zip(lv, b) if x != y))
+            allowed_rel = max([abs(x[1] - y[1]) / y[1] for x, y in zip(rows(lv), rb) if x and y and y[1] > 0] + [0.0])
+    ndiff = 0
+    for la, lb, x, y in zip(a, b, ra, rb):
+        if la == lb:
+            continue
+        ndiff += 1
+        assert x and y and x[0] == y[0], (la, lb)
+        unit = 1.001 * 10.0 ** (np.floor(np.log10(y[1])) - 6)             # one unit of the 7th significant digit
+        assert abs(x[1] - y[1]) <= max(unit, allowed_rel * y[1]), (la, lb, allowed_rel)
+        assert abs(x[3] - y[3]) <= 1.001e-3, (la, lb)
+    assert ndiff <= allowed_lines, (ndiff, allowed_lines, len(b))
