@@ -211,13 +211,13 @@ int nka_hip_state_digest(nka_hip_t a, uint64_t *digest);
  * on w1' = d/s the Gram row fn(w1', w_k) and the projections fn(f, w_j) -- while
  * the scalar step, the combine and the ring stores stay on the device.  fn must
  * return the GLOBAL dot product (as in the reference, F08:58-64); the all-reduce
- * hook is not applied on top.  The calls an update makes are a SUPERSET of the
- * reference's: fn(f, w_k) is evaluated for every older list entry before the drop
- * decisions are known, i.e. also for an entry this very update then drops (capacity
- * F08:301-309 or dependence F08:326-345) -- the reference takes its projection row after
- * the drops (F08:371).  The extra value is discarded; a dp with side effects (call
- * counters, per-call message tags) sees up to mvec more calls per update than with the
- * reference, in this order: (d,d); (f,w1'); then per older entry k: (w1',w_k), (f,w_k).  2+L vectors cross PCIe per update and the call
+ * hook is not applied on top.  The calls an update makes are EXACTLY the reference's, in the
+ * reference's order, on the reference's operands: fn(d,d); if s != 0 the Gram row
+ * fn(w1', w_k) for every older list entry in list order (F08:286-290); then -- after the
+ * device has taken the drop decisions and the host has read the list back -- the
+ * projections fn(f, w_j) for j = first ... last of the list as it then stands (F08:371).
+ * A dp with side effects cannot tell the two apart (tests compare the call sequences).
+ * 2+L vectors cross PCIe per update and the call
  * synchronises: a compatibility path, orders of magnitude slower than the
  * device sums.  fn = NULL restores them. */
 typedef double (*nka_hip_host_dot_fn)(void *ctx, int64_t n, const double *x, const double *y);

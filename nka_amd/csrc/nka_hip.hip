@@ -678,7 +678,7 @@ static int enqueue_solve(nka_hip_t a, int mode) {
 #undef SOLVE
   } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
-                       a->state_in_global ? 1 : 0);
+                       a->state_in_global ? 1 : 0, 0);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -765,21 +765,25 @@ static __global__ __launch_bounds__(kBlock) void k_hostdot_normalise(int64_t n, 
     d[i] = rcp ? rs * d[i] : d[i] / s;
 }
 
-// The inner products of an update through the USER's host dot product
-// (nka_hip_set_host_dot): the reference's own sequence of dp calls on host copies
-// of the operands -- dp(d,d) with d = w1 - f (F08:266-267), then on the
-// normalised w1' = d/s the Gram row dp(w1', w_k) (F08:288) and the projections
-// dp(f, w_j) (F08:371) -- written to red[] for the device scalar step (mode
-// kSolvePrenorm).  d and w1' are formed by device kernels (the host only copies,
-// calls dp and takes one square root to know whether s == 0).  Synchronous and
-// PCIe-bound by construction: a compatibility path, never the measured one.
-static int host_dot_sums(nka_hip_t a, const double *f) {
+static int fetch_state(nka_hip_t a, std::vector<int32_t> &ic, std::vector<double> &dc);
+
+// The inner products AND the scalar step of an update through the USER's host dot product
+// (nka_hip_set_host_dot), as the reference's own sequence of dp calls on host copies of the operands, same
+// operands, same order, no call the reference does not make:
+//   dp(d,d) with d = w1 - f (F08:266-267); if s != 0, on the normalised w1' = d/s the Gram row dp(w1', w_k) for
+//   every older list entry in list order (F08:286-290) -> device: norm, relax, Gram row, factorisation with its
+//   drop decisions (k_solve phase 1) -> the list as it now stands is read back -> the projections dp(f, w_j) for
+//   j = first ... last of THAT list (F08:371: after the drops) -> device: substitutions, plans, prepend (phase 2).
+// d and w1' are formed by device kernels (the host only copies, calls dp and takes one square root to know
+// whether s == 0).  Synchronous and PCIe-bound by construction: a compatibility path, never the measured one.
+static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   const int64_t n = a->n;
-  const int mvec = a->mvec;
+  const int mvec = a->mvec, m1 = mvec + 1;
   const int rcp = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? 1 : 0;
   HIP_TRY(hipStreamSynchronize(a->stream));
-  std::vector<int32_t> ic(a->ctl.ic_count());
-  HIP_TRY(hipMemcpy(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost));
+  std::vector<int32_t> ic;
+  std::vector<double> dc;
+  if (int rc = fetch_state(a, ic, dc)) return rc;
   const int pending = ic[IC_PLAN_PENDING], first = ic[IC_PLAN_FIRST], nolder = ic[IC_PLAN_NOLDER];
   const int32_t *slots = ic.data() + (a->ctl.plan_slots() - a->ctl.ic);
   if (nolder < 0 || nolder > mvec + 1 || (pending && (first < 1 || first > mvec + 1)))
@@ -805,17 +809,42 @@ static int host_dot_sums(nka_hip_t a, const double *f) {
       HIP_TRY(hipGetLastError());
       if (n > 0) HIP_TRY(hipMemcpyAsync(hw1.data(), a->hd_scratch, nb, hipMemcpyDeviceToHost, a->stream));
       HIP_TRY(hipStreamSynchronize(a->stream));
-      red[1] = a->host_dot(a->host_dot_ctx, n, hf.data(), hw1.data());          // F08:371, j = first
+      for (int p = 0; p < nolder; p++) {                                          // F08:286-290, list order
+        const int slot = slots[p];
+        if (slot < 1 || slot > mvec + 1) return fail(NKA_HIP_ESTATE, "host dot path: slot out of range in the dot plan");
+        if (n > 0) HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(slot - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+        red[2 + p] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hk.data());
+      }
     }
   }
-  for (int p = 0; p < nolder; p++) {
-    const int slot = slots[p];
-    if (slot < 1 || slot > mvec + 1) return fail(NKA_HIP_ESTATE, "host dot path: slot out of range in the dot plan");
-    if (n > 0) HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(slot - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
-    if (normed) red[2 + p] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hk.data());       // F08:288
-    red[2 + mvec + p] = a->host_dot(a->host_dot_ctx, n, hf.data(), hk.data());             // F08:371
-  }
   HIP_TRY(hipMemcpy(a->ctl.red(), red.data(), sizeof(double) * red.size(), hipMemcpyHostToDevice));
+  // ---- device: norm, s == 0 -> relax, Gram row, Cholesky with drops (the reference's loops on one lane)
+  const size_t smem = a->state_in_global ? 0 : lst_smem_bytes(a->mvec);
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
+                     a->state_in_global ? 1 : 0, 1);
+  HIP_TRY(hipGetLastError());
+  // ---- the list after the drops; its projections in list order, first ... last (F08:369-371)
+  if (int rc = fetch_state(a, ic, dc)) return rc;
+  std::vector<double> c((size_t)m1 + 1, 0.0);
+  if (ic[IC_SUBSPACE]) {
+    const int32_t *next = ic.data() + IC_HEADER;
+    int steps = 0;
+    for (int j = ic[IC_FIRST]; j != 0; j = next[j]) {
+      if (j < 1 || j > m1 || ++steps > m1) return fail(NKA_HIP_ESTATE, "host dot path: corrupt list on the device");
+      const double *wj = hk.data();
+      if (normed && j == first) {
+        wj = hw1.data();                          // the new w1' (not stored yet: the combine pass writes it)
+      } else if (n > 0) {
+        HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(j - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+      }
+      c[(size_t)j] = a->host_dot(a->host_dot_ctx, n, hf.data(), wj);              // F08:371
+    }
+  }
+  HIP_TRY(hipMemcpy(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+  // ---- device: new slot, substitutions, plans, prepend
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
+                     a->state_in_global ? 1 : 0, 2);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -838,10 +867,11 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   // A failure up to and including the all-reduce leaves the update NOT done: only
   // scratch (partials, red[]) has been written; f, the stored vectors, the lists and
   // the host-side bookkeeping are untouched, so the same call may be repeated.
+  bool solved = false;
   if (a->host_dot) {
-    RoctxRange range("nka:PA host dot products");
-    if (int rc = host_dot_sums(a, f)) return rc;
-    mode |= kSolvePrenorm;
+    RoctxRange range("nka:host dot products + scalar step");
+    if (int rc = host_dot_update_scalars(a, f, mode)) return rc;
+    solved = true;
   } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
     enqueue_pa(a, f, vec, older_ub);
@@ -854,7 +884,8 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
   RoctxRange range_tail("nka:solve + PB combine");
-  if (int rc = enqueue_solve(a, mode)) return rc;
+  if (!solved)
+    if (int rc = enqueue_solve(a, mode)) return rc;
   if (int rc = record(a, 2)) return rc;
 
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;

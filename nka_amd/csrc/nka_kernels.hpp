@@ -916,7 +916,12 @@ __device__ __forceinline__ double solve_nrm(double x, double s, double rs, int m
 }
 
 // The scalar part of accel_update between PA and PB, reference loops verbatim on one lane.
-static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global) {
+// `phase`: 0 = the whole step.  The user-dot-product path (nka_hip_set_host_dot) runs it in two halves so that
+// the host can ask the user's dp for the projection row AFTER the drop decisions, as the reference does (F08:371
+// comes behind F08:295-347): 1 = norm, s == 0 -> relax, Gram row, factorisation with drops; 2 = new slot, the
+// substitutions on the right-hand side the host has put into c[] BY SLOT, combine plan, prepend.
+static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global,
+                                                                                       int phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem, in_global);
@@ -925,40 +930,47 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
     const int32_t *ps = ctl.plan_slots();
     const int nolder = ctl.ic[IC_PLAN_NOLDER];
     const int entry_first = L.first;
-    bool normed = false;
-    double s = 0.0;
-    if (L.pending) {
-      s = sqrt(red[0]);                       // F08:267
-      ctl.dc[DC_S] = s;
-      if (s == 0.0) {                         // F08:275
-        lst_relax(L);
-        ctl.ic[IC_NRELAX] += 1;
+    bool normed = (phase == 2) ? ctl.ic[IC_NORMED] != 0 : false;
+    double s = (phase == 2) ? ctl.dc[DC_S] : 0.0;
+    if (phase != 2) {
+      if (L.pending) {
+        s = sqrt(red[0]);                       // F08:267
+        ctl.dc[DC_S] = s;
+        if (s == 0.0) {                         // F08:275
+          lst_relax(L);
+          ctl.ic[IC_NRELAX] += 1;
+        }
       }
-    }
-    const double rs = 1.0 / s;
-    if (L.pending) {
-      normed = true;
-      // Gram row of w1' = d/s from the raw sums <d,w_k> of PA (F08:286-290)
-      for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = solve_nrm(red[2 + p], s, rs, mode);
-      lst_factor(L);
-    }
-    const int slot = L.free_;
-    L.free_ = L.next[slot];
-    int ncomb = 0;
-    if (L.subspace) {
-      if (normed) L.c[entry_first] = solve_nrm(red[1], s, rs, mode);   // <f,w1'> = <f,d>/s
-      for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
-      lst_solve(L);
-      for (int k = L.first; k != 0; k = L.next[k]) {
-        ctl.comb_slots()[ncomb] = k;
-        ctl.comb_c()[ncomb] = L.c[k];
-        ncomb++;
+      const double rs = 1.0 / s;
+      if (L.pending) {
+        normed = true;
+        // Gram row of w1' = d/s from the raw sums <d,w_k> of PA (F08:286-290)
+        for (int p = 0; p < nolder; p++) L.H(L.first, ps[p]) = solve_nrm(red[2 + p], s, rs, mode);
+        lst_factor(L);
       }
+      ctl.ic[IC_NORMED] = normed ? 1 : 0;
     }
-    ctl.ic[IC_NCOMB] = ncomb;
-    ctl.ic[IC_NEW] = slot;
-    ctl.ic[IC_NORMED] = normed ? 1 : 0;
-    lst_prepend(L, slot);
+    if (phase != 1) {
+      const double rs = 1.0 / s;
+      const int slot = L.free_;
+      L.free_ = L.next[slot];
+      int ncomb = 0;
+      if (L.subspace) {
+        if (phase == 0) {
+          if (normed) L.c[entry_first] = solve_nrm(red[1], s, rs, mode);   // <f,w1'> = <f,d>/s
+          for (int p = 0; p < nolder; p++) L.c[ps[p]] = red[2 + ctl.mvec + p];
+        }
+        lst_solve(L);
+        for (int k = L.first; k != 0; k = L.next[k]) {
+          ctl.comb_slots()[ncomb] = k;
+          ctl.comb_c()[ncomb] = L.c[k];
+          ncomb++;
+        }
+      }
+      ctl.ic[IC_NCOMB] = ncomb;
+      ctl.ic[IC_NEW] = slot;
+      lst_prepend(L, slot);
+    }
   }
   lst_store(L, ctl, in_global);
 }

@@ -42,7 +42,11 @@ def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cu
     (nka_hip_set_host_dot), the device evaluates the reference's own dp calls on
     host copies of bit-identical operands, so results agree BIT FOR BIT --
     dependent inputs (drops), a repeated input (s == 0 -> relax), relax and
-    restart included."""
+    restart included.  And the SEQUENCE of dp calls is the reference's: the same
+    number of calls, in the same order, each on the same two operands (a dp with
+    side effects -- call counters, per-call message tags -- cannot tell the two
+    apart): the projection row is asked for AFTER the drop decisions (F08:371
+    behind F08:295-347), never for an entry the update drops."""
     import nka_amd
     n, m = 1031, 5
     X = oracle.lcg_vectors(14, n, seed=5)
@@ -50,13 +54,16 @@ def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cu
     acc = nka_amd.nka().init(n, m, flavor=flavor)
     ora = oracle.OracleNKA(n, m, flavor)
     calls = [0, 0]
+    seq_a, seq_o = [], []
 
     def dp_a(x, y):
         calls[0] += 1
+        seq_a.append((hash(np.asarray(x).tobytes()), hash(np.asarray(y).tobytes())))
         return pairwise_dot(x, y)
 
     def dp_o(x, y):
         calls[1] += 1
+        seq_o.append((hash(np.asarray(x).tobytes()), hash(np.asarray(y).tobytes())))
         return pairwise_dot(np.asarray(x), np.asarray(y))
 
     acc.set_host_dot(dp_a)
@@ -78,6 +85,7 @@ def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cu
         assert acc.num_vec() == ora.num_vec(), t
         assert acc.state().list_order() == ora.state().list_order(), t
         assert np.array_equal(out, f), (flavor, t, np.abs(out - f).max())
+        assert seq_a == seq_o, (flavor, t, len(seq_a), len(seq_o))      # the reference's dp calls, no more, no fewer, in order
         if t == 10:
             acc.relax(); ora.relax()
         if t == 14:
