@@ -299,7 +299,9 @@ class RefC:
     """The reference src-C accelerator (oracle/ref_c_shim.c) with state dump."""
     _L = None
 
-    def __init__(self, vlen: int, mvec: int, vtol: float = 0.01):
+    def __init__(self, vlen: int, mvec: int, vtol: float = 0.01, dp=None):
+        """dp(x: ndarray, y: ndarray) -> float: the reference's own user dot product argument
+        (nka_init(..., dp), .c:211, 227-231), None = its default."""
         if RefC._L is None:
             L = C.CDLL(os.path.join(REF_DIR, "libnka_ref_c.so"))
             L.nka_init.restype = C.c_void_p
@@ -316,7 +318,12 @@ class RefC:
             L.ref_c_v.restype = _dp
             RefC._L = L
         self.vlen, self.mvec = vlen, mvec
-        self._h = RefC._L.nka_init(vlen, mvec, vtol, None)
+        self._cb = None
+        if dp is not None:
+            def tramp(n, x, y):
+                return float(dp(np.ctypeslib.as_array(x, (n,)), np.ctypeslib.as_array(y, (n,))))
+            self._cb = C.CFUNCTYPE(C.c_double, C.c_int, _dp, _dp)(tramp)
+        self._h = RefC._L.nka_init(vlen, mvec, vtol, C.cast(self._cb, C.c_void_p) if self._cb else None)
 
     def __del__(self):
         if getattr(self, "_h", None):

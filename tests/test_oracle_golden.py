@@ -154,3 +154,47 @@ def test_live_compiled_reference_bit_exact(oracle):
         if t == 23:
             for o in (a, r, c, rc):
                 o.restart()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(S.GOLD), "..", "oracle", "_ref", "libnka_ref_c.so")),
+                    reason="compiled reference absent")
+def test_user_dot_product_call_sequence_is_pinned_to_the_compiled_reference(oracle):
+    """The sequence of user-dp calls -- how many, in which order, on which operands -- is part of the reference's
+    behaviour for a dp with side effects.  The oracle's set_dot_prod run against the COMPILED src-C reference
+    constructed with the same dp (nka_init(..., dp), .c:211, 227-231): identical call sequences, operand by
+    operand, and bit-identical outputs, through dependence drops, a repeated input (s == 0 -> relax), relax and
+    restart.  (tests/test_hip_round2.py then holds the device path to the oracle's sequence.)"""
+    n, m = 257, 4
+    X = oracle.lcg_vectors(12, n, seed=3)
+    basis = oracle.lcg_vectors(2, n, seed=4)
+    seq_o, seq_r = [], []
+
+    def fp(seq):
+        def dp(x, y):
+            x, y = np.asarray(x), np.asarray(y)
+            seq.append((hash(x.tobytes()), hash(y.tobytes())))
+            return float(np.add.reduce((x * y)[::-1]))          # not the default order: really used
+        return dp
+
+    ora = oracle.OracleNKA(n, m, oracle.C_FLAVOR)
+    ora.set_dot_prod(fp(seq_o))
+    ref = oracle.RefC(n, m, 0.01, dp=fp(seq_r))
+    for t in range(20):
+        if t % 4 == 3:
+            x = (t + 1.0) * basis[0] - 0.5 * basis[1]
+        elif t == 9:
+            x = prev.copy()
+        else:
+            x = X[t % 12] * (1.0 + 0.1 * t)
+        prev = x
+        fo, fr = x.copy(), x.copy()
+        ora.accel_update(fo)
+        ref.accel_update(fr)
+        assert np.array_equal(fo, fr), t
+        assert ora.num_vec() == ref.num_vec(), t
+        assert seq_o == seq_r, (t, len(seq_o), len(seq_r))
+        if t == 12:
+            ora.relax(); ref.relax()
+        if t == 16:
+            ora.restart(); ref.restart()
+    assert len(seq_o) > 60
