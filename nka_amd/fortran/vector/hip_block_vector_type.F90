@@ -456,7 +456,7 @@ contains
 
   !! [apply the deferred update,] scale both members of the new pair and take both
   !! inner-product rows while the stored vectors stream past once (R (3+L)n, W 2n).
-  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled)
+  subroutine scale_dot_pair_many_fused(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled, f_row)
     class(hip_block_vector), intent(inout) :: this
     class(vector), intent(inout) :: v
     real(r8), intent(in) :: a
@@ -466,7 +466,7 @@ contains
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
     real(r8), intent(in), optional :: pre_a
-    logical, intent(out), optional :: scaled
+    logical, intent(out), optional :: scaled, f_row
     type(c_ptr) :: ptrs(max(size(idx),1))
     logical :: defer
     integer :: j
@@ -479,6 +479,7 @@ contains
       pre = 1
       pa = pre_a
     end if
+    if (present(f_row)) f_row = .true.          ! both inner-product rows come out of the one pass
     select type (v)
     class is (hip_block_vector)
       select type (f)

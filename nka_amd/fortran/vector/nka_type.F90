@@ -272,18 +272,25 @@ contains
         end do
       else if (stored) then
         call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
-                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, scaled=scaled)
+                                                    idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, scaled=scaled, &
+                                                    f_row=have_rows)
       else                                                   ! the norm stage left w1 <- w1 - f to this one
         call this%w(this%first)%scale_dot_pair_many(this%v(this%first), 1.0_r8/s, this%compact, f, this%w, &
                                                     idx(1:nidx), vals(1:nidx), bvals(1:nidx), cross, pre_a=-1.0_r8, &
-                                                    scaled=scaled)
+                                                    scaled=scaled, f_row=have_rows)
       end if
-      c(this%first) = cross
+      if (fused) have_rows = .true.
+      if (.not. have_rows .and. .not. scaled) &
+        error stop 'nka%accel_update: a vector type that defers the normalisation must also take the projection row'
       do j = 1, nidx
         this%h(this%first,idx(j)) = vals(j)
-        c(idx(j)) = bvals(j)
       end do
-      have_rows = .true.
+      if (have_rows) then                                    ! the projection row came out of the same pass
+        c(this%first) = cross
+        do j = 1, nidx
+          c(idx(j)) = bvals(j)
+        end do
+      end if
       call factor_with_drops(this)
     else if (have_f_row) then
       do j = 1, nidx
@@ -303,36 +310,52 @@ contains
         idx(nidx) = k
         k = this%next(k)
       end do
-      if (.not. have_rows) then                              ! after relax(): no new pair this call
-        call f%dot_many(this%w, idx(1:nidx), vals(1:nidx))   ! <f,w_j>, F08V:347
+      if (.not. have_rows) then
+        !! The reference's own sequence, call by call (F08V:336-382) -- what a vector type that overrides nothing
+        !! sees, and what remains after relax() / s == 0 when no stage has taken the projection row:
+        !! w_new <- f ; <f,w_j> for j = first ... last of the list as it stands AFTER the drops ; the
+        !! substitutions ; f <- f - c w + c v for every k in list order ; v_new <- f.
+        call this%w(slot)%copy(f)
+        call f%dot_many(this%w, idx(1:nidx), vals(1:nidx))
         do j = 1, nidx
           c(idx(j)) = vals(j)
         end do
-      end if
-      call solve_normal_equations(this, c)
-      do j = 1, nidx
-        vals(j) = c(idx(j))
-      end do
-      !! w_new <- f (F08V:336) ; f <- f - c w + c v for every k in list order (F08V:374) ;
-      !! v_new <- f (F08V:382): one stage; the two ring stores are named by slot index
-      !! (a pair left un-normalised above is entry 1 = this%first of the lists: never dropped)
-      if (this%compact) then                                 ! v slots hold v - w: f <- f + c*(v - w)
-        if (scaled) then
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot)
-        else if (stored) then
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s)
+        call solve_normal_equations(this, c)
+        do j = 1, nidx
+          vals(j) = c(idx(j))
+        end do
+        if (this%compact) then
+          call f%axpy_many(vals(1:nidx), this%v, idx(1:nidx))
         else
-          call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s, pend_pre_a=-1.0_r8)
+          call f%update_many(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx))
         end if
+        call this%v(slot)%copy(f)
       else
-        if (scaled) then
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot)
-        else if (stored) then
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
-                                  pend_a=1.0_r8/s, pend_subtract=.false.)
+        call solve_normal_equations(this, c)
+        do j = 1, nidx
+          vals(j) = c(idx(j))
+        end do
+        !! w_new <- f (F08V:336) ; f <- f - c w + c v for every k in list order (F08V:374) ;
+        !! v_new <- f (F08V:382): one stage; the two ring stores are named by slot index
+        !! (a pair left un-normalised above is entry 1 = this%first of the lists: never dropped)
+        if (this%compact) then                                 ! v slots hold v - w: f <- f + c*(v - w)
+          if (scaled) then
+            call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot)
+          else if (stored) then
+            call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s)
+          else
+            call f%axpy_many_keep(vals(1:nidx), this%v, idx(1:nidx), this%w, slot, slot, pend_a=1.0_r8/s, pend_pre_a=-1.0_r8)
+          end if
         else
-          call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
-                                  pend_a=1.0_r8/s, pend_pre_a=-1.0_r8, pend_subtract=.false.)
+          if (scaled) then
+            call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot)
+          else if (stored) then
+            call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
+                                    pend_a=1.0_r8/s, pend_subtract=.false.)
+          else
+            call f%update_many_keep(-vals(1:nidx), this%w, vals(1:nidx), this%v, idx(1:nidx), slot, slot, &
+                                    pend_a=1.0_r8/s, pend_pre_a=-1.0_r8, pend_subtract=.false.)
+          end if
         end if
       end if
     else

@@ -300,14 +300,15 @@ contains
   !! Normalise the new pair and take both inner-product rows (F08V:255-264, 347):
   !!   [pre_a present: this <- pre_a*f + this, the update update_norm2 did not store ;]
   !!   v <- a*v ; this <- a*this ; [subtract: v <- v - this] ;
-  !!   vals_this(j) = <this, ys(idx(j))>, vals_f(j) = <f, ys(idx(j))>, cross = <f, this>.
+  !!   vals_this(j) = <this, ys(idx(j))> ; and, if the type takes them in the same pass (f_row = .true.),
+  !!   vals_f(j) = <f, ys(idx(j))>, cross = <f, this>.
   !! `scaled` (optional, like `stored` of update_norm2): .true. = this default, `this` and v now HOLD
   !! the normalised pair; an override may answer .false. after a PURE-READ pass that only formed
   !! a*(pre_a*f + this) in registers for the inner products -- the caller then passes the pending
   !! normalisation (pend_a, pend_pre_a, pend_subtract[, pend_w]) to the combine stage, whose
   !! override applies it to entry 1 of its lists while it combines (a type that answers .false.
   !! must override update_many_keep / axpy_many_keep accordingly).
-  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled)
+  subroutine scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled, f_row)
     class(vector), intent(inout) :: this, v
     real(r8), intent(in) :: a
     logical, intent(in) :: subtract
@@ -316,13 +317,21 @@ contains
     integer, intent(in) :: idx(:)
     real(r8), intent(out) :: vals_this(:), vals_f(:), cross
     real(r8), intent(in), optional :: pre_a
-    logical, intent(out), optional :: scaled
+    logical, intent(out), optional :: scaled, f_row
+    !! THIS DEFAULT BODY is what a user type that overrides nothing runs: exactly the reference's calls at this
+    !! point of accel_update, in its order -- scale v, scale w, the Gram row <w1,w_k> (F08V:255-264) -- and NOT the
+    !! projection row: the reference asks for <f,w_j> only after the drop decisions and after w_new <- f
+    !! (F08V:336-347), and so does the accelerator when f_row comes back .false. (see nka_type: accel_update).
+    !! An override that streams the ys anyway takes both rows in its one pass and answers f_row = .true..
     if (present(pre_a)) call this%update(pre_a, f)
     call v%scale(a)
     call this%scale(a)
     if (subtract) call v%update(-1.0_r8, this)
-    call this%dot_pair_many(f, ys, idx, vals_this, vals_f, cross)
+    call this%dot_many(ys, idx, vals_this)
+    vals_f = 0.0_r8
+    cross = 0.0_r8
     if (present(scaled)) scaled = .true.
+    if (present(f_row)) f_row = .false.
   end subroutine
 
   !! xs(keep_in) <- this ; this <- this + sum_j (a(j)*xs(idx(j)) + b(j)*ys(idx(j))) in
