@@ -208,3 +208,89 @@ def test_abstract_vector_flavour_at_baseline_config5_size(torch_cuda, oracle, tm
                 spread=spread.value)
         worst = max(worst, err)
     print(f"abstract-vector flavour n={n0 * R} m={m} compact={compact}: worst rel err vs tiled oracle {worst:.2e}")
+
+
+def _tiled_rel_err(torch, big, small_ref, small_in, reps):
+    """||big - tile(small_ref)|| / ||tile(small_in)|| without a second vector of the big length."""
+    n0 = small_ref.numel()
+    acc = 0.0
+    for r in range(reps):
+        d = big[r * n0:(r + 1) * n0] - small_ref
+        acc += float(torch.dot(d, d))
+    return (acc ** 0.5) / (float(torch.linalg.vector_norm(small_in)) * reps ** 0.5)
+
+
+@pytest.mark.parametrize("flavor", [0, 2])
+def test_more_than_2_to_the_31_elements(torch_cuda, oracle, flavor):
+    """MAXIMUM SIZE.  The reference's vlen is a default integer (F08:156, 185-187): at most 2^31-1 elements.
+    The C ABI takes int64 (include/nka_hip.h: nka_hip_create) and one MI355X holds far more than that, so the
+    kernels index with 64 bits throughout; this runs n = 2^31 + 256 -- 17.2 GB per vector, beyond every int32,
+    with a ragged tail of 256 elements after the last full tile -- against the tiled oracle (256 = 16^2 copies
+    of an n0 = 2^23 + 1 problem), capacity and dependence drops included."""
+    import nka_amd
+    torch = torch_cuda
+    reps, n0, m = 256, 2**23 + 1, 2
+    n = n0 * reps
+    assert n > 2**31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 * n * (2 * (m + 1) + 2) + (8 << 30):
+        pytest.skip("not enough free HBM for n > 2^31")
+    ora = oracle.OracleNKA(n0, m, flavor)
+    spread = P.Spread(oracle, n0, m)
+    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    assert acc.vec_len() == n
+    worst = 0.0
+    for t, x in enumerate(_small_inputs(n0, 9, seed=77)):
+        f = x.copy()
+        ora.accel_update(f)
+        spread.update(x)
+        big = torch.from_numpy(x).cuda().repeat(reps)
+        acc.accel_update(big)
+        assert acc.num_vec() == ora.num_vec(), (t, acc.num_vec(), ora.num_vec())
+        assert acc.state().list_order() == ora.state().list_order()
+        err = _tiled_rel_err(torch, big, torch.from_numpy(f).cuda(), torch.from_numpy(x).cuda(), reps)
+        P.check(err, ora.state(), f"n = 2^31+256 m={m} flavor {flavor} vs tiled oracle", base=TOL_FULL, where=t,
+                spread=spread.value)
+        worst = max(worst, err)
+        del big
+    assert acc.defined()
+    del acc
+    torch.cuda.empty_cache()
+    print(f"n={n} m={m} flavor={flavor}: worst rel err vs tiled oracle {worst:.2e}")
+
+
+def test_vector_hooks_beyond_2_to_the_31_elements(torch_cuda):
+    """The hooks of the abstract-vector path (C ABI, int64 lengths) at n = 2^31 + 256: an elementwise hook is
+    checked on its last elements and by its sums, the reductions against the tiled values."""
+    import ctypes as C
+    import nka_amd
+    torch = torch_cuda
+    L = nka_amd.load()
+    h = C.c_void_p()
+    assert L.nka_hip_vec_workspace_create(C.byref(h), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    try:
+        reps, n0 = 256, 2**23 + 1
+        n = n0 * reps
+        rng = np.random.default_rng(5)
+        xs, ys = rng.standard_normal(n0), rng.standard_normal(n0)
+        x = torch.from_numpy(xs).cuda().repeat(reps)
+        y = torch.from_numpy(ys).cuda().repeat(reps)
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        r = C.c_double()
+        assert L.nka_hip_vec_dot(h, n, ptr(x), ptr(y), C.byref(r)) == 0
+        assert r.value == pytest.approx(reps * float(xs @ ys), abs=1e-12 * reps * np.linalg.norm(xs) * np.linalg.norm(ys))
+        assert L.nka_hip_vec_norm2(h, n, ptr(x), C.byref(r)) == 0
+        assert r.value == pytest.approx(16.0 * float(np.linalg.norm(xs)), rel=1e-12)
+        a, b = 0.75, -1.5
+        assert L.nka_hip_vec_update2(h, n, ptr(y), a, ptr(x), b) == 0          # y <- a*x + b*y
+        want = torch.from_numpy(a * xs + b * ys).cuda()
+        for rep in (0, 127, reps - 1):                                          # first, middle and last period
+            assert torch.equal(y[rep * n0:(rep + 1) * n0], want), rep
+        vals = (C.c_double * 2)()
+        ysp = (C.c_void_p * 2)(x.data_ptr(), y.data_ptr())
+        assert L.nka_hip_vec_dot_many(h, n, ptr(y), ysp, 2, vals) == 0
+        w = a * xs + b * ys
+        assert vals[0] == pytest.approx(reps * float(w @ xs), abs=1e-12 * reps * np.linalg.norm(w) * np.linalg.norm(xs))
+        assert vals[1] == pytest.approx(reps * float(w @ w), rel=1e-12)
+    finally:
+        L.nka_hip_vec_workspace_destroy(h)
