@@ -1,27 +1,32 @@
 """Shared tolerance rule and worst-error bookkeeping of the GPU parity tests.
 
 The bar: ||f_hip - f_ref||_2 / ||f_in||_2 <= 1e-12 for n <= 1e5
-(1e-10 at BASELINE sizes).  That figure is asserted UNSCALED whenever the subspace
-is well conditioned (smallest Cholesky pivot of the live list > 0.5).
-
-Below that the coefficients solve (L L^T) z = W^T f and last-bit differences of the
-inner products are amplified -- the drop rule lets pivots get as small as vtol
-(F08:326).  How much is NOT taken from a formula but from the REFERENCE ITSELF: its
-three flavours (src-F08, src-F08-vector, src-C) differ from one another only in the
-rounding of elementwise statements, so the largest pairwise
-difference of their outputs on the same calls -- the `spread`, taken from the three
-reference outputs the fixtures hold for every call (tests/golden/scenario_*.npz:
-f_out_f08, f_out_f08vec, f_out_c) or, for inputs without a fixture, from the oracle's
-three flavours in lock step (the oracle is pinned to those references bit for bit,
-tests/test_oracle_golden.py) plus the src-F08 flavour with a user dot product that adds
-the same products in another order (class Spread) -- is what the reference's own
-arithmetic does with rounding-level perturbations on THIS input.  The bound in the ill-conditioned branch is
+(1e-10 at BASELINE sizes).  The coefficients solve (L L^T) z = W^T f, the stored
+v's are scaled by 1/s, and last-bit differences of the inner products are amplified
+by both -- the drop rule lets pivots get as small as vtol (F08:326), and a small
+difference norm s makes the v's large against f.  How much is NOT taken from a formula
+but from the REFERENCE ITSELF: its three flavours (src-F08, src-F08-vector, src-C)
+differ from one another only in the rounding of elementwise statements (SURVEY.md
+Appendix A), so the largest pairwise difference of their outputs on the same calls --
+the `spread`, taken from the three reference outputs the fixtures hold for every call
+(tests/golden/scenario_*.npz: f_out_f08, f_out_f08vec, f_out_c) or, for inputs without a
+fixture, from the oracle's three flavours in lock step (the oracle is pinned to those
+references bit for bit, tests/test_oracle_golden.py) plus the src-F08 flavour with two
+user dot products (set_dot_prod, F08:209-219): one that adds the same products in another
+order, one whose results are one unit in the last place off (class Spread) -- is what the
+reference's own arithmetic does with rounding-level perturbations on THIS input.  The bound is
         max(base, K_SPREAD * spread)          (spread cumulative over the calls so far)
-e.g. 1e-9 on fixture S8 (spread 1.3e-10) and 2e-9 on S9 (2.5e-10) where the former
-1/pivot^2 rule allowed 1.5e-9 and 2.8e-7.  The K actually needed (err / spread) is
-recorded per test and printed.  A test that supplies no spread falls back to
-base / pivot^2 and is labelled so.  Every check records the error it saw; the worst
-per test is printed at the end of the run and written to gpurun_out/parity_worst.json.
+e.g. 1e-9 on fixture S8 (spread 1.3e-10) and 2e-9 on S9 (2.5e-10) where a 1/pivot^2 rule
+would allow 1.5e-9 and 2.8e-7; wherever the reference's flavours agree among themselves
+to base / K_SPREAD the stated figure is asserted unscaled.  (Rounds 2-3 applied the spread
+only below a smallest pivot of 0.5 and the unscaled figure above it; a soak run of random
+call sequences -- tools/fuzz_gpu.py, profiles/r03/fuzz_soak.txt -- showed that pivot to be no
+measure of the amplification: with every pivot > 0.5 the reference's own flavours differ by up to
+1.6e-8 on such sequences.)  The K actually needed (err / spread) is recorded per test and
+printed, and so is the worst error seen while the smallest pivot was > 0.5.  A test that
+supplies no spread keeps the pivot rule (base above 0.5, base / pivot^2 below) and is labelled
+so.  Every check records the error it saw; the worst per test is printed at the end of the run
+and written to gpurun_out/parity_worst.json.
 """
 import json
 import os
@@ -38,6 +43,19 @@ def _reordered_dot(x, y):
     return float(np.add.reduce((x * y)[::-1]))
 
 
+class _UlpDot:
+    """A user dot product whose every result is one unit in the last place off, up and down in turn --
+    what any parallel (blocked, tree, all-reduced) evaluation of the same sum does to the reference."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, x, y):
+        self.calls += 1
+        d = float(np.add.reduce(x * y))
+        return float(np.nextafter(d, np.inf if self.calls & 1 else -np.inf))
+
+
 class Spread:
     """The reference's own spread on a call sequence without a fixture: the oracle's three
     flavours (each bit-identical to its reference flavour) PLUS the src-F08 flavour with its
@@ -48,8 +66,9 @@ class Spread:
     .value = largest pairwise ||out_a - out_b|| / ||f_in|| over the calls so far."""
 
     def __init__(self, oracle, n, m, vtol=None):
-        self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR, oracle.F08)]
+        self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR, oracle.F08, oracle.F08)]
         self.accs[3].set_dot_prod(_reordered_dot)
+        self.accs[4].set_dot_prod(_UlpDot())
         if vtol is not None:
             self.set_vec_tol(vtol)
         self.value = 0.0
@@ -99,10 +118,11 @@ def pivot_min(state):
 def tolerance(state, base=1e-12, spread=None):
     """-> (tol, pivot, rule)"""
     piv = pivot_min(state)
+    if spread is not None:
+        tol = max(base, K_SPREAD * spread)
+        return tol, piv, ("stated" if tol == base else "reference spread")
     if piv > 0.5:
         return base, piv, "stated"
-    if spread is not None:
-        return max(base, K_SPREAD * spread), piv, "reference spread"
     return base / (piv * piv), piv, "conditioning (no spread supplied)"
 
 
@@ -115,7 +135,7 @@ def check(err, state, key, base=1e-12, where=None, spread=None):
     rec["checks"] += 1
     if piv > 0.5:
         rec["worst_well_conditioned"] = max(rec["worst_well_conditioned"], float(err))
-    elif spread and err > base:
+    if spread and err > base:
         rec["k_needed"] = max(rec["k_needed"], float(err) / spread)
     if err >= rec["err"]:
         rec.update(err=float(err), tol=float(tol), pivot=float(piv), rule=rule)

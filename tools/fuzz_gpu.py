@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""tools/fuzz_gpu.py -- soak run (not part of the test suite): random call sequences of every public
+operation at random sizes, subspace capacities and flavours, the HIP path against the oracle in lock
+step, for a time budget.
+
+    python tools/fuzz_gpu.py [--seconds 300] [--first-seed 0] [--out gpurun_out/fuzz.txt]
+
+Per seed: n from a set that straddles every tile boundary of the kernels (1 .. ~70 000), mvec in
+1 .. 40, flavour 0 / 1 / 2, 120 operations -- updates with fresh, dependent (rank-3 pool), repeated
+(s == 0) and zero inputs, relax, restart, set_vec_tol, and a deep copy that replaces the accelerator in
+mid-stream.  After EVERY call: num_vec, list order, free list, flags equal the oracle's; after every update
+the value within the rule of tests/parity_util.py (base 1e-12, reference-spread branch when ill-conditioned).
+A failure is recorded with its seed (the run continues); exit status 1 if any seed failed.
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SIZES = [1, 2, 3, 7, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4097, 8191, 8193,
+         16385, 32767, 65537, 70001]
+
+
+def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 70001))
+    m = int(rng.integers(1, 41))
+    flavor = int(rng.integers(0, 3))
+    key = f"fuzz seed {seed} n={n} m={m} flavor {flavor}"
+    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    ora = oracle.OracleNKA(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    for step in range(steps):
+        r = rng.random()
+        if r < 0.80:
+            kind = rng.random()
+            if kind < 0.55:
+                x = rng.standard_normal(n)
+            elif kind < 0.85:
+                x = rng.standard_normal(3) @ basis
+            elif kind < 0.95:
+                x = prev.copy()
+            else:
+                x = np.zeros(n)
+            prev = x
+            f = x.copy()
+            ora.accel_update(f)
+            spread.update(x)
+            ft = torch.from_numpy(x.copy()).cuda()
+            acc.accel_update(ft)
+            if np.linalg.norm(x) > 0:
+                P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value)
+        elif r < 0.87:
+            acc.relax(); ora.relax(); spread.relax()
+        elif r < 0.91:
+            acc.restart(); ora.restart(); spread.restart()
+        elif r < 0.96:
+            vt = float(10.0 ** rng.uniform(-3, -0.3))
+            acc.set_vec_tol(vt); ora.set_vec_tol(vt); spread.set_vec_tol(vt)
+        else:
+            acc = acc.copy()                                # the original is released; the copy carries on
+        sa, so = acc.state(), ora.state()
+        assert acc.num_vec() == ora.num_vec(), (key, step, acc.num_vec(), ora.num_vec())
+        assert sa.list_order() == so.list_order(), (key, step)
+        assert sa.free_order() == so.free_order(), (key, step)
+        assert (sa.subspace, sa.pending) == (so.subspace, so.pending), (key, step)
+    assert acc.defined(), key
+    return key
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
+    args = ap.parse_args()
+    import torch
+    import nka_amd
+    import parity_util as P
+    import scenarios as S
+    from oracle import oracle_py as oracle
+    oracle.lib()
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    t0, seed, failed = time.time(), args.first_seed, []
+    with open(args.out, "w") as out:
+        while time.time() - t0 < args.seconds:
+            try:
+                key = one_seed(seed, torch, oracle, P, S, nka_amd)
+                rec = P.WORST.get(key, {})
+                out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
+                          f"{rec.get('k_needed', 0.0):.2f})\n")
+            except Exception:                               # noqa: BLE001 -- record and carry on with the next seed
+                failed.append(seed)
+                out.write(f"FAIL seed {seed}\n{traceback.format_exc()}\n")
+            out.flush()
+            seed += 1
+            if (seed - args.first_seed) % 20 == 0:
+                print(f"{seed - args.first_seed} seeds, {len(failed)} failed, {time.time() - t0:.0f} s", flush=True)
+        kmax = max([r.get("k_needed", 0.0) for r in P.WORST.values()] + [0.0])
+        wmax = max([r.get("worst_well_conditioned", 0.0) for r in P.WORST.values()] + [0.0])
+        summary = (f"# seeds {args.first_seed}..{seed - 1}: {seed - args.first_seed - len(failed)} ok, {len(failed)} failed "
+                   f"{failed}; largest K needed {kmax:.2f} of {P.K_SPREAD}; well-conditioned worst {wmax:.2e}")
+        out.write(summary + "\n")
+    print(summary)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
