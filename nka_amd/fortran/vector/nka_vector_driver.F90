@@ -32,6 +32,12 @@
 !!       with RCCL 1, the built-in RCCL hook on a one-rank communicator in front of
 !!       it (the device-side path).  Written per call: the global input, num_vec, the
 !!       digest of this rank's replicated scalar state, this rank's slices of the result.
+!!   nka_vector_driver script NFIELD NPER MVEC NOPS OUTFILE COMPACT SCRIPTFILE
+!!       replays NOPS operations from SCRIPTFILE (stream of real64: an operation code, then
+!!       its payload -- 0 accel_update + the NFIELD*NPER input values, 1 relax, 2 restart,
+!!       3 set_vec_tol + the tolerance) on a hip_block_vector and writes, per operation,
+!!       num_vec and, after an update, the returned vector: random call sequences generated
+!!       and checked against the oracle by tools/fuzz_gpu.py --vector.
 !!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
@@ -49,7 +55,7 @@ program nka_vector_driver
   use nka_type
   implicit none
 
-  character(256) :: mode, arg, outfile, shmfile
+  character(256) :: mode, arg, outfile, shmfile, scriptfile
   integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1, rank = 0, world = 1, irccl = 0
   logical :: compact, grid = .false.
   integer(i8) :: nper
@@ -85,6 +91,12 @@ program nka_vector_driver
     end if
     compact = icompact /= 0
     call run_check
+  case ('script')
+    call get_command_argument(6, outfile)
+    call get_command_argument(7, arg); read(arg,*) icompact
+    call get_command_argument(8, scriptfile)
+    compact = icompact /= 0
+    call run_script
   case ('shard')
     call get_command_argument(6, outfile)
     call get_command_argument(7, arg); read(arg,*) icompact
@@ -170,6 +182,55 @@ contains
     close(lun)
     if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
     write(*,'(a,i0,a,i0)') 'check: wrote ', ncalls, ' calls, final num_vec ', accel%num_vec()
+  end subroutine
+
+  subroutine run_script
+    type(hip_block_vector) :: f
+    type(nka) :: accel
+    type(c_ptr) :: ws
+    real(r8), allocatable :: host(:)
+    real(r8) :: code, vtol
+    integer :: t, k, lun, lin
+    integer(i8) :: n
+    n = nfield * nper
+    ws = hip_block_vector_workspace(0)
+    call f%init(nfield, nper, ws)
+    call accel%init(f, mvec, compact=compact)
+    allocate(host(n))
+    open(newunit=lin, file=trim(scriptfile), access='stream', form='unformatted', status='old', action='read')
+    open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    do t = 1, ncalls
+      read(lin) code
+      select case (nint(code))
+      case (0)
+        read(lin) host
+        do k = 1, nfield
+          call f%set_field(k, host((k-1)*nper+1:k*nper))
+        end do
+        call accel%accel_update(f)
+        do k = 1, nfield
+          call f%get_field(k, host((k-1)*nper+1:k*nper))
+        end do
+        write(lun) real(accel%num_vec(), r8)
+        write(lun) host
+      case (1)
+        call accel%relax
+        write(lun) real(accel%num_vec(), r8)
+      case (2)
+        call accel%restart
+        write(lun) real(accel%num_vec(), r8)
+      case (3)
+        read(lin) vtol
+        call accel%set_vec_tol(vtol)
+        write(lun) real(accel%num_vec(), r8)
+      case default
+        error stop 'script: unknown operation code'
+      end select
+    end do
+    close(lun)
+    close(lin)
+    if (.not. accel%defined()) error stop 'accelerator not well defined after the run'
+    write(*,'(a,i0,a,i0)') 'script: ', ncalls, ' operations, final num_vec ', accel%num_vec()
   end subroutine
 
   !! contiguous slice [lo, hi) (0-based) of rank r of `world` over n values; lo, hi even

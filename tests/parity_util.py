@@ -13,7 +13,8 @@ the `spread`, taken from the three reference outputs the fixtures hold for every
 fixture, from the oracle's three flavours in lock step (the oracle is pinned to those
 references bit for bit, tests/test_oracle_golden.py) plus the src-F08 flavour with two
 user dot products (set_dot_prod, F08:209-219): one that adds the same products in another
-order, one whose results are one unit in the last place off (class Spread) -- is what the
+order, and three whose results are one unit in the last place off, up or down in different
+patterns (class Spread) -- is what the
 reference's own arithmetic does with rounding-level perturbations on THIS input.  The bound is
         max(base, K_SPREAD * spread)          (spread cumulative over the calls so far)
 e.g. 1e-9 on fixture S8 (spread 1.3e-10) and 2e-9 on S9 (2.5e-10) where a 1/pivot^2 rule
@@ -47,13 +48,16 @@ class _UlpDot:
     """A user dot product whose every result is one unit in the last place off, up and down in turn --
     what any parallel (blocked, tree, all-reduced) evaluation of the same sum does to the reference."""
 
-    def __init__(self):
+    def __init__(self, pattern=(1, -1)):
         self.calls = 0
+        self.pattern = pattern
 
     def __call__(self, x, y):
         self.calls += 1
         d = float(np.add.reduce(x * y))
-        return float(np.nextafter(d, np.inf if self.calls & 1 else -np.inf))
+        if d == 0.0:                       # an exact zero stays one (a zero input must still give a zero correction)
+            return d
+        return float(np.nextafter(d, np.inf * self.pattern[self.calls % len(self.pattern)]))
 
 
 class Spread:
@@ -66,9 +70,12 @@ class Spread:
     .value = largest pairwise ||out_a - out_b|| / ||f_in|| over the calls so far."""
 
     def __init__(self, oracle, n, m, vtol=None):
-        self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR, oracle.F08, oracle.F08)]
+        self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR, oracle.F08, oracle.F08,
+                                                           oracle.F08, oracle.F08)]
         self.accs[3].set_dot_prod(_reordered_dot)
-        self.accs[4].set_dot_prod(_UlpDot())
+        self.accs[4].set_dot_prod(_UlpDot((1, -1)))
+        self.accs[5].set_dot_prod(_UlpDot((-1, 1)))
+        self.accs[6].set_dot_prod(_UlpDot((1, 1, -1)))
         if vtol is not None:
             self.set_vec_tol(vtol)
         self.value = 0.0
@@ -79,9 +86,10 @@ class Spread:
             f = np.array(x, dtype=np.float64, copy=True)
             a.accel_update(f)
             outs.append(f)
-        nx = max(np.linalg.norm(x), 1e-300)
-        d = max(np.linalg.norm(outs[i] - outs[j]) for i in range(len(outs)) for j in range(i)) / nx
-        self.value = max(self.value, float(d))
+        nx = float(np.linalg.norm(x))
+        if nx > 0.0:                       # (a zero input is checked for an exactly zero result, not against a ratio)
+            d = max(np.linalg.norm(outs[i] - outs[j]) for i in range(len(outs)) for j in range(i)) / nx
+            self.value = max(self.value, float(d))
         return self.value
 
     def relax(self):

@@ -3,7 +3,7 @@
 operation at random sizes, subspace capacities and flavours, the HIP path against the oracle in lock
 step, for a time budget.
 
-    python tools/fuzz_gpu.py [--seconds 300] [--first-seed 0] [--out gpurun_out/fuzz.txt]
+    python tools/fuzz_gpu.py [--seconds 300] [--first-seed 0] [--out gpurun_out/fuzz.txt] [--vector]
 
 Per seed: n from a set that straddles every tile boundary of the kernels (1 .. ~70 000), mvec in
 1 .. 40, flavour 0 / 1 / 2, 120 operations -- updates with fresh, dependent (rank-3 pool), repeated
@@ -11,6 +11,12 @@ Per seed: n from a set that straddles every tile boundary of the kernels (1 .. ~
 mid-stream.  After EVERY call: num_vec, list order, free list, flags equal the oracle's; after every update
 the value within the rule of tests/parity_util.py (base 1e-12, reference-spread branch when ill-conditioned).
 A failure is recorded with its seed (the run continues); exit status 1 if any seed failed.
+
+--vector: the same kind of sequence through the ABSTRACT-VECTOR flavour -- the Fortran accelerator of
+nka_amd/fortran/vector on a device block vector (`nka_vector_driver script`), with the norm stage fused or not
+(NKA_HIP_VEC_FUSE_NORM), the normalisation deferred or not (NKA_HIP_VEC_DEFER_SCALE), compact storage or not, lists
+within and beyond one launch (mvec up to 40) -- against the oracle's F08-vector flavour (no deep copies: the vector
+flavour's objects are the caller's Fortran variables).
 """
 import argparse
 import os
@@ -59,6 +65,8 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120):
             acc.accel_update(ft)
             if np.linalg.norm(x) > 0:
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value)
+            else:
+                assert np.array_equal(ft.cpu().numpy(), f), (key, step)     # a zero input returns a zero
         elif r < 0.87:
             acc.relax(); ora.relax(); spread.relax()
         elif r < 0.91:
@@ -77,12 +85,84 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120):
     return key
 
 
+def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
+    import subprocess
+    rng = np.random.default_rng(10_000 + seed)
+    nfield = int(rng.integers(1, 5))
+    nper = int(rng.choice([1, 2, 3, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1025, 2049, 4097, 9973])) \
+        if rng.random() < 0.8 else int(rng.integers(1, 12000))
+    n = nfield * nper
+    m = int(rng.integers(1, 41))
+    compact, fuse, defer = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    if fuse:
+        defer = 1                                           # fusing needs the deferral
+    key = f"fuzz vector seed {seed} {nfield}x{nper} m={m} compact={compact} fuse={fuse} defer={defer}"
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    ops, script = [], []
+    for _ in range(steps):
+        r = rng.random()
+        if r < 0.82:
+            kind = rng.random()
+            if kind < 0.55:
+                x = rng.standard_normal(n)
+            elif kind < 0.85:
+                x = rng.standard_normal(3) @ basis
+            elif kind < 0.95:
+                x = prev.copy()
+            else:
+                x = np.zeros(n)
+            prev = x
+            ops.append((0, x))
+            script.append(np.concatenate(([0.0], x)))
+        elif r < 0.89:
+            ops.append((1, None)); script.append(np.array([1.0]))
+        elif r < 0.93:
+            ops.append((2, None)); script.append(np.array([2.0]))
+        else:
+            vt = float(10.0 ** rng.uniform(-3, -0.3))
+            ops.append((3, vt)); script.append(np.array([3.0, vt]))
+    sfile, ofile = os.path.join(tmpdir, "script.bin"), os.path.join(tmpdir, "out.bin")
+    np.concatenate(script).tofile(sfile)
+    exe = os.path.join(ROOT, "nka_amd", "fortran", "build", "nka_vector_driver")
+    p = subprocess.run([exe, "script", str(nfield), str(nper), str(m), str(steps), ofile, str(compact), sfile],
+                       capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, NKA_HIP_VEC_FUSE_NORM=str(fuse), NKA_HIP_VEC_DEFER_SCALE=str(defer)))
+    assert p.returncode == 0, (key, p.stdout[-400:], p.stderr[-400:])
+    raw = np.fromfile(ofile, dtype=np.float64)
+    ora = oracle.OracleNKA(n, m, oracle.F08_VECTOR)
+    spread = P.Spread(oracle, n, m)
+    pos = 0
+    for step, (code, arg) in enumerate(ops):
+        nv = int(raw[pos]); pos += 1
+        if code == 0:
+            got = raw[pos:pos + n]; pos += n
+            f = arg.copy()
+            ora.accel_update(f)
+            spread.update(arg)
+            if np.linalg.norm(arg) > 0:
+                P.check(S.rel_err(got, f, arg), ora.state(), key, where=step, spread=spread.value)
+            else:
+                assert np.array_equal(got, f), (key, step)
+        elif code == 1:
+            ora.relax(); spread.relax()
+        elif code == 2:
+            ora.restart(); spread.restart()
+        else:
+            ora.set_vec_tol(arg); spread.set_vec_tol(arg)
+        assert nv == ora.num_vec(), (key, step, nv, ora.num_vec())
+    assert pos == raw.size, key
+    return key
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--first-seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
+    ap.add_argument("--vector", action="store_true")
     args = ap.parse_args()
+    import tempfile
     import torch
     import nka_amd
     import parity_util as P
@@ -96,7 +176,11 @@ def main():
     with open(args.out, "w") as out:
         while time.time() - t0 < args.seconds:
             try:
-                key = one_seed(seed, torch, oracle, P, S, nka_amd)
+                if args.vector:
+                    with tempfile.TemporaryDirectory() as tmpdir:
+                        key = one_seed_vector(seed, oracle, P, S, tmpdir)
+                else:
+                    key = one_seed(seed, torch, oracle, P, S, nka_amd)
                 rec = P.WORST.get(key, {})
                 out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
                           f"{rec.get('k_needed', 0.0):.2f})\n")
