@@ -12,6 +12,9 @@ mid-stream.  After EVERY call: num_vec, list order, free list, flags equal the o
 the value within the rule of tests/parity_util.py (base 1e-12, reference-spread branch when ill-conditioned).
 A failure is recorded with its seed (the run continues); exit status 1 if any seed failed.
 
+--hostdot: a user dot product installed on both sides (nka_hip_set_host_dot / the oracle's set_dot_prod): results
+must agree BIT FOR BIT and the two sides must have made the same number of dp calls after every update.
+
 --vector: the same kind of sequence through the ABSTRACT-VECTOR flavour -- the Fortran accelerator of
 nka_amd/fortran/vector on a device block vector (`nka_vector_driver script`), with the norm stage fused or not
 (NKA_HIP_VEC_FUSE_NORM), the normalisation deferred or not (NKA_HIP_VEC_DEFER_SCALE), compact storage or not, lists
@@ -34,15 +37,34 @@ SIZES = [1, 2, 3, 7, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048,
          16385, 32767, 65537, 70001]
 
 
-def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120):
-    rng = np.random.default_rng(seed)
+def _pairwise_dot(x, y):
+    return float(np.add.reduce(np.asarray(x) * np.asarray(y)))
+
+
+def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
+    rng = np.random.default_rng(seed + (50_000 if hostdot else 0))
     n = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 70001))
+    if hostdot:
+        n = min(n, 8193)                                   # (2 + L vectors cross PCIe per update on this path)
     m = int(rng.integers(1, 41))
     flavor = int(rng.integers(0, 3))
-    key = f"fuzz seed {seed} n={n} m={m} flavor {flavor}"
+    key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}"
     acc = nka_amd.nka().init(n, m, flavor=flavor)
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)
+    calls = [0, 0]
+    if hostdot:
+        # the caller's own dot product (set_dot_prod, F08:209-219) on both sides: the device path evaluates the
+        # reference's sequence of dp calls on host copies of bit-identical operands -> BIT-EXACT results, same call count
+        def dp_a(x, y):
+            calls[0] += 1
+            return _pairwise_dot(x, y)
+
+        def dp_o(x, y):
+            calls[1] += 1
+            return _pairwise_dot(x, y)
+        acc.set_host_dot(dp_a)
+        ora.set_dot_prod(dp_o)
     basis = rng.standard_normal((3, n))
     prev = rng.standard_normal(n)
     for step in range(steps):
@@ -60,10 +82,15 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120):
             prev = x
             f = x.copy()
             ora.accel_update(f)
-            spread.update(x)
+            if not hostdot:
+                spread.update(x)
             ft = torch.from_numpy(x.copy()).cuda()
             acc.accel_update(ft)
-            if np.linalg.norm(x) > 0:
+            if hostdot:
+                assert np.array_equal(ft.cpu().numpy(), f), (key, step, float(np.abs(ft.cpu().numpy() - f).max()))
+                assert calls[0] == calls[1], (key, step, calls)
+                P.record(0.0, 0.0, key)
+            elif np.linalg.norm(x) > 0:
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value)
             else:
                 assert np.array_equal(ft.cpu().numpy(), f), (key, step)     # a zero input returns a zero
@@ -161,6 +188,7 @@ def main():
     ap.add_argument("--first-seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
     ap.add_argument("--vector", action="store_true")
+    ap.add_argument("--hostdot", action="store_true")
     args = ap.parse_args()
     import tempfile
     import torch
@@ -180,7 +208,7 @@ def main():
                     with tempfile.TemporaryDirectory() as tmpdir:
                         key = one_seed_vector(seed, oracle, P, S, tmpdir)
                 else:
-                    key = one_seed(seed, torch, oracle, P, S, nka_amd)
+                    key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot)
                 rec = P.WORST.get(key, {})
                 out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
                           f"{rec.get('k_needed', 0.0):.2f})\n")
