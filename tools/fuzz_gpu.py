@@ -15,6 +15,10 @@ A failure is recorded with its seed (the run continues); exit status 1 if any se
 --hostdot: a user dot product installed on both sides (nka_hip_set_host_dot / the oracle's set_dot_prod): results
 must agree BIT FOR BIT and the two sides must have made the same number of dp calls after every update.
 
+--sharded WORLD: WORLD ranks (sharing cuda:0) each run the HIP path on a contiguous slice -- empty slices at tiny n
+included -- with the all-reduce hook staged through gloo; unsharded oracle on every rank; after every call the
+replicated state digests of all ranks must be equal.  Per-rank logs <out>.rank<r>.
+
 --vector: the same kind of sequence through the ABSTRACT-VECTOR flavour -- the Fortran accelerator of
 nka_amd/fortran/vector on a device block vector (`nka_vector_driver script`), with the norm stage fused or not
 (NKA_HIP_VEC_FUSE_NORM), the normalisation deferred or not (NKA_HIP_VEC_DEFER_SCALE), compact storage or not, lists
@@ -182,6 +186,121 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
     return key
 
 
+class _Alias:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60):
+    """Every rank draws the same sequence; each runs the HIP path on its contiguous slice (some slices are EMPTY at
+    tiny n) with an all-reduce hook staged through gloo, against the unsharded oracle."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(90_000 + seed)
+    n = int(rng.choice([1, 2, 3, 4, 5, 7, 255, 512, 513, 1025, 2049, 4099])) if rng.random() < 0.7 else int(rng.integers(1, 9000))
+    m = int(rng.integers(1, 25))
+    flavor = int(rng.integers(0, 3))
+    key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}"
+    lo, hi = nd.slice_bounds(n, world, rank)
+
+    def hook(ptr, count, stream):
+        dev = torch.as_tensor(_Alias(ptr, count), device="cuda")
+        host = dev.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        dev.copy_(host)
+
+    acc = nka_amd.nka().init(hi - lo, m, flavor=flavor)
+    acc.set_dot_prod(hook)
+    ora = oracle.OracleNKA(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    for step in range(steps):
+        r = rng.random()
+        if r < 0.80:
+            kind = rng.random()
+            if kind < 0.55:
+                x = rng.standard_normal(n)
+            elif kind < 0.85:
+                x = rng.standard_normal(3) @ basis
+            elif kind < 0.95:
+                x = prev.copy()
+            else:
+                x = np.zeros(n)
+            prev = x
+            f = x.copy()
+            ora.accel_update(f)
+            spread.update(x)
+            ft = torch.from_numpy(x[lo:hi].copy()).cuda()
+            acc.accel_update(ft)
+            out = ft.cpu().numpy()
+            nx = np.linalg.norm(x)
+            if nx > 0:
+                # this rank's share of the global error (the slices' squares add up to the whole)
+                P.check(float(np.linalg.norm(out - f[lo:hi]) / nx), acc.state(), key, where=step, spread=spread.value)
+            else:
+                assert np.array_equal(out, f[lo:hi]), (key, step)
+        elif r < 0.87:
+            acc.relax(); ora.relax(); spread.relax()
+        elif r < 0.91:
+            acc.restart(); ora.restart(); spread.restart()
+        elif r < 0.96:
+            vt = float(10.0 ** rng.uniform(-3, -0.3))
+            acc.set_vec_tol(vt); ora.set_vec_tol(vt); spread.set_vec_tol(vt)
+        else:
+            acc = acc.copy()
+        sa, so = acc.state(), ora.state()
+        assert acc.num_vec() == ora.num_vec(), (key, rank, step, acc.num_vec(), ora.num_vec())
+        assert sa.list_order() == so.list_order() and sa.free_order() == so.free_order(), (key, rank, step)
+        digs = nd.replica_digests(acc)
+        assert all(d == digs[0] for d in digs), (key, rank, step, digs)
+    assert acc.defined(), key
+    return key
+
+
+def sharded_worker(args):
+    """One rank of `--sharded` (started by torch.distributed.run).  A failure on any rank ends the whole run (the
+    others would wait in a collective), after the seed has been written."""
+    import torch
+    import torch.distributed as dist
+    import nka_amd
+    from nka_amd import dist as nd
+    import parity_util as P
+    from oracle import oracle_py as oracle
+    oracle.lib()
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    torch.cuda.set_device(0)
+    t0, seed = time.time(), args.first_seed
+    out = open(f"{args.out}.rank{rank}", "w")
+    while True:
+        go = torch.tensor([1 if time.time() - t0 < args.seconds else 0])
+        dist.broadcast(go, 0)
+        if not int(go.item()):
+            break
+        try:
+            key = one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd)
+            rec = P.WORST.get(key, {})
+            out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
+                      f"{rec.get('k_needed', 0.0):.2f})\n")
+            out.flush()
+        except Exception:                                   # noqa: BLE001
+            out.write(f"FAIL seed {seed} rank {rank}\n{traceback.format_exc()}\n")
+            out.close()
+            print(f"FAIL seed {seed} rank {rank}", flush=True)
+            os._exit(1)
+        seed += 1
+        if rank == 0 and (seed - args.first_seed) % 20 == 0:
+            print(f"{seed - args.first_seed} seeds, {time.time() - t0:.0f} s", flush=True)
+    kmax = max([r.get("k_needed", 0.0) for r in P.WORST.values()] + [0.0])
+    out.write(f"# rank {rank}: seeds {args.first_seed}..{seed - 1} ok; largest K needed {kmax:.2f} of {P.K_SPREAD}\n")
+    out.close()
+    if rank == 0:
+        print(f"# seeds {args.first_seed}..{seed - 1} ok on {dist.get_world_size()} ranks; largest K needed (rank 0) {kmax:.2f}")
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
@@ -189,7 +308,22 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
     ap.add_argument("--vector", action="store_true")
     ap.add_argument("--hostdot", action="store_true")
+    ap.add_argument("--sharded", type=int, default=0, metavar="WORLD", help="WORLD ranks sharing cuda:0, gloo-staged hook")
+    ap.add_argument("--sharded-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sharded_worker:
+        return sharded_worker(args)
+    if args.sharded:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.sharded}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--sharded-worker",
+               "--seconds", str(args.seconds), "--first-seed", str(args.first_seed), "--out", args.out]
+        return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")).returncode
     import tempfile
     import torch
     import nka_amd
