@@ -120,3 +120,57 @@ def test_relax_and_restart_storm(torch_cuda, oracle):
         else:
             _track(torch_cuda, a, oa, rng.standard_normal(777), ("storm", t))
         assert a.num_vec() == oa.num_vec() and a.defined()
+
+
+def test_distinct_objects_driven_from_concurrent_host_threads(torch_cuda, oracle):
+    """The reference's object is plain mutable state and distinct objects are independent (SURVEY.md 8b,
+    Threading): four host threads, each with its own accelerator on its own stream, run different sequences at the
+    same time (ctypes releases the interpreter lock inside the C ABI); each must track its own oracle -- decisions
+    exact, and bit for bit the result of the same sequence run alone afterwards."""
+    import threading
+    import nka_amd
+    torch = torch_cuda
+    nthreads, calls = 4, 40
+    shapes = [(30011, 5, 0), (4099, 12, 2), (257, 33, 1), (100003, 8, 2)]
+    inputs, outs, errors = [], [None] * nthreads, []
+    for k, (n, m, fl) in enumerate(shapes):
+        rng = np.random.default_rng(500 + k)
+        basis = rng.standard_normal((3, n))
+        inputs.append([rng.standard_normal(3) @ basis if t % 6 == 4 else rng.standard_normal(n) for t in range(calls)])
+
+    def run(k, record):
+        n, m, fl = shapes[k]
+        res = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            acc = nka_amd.nka().init(n, m, flavor=fl)
+            ora = oracle.OracleNKA(n, m, fl)
+            for t, x in enumerate(inputs[k]):
+                f = x.copy()
+                ora.accel_update(f)
+                ft = torch.from_numpy(x.copy()).cuda(non_blocking=False)
+                acc.accel_update(ft)
+                if t == 17:
+                    acc.relax(); ora.relax()
+                assert acc.num_vec() == ora.num_vec(), (k, t)
+                assert acc.state().list_order() == ora.state().list_order(), (k, t)
+                res.append(ft.cpu().numpy())
+            assert acc.defined()
+        record[k] = res
+
+    def guarded(k):
+        try:
+            run(k, outs)
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=guarded, args=(k,)) for k in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    alone = [None] * nthreads
+    for k in range(nthreads):
+        run(k, alone)
+        for t in range(calls):
+            assert np.array_equal(outs[k][t], alone[k][t]), (k, t)
