@@ -174,6 +174,7 @@ struct nka_hip_state {
   bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
                                  // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
+  int solve_form = 1;         // 1: row-per-lane registers (k_solve_rows); 0: pairs through LDS (k_solve_wave2)
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
   // distribution hook
@@ -613,6 +614,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tile = src->pb_tile;
   b->pb_tickets = src->pb_tickets;
   b->serial_solve = src->serial_solve;
+  b->solve_form = src->solve_form;
   b->debug = src->debug;
   if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
     b->allreduce = src->allreduce;
@@ -661,7 +663,17 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
 // ---- the three stages of an update, enqueued on the handle's stream -------------
 static int enqueue_solve(nka_hip_t a, int mode) {
   hipStream_t s = a->stream;
-  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
+  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve && a->solve_form == 1) {
+    const size_t sm = solve_wave_smem_bytes(a->mvec);
+    const int nl = a->mvec + 1;
+#define ROWS(NL) hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode)
+    if (nl <= 6) ROWS(6);
+    else if (nl <= 11) ROWS(11);
+    else if (nl <= 21) ROWS(21);
+    else if (nl <= 33) ROWS(33);
+    else ROWS(48);
+#undef ROWS
+  } else if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int ns = solve_pairs_per_lane(a->mvec);
 #define SOLVE(NS)                                                                                        \
@@ -1242,6 +1254,8 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
+  } else if (k == "solve_form") {
+    a->solve_form = value != 0;
 
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);

@@ -1051,16 +1051,42 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
   int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
   int32_t *psL = ord + 2 * NL;
   NKA_STAMP(ctl, 0);
-  // ---- one global round trip
+  // ---- one global round trip: EVERY load is issued before the first is waited for (written as plain
+  //      loops the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eleven serial
+  //      round trips of ~500 cycles at mvec = 20).  m1 + 1 <= kSolveWaveMax + 1 <= 64 and
+  //      2 + 2 mvec <= 128, so the lists, sums and plan take one or two loads a lane; the Gram
+  //      matrix kHB a lane (mvec <= 21), the rest of a larger one in the old loop.
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  for (int i = lane; i < nh; i += kSolveThreads) L.h[i] = ctl.h()[i];
-  for (int i = lane; i < m1 + 1; i += kSolveThreads) {
-    L.c[i] = ctl.c()[i];
-    L.next[i] = ctl.next()[i];
-    L.prev[i] = ctl.prev()[i];
+  {
+    constexpr int kHB = 8;
+    static_assert(kSolveWaveMax + 1 <= kSolveThreads, "lists: one load a lane");
+    const double *gh = ctl.h(), *gred = ctl.red();
+    double hreg[kHB], rreg[2], creg = 0.0;
+    int32_t nreg = 0, preg = 0, psreg = 0;
+#pragma unroll
+    for (int k = 0; k < kHB; k++) hreg[k] = (lane + kSolveThreads * k < nh) ? gh[lane + kSolveThreads * k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) rreg[k] = (lane + kSolveThreads * k < 2 + 2 * M) ? gred[lane + kSolveThreads * k] : 0.0;
+    if (lane < m1 + 1) {
+      creg = ctl.c()[lane];
+      nreg = ctl.next()[lane];
+      preg = ctl.prev()[lane];
+    }
+    if (lane < M) psreg = ctl.plan_slots()[lane];        // (bounded by mvec, not by the count still on its way)
+#pragma unroll
+    for (int k = 0; k < kHB; k++)
+      if (lane + kSolveThreads * k < nh) L.h[lane + kSolveThreads * k] = hreg[k];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (lane + kSolveThreads * k < 2 + 2 * M) redL[lane + kSolveThreads * k] = rreg[k];
+    if (lane < m1 + 1) {
+      L.c[lane] = creg;
+      L.next[lane] = nreg;
+      L.prev[lane] = preg;
+    }
+    if (lane < nolder) psL[lane] = psreg;
+    for (int i = lane + kSolveThreads * kHB; i < nh; i += kSolveThreads) L.h[i] = gh[i];
   }
-  for (int i = lane; i < 2 + 2 * M; i += kSolveThreads) redL[i] = ctl.red()[i];
-  for (int i = lane; i < nolder; i += kSolveThreads) psL[i] = ctl.plan_slots()[i];
   L.subspace = ctl.ic[IC_SUBSPACE];
   L.pending = ctl.ic[IC_PENDING];
   L.first = ctl.ic[IC_FIRST];
@@ -1235,6 +1261,294 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode
       const double ci = readlane_f64(yr, i) / readlane_f64(Ldr, i);
       if (lane == i) yr = ci;
       if (lane < i && ((alive >> lane) & 1)) yr = yr - A[i * LDA + lane] * ci;
+    }
+    NKA_STAMP(ctl, 7);
+    nk = __builtin_popcountll(alive & listmask);
+    if (lane < nl && ((alive >> lane) & 1)) {
+      const int r = __builtin_popcountll(alive & ((1ull << lane) - 1));   // position among the kept entries
+      ctl.comb_slots()[r] = myord;
+      ctl.comb_c()[r] = yr;
+      ctl.plan_slots()[r] = myord;             // the next update's older entries: this list, in order
+      L.c[myord] = yr;
+    }
+  } else if (L.subspace) {
+    // no new pair this call (after relax / s == 0): substitute on the stored factor
+    for (int k = L.first; k != 0; k = L.next[k]) ord[nk++] = k;
+    __syncthreads();
+    for (int p = lane; p < nk; p += kSolveThreads) bb[p] = L.c[ord[p]];
+    for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
+      const int p = idx / nk, q = idx - p * nk;
+      if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
+    }
+    __syncthreads();
+    for (int i = 0; i < nk; i++) {             // forward, F08:369-379
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
+      __syncthreads();
+    }
+    for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
+      const double ci = bb[i] / A[i * LDA + i];
+      __syncthreads();
+      if (lane == 0) bb[i] = ci;
+      for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
+      __syncthreads();
+    }
+    for (int p = lane; p < nk; p += kSolveThreads) {
+      ctl.comb_slots()[p] = ord[p];
+      ctl.comb_c()[p] = bb[p];
+      ctl.plan_slots()[p] = ord[p];
+      L.c[ord[p]] = bb[p];
+    }
+  }
+  __syncthreads();
+  lst_prepend(L, slot);                        // F08:406-417 (every lane, same values)
+  NKA_STAMP(ctl, 8);
+  // ---- state back to global memory (the plan was written above: without a subspace
+  //      the list was empty before the prepend, so the next update has no older entry)
+  __syncthreads();
+  for (int i = lane; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
+  for (int i = lane; i < m1 + 1; i += kSolveThreads) {
+    ctl.c()[i] = L.c[i];
+    ctl.next()[i] = L.next[i];
+    ctl.prev()[i] = L.prev[i];
+  }
+  if (lane == 0) {
+    ctl.dc[DC_S] = s;
+    if (entry_first != 0 && !normed && entry_pending) ctl.ic[IC_NRELAX] += 1;
+    ctl.ic[IC_NEW] = slot;
+    ctl.ic[IC_NCOMB] = nk;
+    ctl.ic[IC_NORMED] = normed;
+    ctl.ic[IC_SUBSPACE] = L.subspace;
+    ctl.ic[IC_PENDING] = L.pending;
+    ctl.ic[IC_FIRST] = L.first;
+    ctl.ic[IC_LAST] = L.last;
+    ctl.ic[IC_FREE] = L.free_;
+    ctl.ic[IC_PLAN_PENDING] = L.pending;
+    ctl.ic[IC_PLAN_FIRST] = L.first;
+    ctl.ic[IC_PLAN_NOLDER] = nk;
+  }
+  NKA_STAMP(ctl, 9);
+}
+
+// ---- the wavefront solve, ROW-PER-LANE --------------------------------------------------
+// Lane p keeps row p of the position-ordered matrix in REGISTERS (a[q] = entry (p,q), q < p; the
+// right-hand side is row nl), so a column step needs no LDS and no barrier: the pivot and the
+// column entries of the other rows come through v_readlane with a UNIFORM source lane (a scalar
+// broadcast -- unlike the per-lane ds_bpermute of the pair layout tried in round 3, which waits
+// on the LDS pipe for every shuffle).  Column i: l_p = a_p[i] / L_ii on every lane, then for
+// q = i+1 .. nl-1 (uniform loop) a_p[q] -= l_p * l_q with l_q = readlane(l, q) -- lanes p <= q
+// update entries nobody reads.  Every entry receives the same subtractions in the same ascending-i
+// order and the same division as in k_solve_wave2 / F08:316-321: the same bits.  NLMAX >= nl is a
+// template parameter: both loops are fully unrolled so that a[] stays in registers.
+template <int NLMAX>
+__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
+  Lst L;
+  L.m1 = m1;
+  L.mvec = M;
+  L.h = reinterpret_cast<double *>(smem);
+  L.c = L.h + nh;
+  L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
+  L.prev = L.next + (m1 + 1);
+  double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
+  double *bb = A + (NL + 1) * LDA + 2 * NL;   // (the 2*NL doubles in between are unused)
+  double *redL = bb + NL;
+  int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
+  int32_t *psL = ord + 2 * NL;
+  NKA_STAMP(ctl, 0);
+  // ---- one global round trip: EVERY load is issued before the first is waited for (written as plain
+  //      loops the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eleven serial
+  //      round trips of ~500 cycles at mvec = 20).  m1 + 1 <= kSolveWaveMax + 1 <= 64 and
+  //      2 + 2 mvec <= 128, so the lists, sums and plan take one or two loads a lane; the Gram
+  //      matrix kHB a lane (mvec <= 21), the rest of a larger one in the old loop.
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  {
+    constexpr int kHB = 8;
+    static_assert(kSolveWaveMax + 1 <= kSolveThreads, "lists: one load a lane");
+    const double *gh = ctl.h(), *gred = ctl.red();
+    double hreg[kHB], rreg[2], creg = 0.0;
+    int32_t nreg = 0, preg = 0, psreg = 0;
+#pragma unroll
+    for (int k = 0; k < kHB; k++) hreg[k] = (lane + kSolveThreads * k < nh) ? gh[lane + kSolveThreads * k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) rreg[k] = (lane + kSolveThreads * k < 2 + 2 * M) ? gred[lane + kSolveThreads * k] : 0.0;
+    if (lane < m1 + 1) {
+      creg = ctl.c()[lane];
+      nreg = ctl.next()[lane];
+      preg = ctl.prev()[lane];
+    }
+    if (lane < M) psreg = ctl.plan_slots()[lane];        // (bounded by mvec, not by the count still on its way)
+#pragma unroll
+    for (int k = 0; k < kHB; k++)
+      if (lane + kSolveThreads * k < nh) L.h[lane + kSolveThreads * k] = hreg[k];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (lane + kSolveThreads * k < 2 + 2 * M) redL[lane + kSolveThreads * k] = rreg[k];
+    if (lane < m1 + 1) {
+      L.c[lane] = creg;
+      L.next[lane] = nreg;
+      L.prev[lane] = preg;
+    }
+    if (lane < nolder) psL[lane] = psreg;
+    for (int i = lane + kSolveThreads * kHB; i < nh; i += kSolveThreads) L.h[i] = gh[i];
+  }
+  L.subspace = ctl.ic[IC_SUBSPACE];
+  L.pending = ctl.ic[IC_PENDING];
+  L.first = ctl.ic[IC_FIRST];
+  L.last = ctl.ic[IC_LAST];
+  L.free_ = ctl.ic[IC_FREE];
+  L.vtol = ctl.dc[DC_VTOL];
+  const int entry_pending = L.pending;
+  __syncthreads();
+  NKA_STAMP(ctl, 1);
+  const double vtol2 = L.vtol * L.vtol;
+
+  // ---- phase 0: norm, s == 0 -> relax, Gram row of w1' = d/s, right-hand side
+  const int entry_first = L.first;
+  int normed = 0;
+  double s = 0.0;
+  if (L.pending) {
+    s = sqrt(redL[0]);                        // F08:267
+    if (s == 0.0) lst_relax(L);               // F08:275
+  }
+  if (L.pending) normed = 1;
+  {
+    const double rs = 1.0 / s;
+    for (int p = lane; p < nolder; p += kSolveThreads) {
+      if (normed) L.H(L.first, psL[p]) = solve_nrm(redL[2 + p], s, rs, mode);         // F08:286-290
+      L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
+    }
+    if (normed && lane == 0) L.c[entry_first] = solve_nrm(redL[1], s, rs, mode);     // <f,w1'> = <f,d>/s
+  }
+  __syncthreads();
+  // list position -> slot WITHOUT walking the list: with a new pair this call the list is `first` followed
+  // by the plan (the older entries in list order, which PA's sums follow too; every operation that changes
+  // the list rewrites the plan).  The path without a new pair walks the list itself, below.
+  const int nl = normed ? 1 + nolder : 0;
+  const int myord = normed ? (lane == 0 ? entry_first : (lane <= nolder ? psL[lane - 1] : 0)) : 0;
+  NKA_STAMP(ctl, 2);
+  const uint64_t listmask = (nl >= 64) ? ~0ull : ((1ull << nl) - 1);
+  uint64_t alive = listmask;
+  int capdrop = -1;
+  bool forward_done = false;
+  double ddr = 1.0;    // lane p: running pivot 1 - sum l^2 of list position p
+  double Ldr = 1.0;    // lane p: accepted pivot sqrt(hkk)
+  double yr = 0.0;     // lane p: right-hand side / solution of list position p
+  int nk = 0;
+
+  if (normed) {
+    // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
+    //      plus the right-hand side as row nl (lane p scales row p of each column).
+    // Row p of the matrix is gathered into the registers of lane p (the loads are issued as a batch).
+    double a[NLMAX];
+#pragma unroll
+    for (int q = 0; q < NLMAX; q++) {
+      const int oq = __builtin_amdgcn_readlane(myord, q);      // slot of list position q (0 beyond the list)
+      a[q] = (lane < nl) ? L.H(oq, myord)                      // raw <w_q,w_p>, q newer (used for q < p only)
+                         : L.c[oq];                            // row nl: rhs <f,w_q>
+    }
+    NKA_STAMP(ctl, 3);
+    int kept = 0;
+    bool open_ = true;                           // false once the capacity drop has ended the list (F08:309 exit)
+    // (constant trip counts, guards instead of break / continue: both loops must unroll completely)
+#pragma unroll
+    for (int i = 0; i < NLMAX; i++) {
+      bool keep = false;
+      double Lii = 1.0;
+      if (open_ && i < nl) {
+        if (i == 0) {
+          keep = true;                           // F08:295 h(first,first) = 1
+        } else if (kept + 1 > L.mvec) {
+          capdrop = i;                           // F08:301-308 capacity: i is the last entry
+          open_ = false;
+        } else {
+          const double hkk = readlane_f64(ddr, i);
+          keep = hkk > vtol2;                    // F08:326
+          if (keep) Lii = sqrt(hkk);
+        }
+        if (!keep) alive &= ~(1ull << i);
+      }
+      if (keep) {
+        kept++;
+        if (lane == i) Ldr = Lii;
+        const double l = a[i] / Lii;             // F08:320 (row nl: F08:377); rows <= i: unused
+        a[i] = l;
+        if (lane > i && lane < nl) ddr = ddr - l * l;            // F08:321
+#pragma unroll
+        for (int q = i + 1; q < NLMAX; q++)                      // (no guard q < nl: straight-line code; columns
+          a[q] = a[q] - l * readlane_f64(l, q);                  //  beyond the list hold values nobody reads)
+                                                                 // trailing entry (p,q), p > q: F08:317 (row nl: F08:374)
+      }
+    }
+    NKA_STAMP(ctl, 4);
+    // ---- phase 2: the factor back by slot, and into LDS for the back-substitution (which reads
+    //      COLUMNS of it); replay the drops in list order
+    // (branch-free: a lone wavefront pays ~20 cycles for every taken branch.  Rows are written whole --
+    //  the part right of the diagonal and the columns beyond the list, folded onto column nl, are
+    //  read by nobody -- and an entry that must NOT reach the stored factor goes to a dump word.)
+    {
+      double *const dump = A + NL * LDA + NL;
+      const uint64_t rowbits = (lane < nl && ((alive >> lane) & 1)) ? (alive & ((1ull << lane) - 1)) : 0ull;
+      if (lane <= nl) {
+#pragma unroll
+        for (int q = 0; q < NLMAX; q++) A[lane * LDA + (q < nl ? q : nl)] = a[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NLMAX; q++) {
+        const int oq = __builtin_amdgcn_readlane(myord, q);
+        double *const dst = ((rowbits >> q) & 1) ? &L.H(myord, oq) : dump;
+        *dst = a[q];
+      }
+    }
+    __syncthreads();
+    if (lane < nl && ((alive >> lane) & 1)) L.H(myord, myord) = Ldr;
+    if (lane < nl) yr = A[nl * LDA + lane];    // forward-substituted right-hand side of position p
+    forward_done = true;
+    for (uint64_t dm = ~alive & listmask & ~1ull; dm != 0; dm &= dm - 1) {
+      const int p = __builtin_ctzll(dm);
+      const int k = __builtin_amdgcn_readlane(myord, p);
+      if (p == capdrop) {                      // F08:303-307
+        L.next[L.last] = L.free_;
+        L.free_ = k;
+        L.last = L.prev[k];
+        L.next[L.last] = 0;
+      } else {                                 // F08:331-340
+        const int pv = L.prev[k], nx = L.next[k];
+        L.next[pv] = nx;
+        if (nx == 0) L.last = pv; else L.prev[nx] = pv;
+        L.next[k] = L.free_;
+        L.free_ = k;
+      }
+    }
+    L.subspace = 1;
+    L.pending = 0;
+    __syncthreads();
+  }
+
+  // ---- phase 3: new slot, then the substitutions on the current list
+  NKA_STAMP(ctl, 5);
+  const int slot = L.free_;                    // F08:357-358
+  L.free_ = L.next[slot];
+  if (forward_done) {
+    // back-substitution F08:382-392 in position space: the factor lies in A, its
+    // diagonal in Ldr, the forward-substituted right-hand side in yr
+    NKA_STAMP(ctl, 6);
+    // column `lane` of the factor, requested as ONE batch of LDS reads (rows / lanes beyond the list fold
+    // onto row / column nl: valid addresses, values nobody uses)
+    double t[NLMAX];
+#pragma unroll
+    for (int i = 0; i < NLMAX; i++) t[i] = A[(i < nl ? i : nl) * LDA + (lane < nl ? lane : nl)];
+#pragma unroll
+    for (int i = NLMAX - 1; i >= 0; i--) {
+      if (i < nl && ((alive >> i) & 1)) {
+        const double ci = readlane_f64(yr, i) / readlane_f64(Ldr, i);
+        if (lane == i) yr = ci;
+        if (lane < i && ((alive >> lane) & 1)) yr = yr - t[i] * ci;
+      }
     }
     NKA_STAMP(ctl, 7);
     nk = __builtin_popcountll(alive & listmask);
