@@ -250,7 +250,7 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
  * ticket counters, so that the blocks advance as one compact front.
  * "pb_tile" (-1 automatic, 1, 2): 512- or 1024-element tiles for the shortest lists (<= 14 words
  * per element and tile), where double-width tiles let one ticket counter serve the pass.
- * "serial_solve" = 0/1: the scalar step on one wavefront (k_solve_wave2) or as the reference's loops on one lane.
+ * "serial_solve" = 0/1: the scalar step on one wavefront (k_solve_rows) or as the reference's loops on one lane.
  * Results are bit-identical across variants.
  * "timing_stride" = s (1..1024): with nka_hip_set_timing on, record the events of every
  * s-th update only (the first one after the call included): four event records widen

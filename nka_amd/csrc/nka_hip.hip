@@ -174,7 +174,6 @@ struct nka_hip_state {
   bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
                                  // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
-  int solve_form = 1;         // 1: row-per-lane registers (k_solve_rows); 0: pairs through LDS (k_solve_wave2)
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
   // distribution hook
@@ -614,7 +613,6 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tile = src->pb_tile;
   b->pb_tickets = src->pb_tickets;
   b->serial_solve = src->serial_solve;
-  b->solve_form = src->solve_form;
   b->debug = src->debug;
   if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
     b->allreduce = src->allreduce;
@@ -663,7 +661,7 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
 // ---- the three stages of an update, enqueued on the handle's stream -------------
 static int enqueue_solve(nka_hip_t a, int mode) {
   hipStream_t s = a->stream;
-  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve && a->solve_form == 1) {
+  if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int nl = a->mvec + 1;
 #define ROWS(NL) hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode)
@@ -673,21 +671,6 @@ static int enqueue_solve(nka_hip_t a, int mode) {
     else if (nl <= 33) ROWS(33);
     else ROWS(48);
 #undef ROWS
-  } else if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
-    const size_t sm = solve_wave_smem_bytes(a->mvec);
-    const int ns = solve_pairs_per_lane(a->mvec);
-#define SOLVE(NS)                                                                                        \
-  do {                                                                                                   \
-    hipLaunchKernelGGL((k_solve_wave2<NS>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode);          \
-  } while (0)
-    if (ns <= 1) SOLVE(1);
-    else if (ns <= 2) SOLVE(2);
-    else if (ns <= 4) SOLVE(4);
-    else if (ns <= 6) SOLVE(6);
-    else if (ns <= 9) SOLVE(9);
-    else if (ns <= 13) SOLVE(13);
-    else SOLVE(19);
-#undef SOLVE
   } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
                        a->state_in_global ? 1 : 0, 0);
@@ -1254,8 +1237,6 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
-  } else if (k == "solve_form") {
-    a->solve_form = value != 0;
 
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);

@@ -975,26 +975,42 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
   lst_store(L, ctl, in_global);
 }
 
-// ---- the same scalar step with the O(m^3) arithmetic spread over the wavefront ----
-// k_solve above runs the reference loops verbatim on one lane (~130 us at m=20:
-// every step waits on an LDS-resident linked list).  Here the list is first
-// linearised, the Gram entries gathered into a dense position-indexed matrix,
-// and the Cholesky factorisation done RIGHT-LOOKING: when column i is reached
-// its pivot is final (decide keep / drop exactly as F08:326), the column is
-// scaled by one division per row (lanes = rows) and every trailing entry gets
+// ---- the same scalar step with the O(m^3) arithmetic spread over ONE wavefront ----
+// k_solve above runs the reference loops verbatim on one lane (~130 us at m=20: every step waits
+// on an LDS-resident linked list).  k_solve_rows linearises the list, gathers the Gram entries
+// into a dense position-indexed matrix and factorises it RIGHT-LOOKING: when column i is reached
+// its pivot is final (decide keep / drop exactly as F08:326), the column is scaled by one division
+// per row (lanes = rows) and every trailing entry gets
 //      a(p,q) <- a(p,q) - a(p,i)*a(q,i)
-// Each entry thus receives the same subtractions in the same (ascending i)
-// order as the reference's inner loop F08:316-319, then the same division
-// F08:320 -- bit-identical results, ~m sequential steps instead of ~m^3/3.  The
-// two substitutions (F08:369-392) are done the same way.  List surgery (drops,
-// free-list pushes in list order, new slot, prepend) stays on lane 0.
-// Requires mvec+1 <= kSolveWaveMax; larger subspaces use k_solve.
+// Each entry thus receives the same subtractions in the same (ascending i) order as the
+// reference's inner loop F08:316-319, then the same division F08:320 -- bit-identical results,
+// ~m sequential steps instead of ~m^3/3.  The right-hand side rides along as one more row (forward
+// substitution, F08:369-379); the back-substitution (F08:382-392) is column-oriented in the same
+// way.  List surgery (drops, free-list pushes in list order, new slot, prepend) is O(m) and done
+// redundantly by all lanes on private copies of the scalars.  Requires mvec+1 <= kSolveWaveMax;
+// larger subspaces use k_solve.
+//
+// What sets the run time of a LONE wavefront (tools/solve_phases.py, s_memtime stamps;
+// profiles/r02 and r03/solve_phases*.txt for the forms tried) is, in this order: serial round trips
+// (LDS ~130 cycles, global ~500-2000), taken branches (~20 cycles each), and the issue rate of
+// dependent fp64 instructions (~6 cycles each; sqrt and divide are ~15-instruction chains).  So:
+//   * ONE global round trip at entry: every load of the state, sums and plan issued before the first
+//     is waited for (as plain loops the compiler emits load -> wait -> ds_write per iteration);
+//   * the list order comes from the plan (no walk); lane p holds row p of the matrix IN REGISTERS,
+//     pivots and column entries travel by v_readlane with a uniform source lane (a scalar
+//     broadcast): no LDS access and no barrier inside the factorisation;
+//   * constant trip counts and guards instead of break / continue, no per-entry branches: both
+//     loops unroll completely and the inner one is straight-line code;
+//   * `alive` as a 64-bit mask: drops are visited by count-trailing-zeros, compaction by
+//     population count, in parallel;
+//   * the factor goes to LDS once (the back-substitution reads COLUMNS of it, requested as one
+//     batch) and to the stored matrix by slot with branch-free predicated addresses; the plan of
+//     the next update is written in parallel.
+// History: k_solve_wave (LDS-resident, round 2: ~66 k cycles at m = 20), k_solve_wave2 (pairs dealt
+// to lanes, LDS column exchange with two barriers per column: 42.9 k), a ds_bpermute variant
+// (50 k, not kept), this one: 26.4 k.  The rare path without a new pair (after relax / s == 0)
+// keeps the first version's gather-and-substitute code.
 constexpr int kSolveWaveMax = 48;
-// pairs (p,q), p > q, of the (mvec+2)-row triangle (list rows + the rhs row) dealt
-// round-robin to the 64 lanes
-__host__ __device__ inline int solve_pairs_per_lane(int mvec) {
-  return ((mvec + 2) * (mvec + 1) / 2 + kSolveThreads - 1) / kSolveThreads;
-}
 
 __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   const int nl = mvec + 1;
@@ -1004,27 +1020,6 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   return b;
 }
 
-// ---- the wavefront solve -----------------------------------------------------------------
-// NS = pairs per lane = ceil((mvec+2)(mvec+1)/2 / 64), a template parameter so the per-column
-// update loop is exactly as long as this mvec needs: a lone wavefront issues ~1 instruction per
-// 4-5 cycles, so instruction COUNT, not latency, sets the run time here.  All 64 lanes run the
-// O(m) list bookkeeping redundantly on private copies of the scalars (first/last/free/flags).
-// A first version (k_solve_wave, removed at the end of round 2) walked the lists and read the
-// pivots through LDS: it spent most of its ~66 k cycles (m = 20, tools/solve_phases.py) not on
-// arithmetic but on SERIAL LDS round trips of ~130 cycles each: the list walks
-// (three per update), the per-column pivot read, the position loops over `alive`,
-// and two global round trips at entry.  This one keeps the algorithm and the operation order
-// per matrix entry (hence the bits), with
-//   * ONE global round trip at entry (state, sums and plan loaded together);
-//   * lane k holding next[k]: the list is walked with v_readlane (~10 cycles a step);
-//   * lane p holding the running pivot, the accepted pivot and the right-hand side
-//     of list position p (pivot broadcast by v_readlane, no LDS);
-//   * `alive` as a 64-bit mask: drops are visited by count-trailing-zeros, compaction
-//     by population count, in parallel;
-//   * the back-substitution in POSITION space on the factor where it lies (no
-//     re-gather by slot); the plan of the next update written in parallel.
-// The rare path without a new pair (after relax / s == 0) keeps the first version's
-// gather-and-substitute code.
 __device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
   union { double d; int i[2]; } u;
   u.d = x;
@@ -1033,315 +1028,10 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
   return u.d;
 }
 
-template <int NS>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_wave2(Ctl ctl, int mode) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
-  Lst L;
-  L.m1 = m1;
-  L.mvec = M;
-  L.h = reinterpret_cast<double *>(smem);
-  L.c = L.h + nh;
-  L.next = reinterpret_cast<int32_t *>(L.c + (m1 + 1));
-  L.prev = L.next + (m1 + 1);
-  double *A = reinterpret_cast<double *>(smem + (lst_smem_bytes(ctl.mvec) + 15) / 16 * 16);
-  double *bb = A + (NL + 1) * LDA + 2 * NL;   // (the 2*NL doubles in between are unused)
-  double *redL = bb + NL;
-  int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
-  int32_t *psL = ord + 2 * NL;
-  NKA_STAMP(ctl, 0);
-  // ---- one global round trip: EVERY load is issued before the first is waited for (written as plain
-  //      loops the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eleven serial
-  //      round trips of ~500 cycles at mvec = 20).  m1 + 1 <= kSolveWaveMax + 1 <= 64 and
-  //      2 + 2 mvec <= 128, so the lists, sums and plan take one or two loads a lane; the Gram
-  //      matrix kHB a lane (mvec <= 21), the rest of a larger one in the old loop.
-  const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  {
-    constexpr int kHB = 8;
-    static_assert(kSolveWaveMax + 1 <= kSolveThreads, "lists: one load a lane");
-    const double *gh = ctl.h(), *gred = ctl.red();
-    double hreg[kHB], rreg[2], creg = 0.0;
-    int32_t nreg = 0, preg = 0, psreg = 0;
-#pragma unroll
-    for (int k = 0; k < kHB; k++) hreg[k] = (lane + kSolveThreads * k < nh) ? gh[lane + kSolveThreads * k] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) rreg[k] = (lane + kSolveThreads * k < 2 + 2 * M) ? gred[lane + kSolveThreads * k] : 0.0;
-    if (lane < m1 + 1) {
-      creg = ctl.c()[lane];
-      nreg = ctl.next()[lane];
-      preg = ctl.prev()[lane];
-    }
-    if (lane < M) psreg = ctl.plan_slots()[lane];        // (bounded by mvec, not by the count still on its way)
-#pragma unroll
-    for (int k = 0; k < kHB; k++)
-      if (lane + kSolveThreads * k < nh) L.h[lane + kSolveThreads * k] = hreg[k];
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-      if (lane + kSolveThreads * k < 2 + 2 * M) redL[lane + kSolveThreads * k] = rreg[k];
-    if (lane < m1 + 1) {
-      L.c[lane] = creg;
-      L.next[lane] = nreg;
-      L.prev[lane] = preg;
-    }
-    if (lane < nolder) psL[lane] = psreg;
-    for (int i = lane + kSolveThreads * kHB; i < nh; i += kSolveThreads) L.h[i] = gh[i];
-  }
-  L.subspace = ctl.ic[IC_SUBSPACE];
-  L.pending = ctl.ic[IC_PENDING];
-  L.first = ctl.ic[IC_FIRST];
-  L.last = ctl.ic[IC_LAST];
-  L.free_ = ctl.ic[IC_FREE];
-  L.vtol = ctl.dc[DC_VTOL];
-  const int entry_pending = L.pending;
-  __syncthreads();
-  NKA_STAMP(ctl, 1);
-  const double vtol2 = L.vtol * L.vtol;
-
-  // ---- phase 0: norm, s == 0 -> relax, Gram row of w1' = d/s, right-hand side
-  const int entry_first = L.first;
-  int normed = 0;
-  double s = 0.0;
-  if (L.pending) {
-    s = sqrt(redL[0]);                        // F08:267
-    if (s == 0.0) lst_relax(L);               // F08:275
-  }
-  if (L.pending) normed = 1;
-  {
-    const double rs = 1.0 / s;
-    for (int p = lane; p < nolder; p += kSolveThreads) {
-      if (normed) L.H(L.first, psL[p]) = solve_nrm(redL[2 + p], s, rs, mode);         // F08:286-290
-      L.c[psL[p]] = redL[2 + M + p];                                                 // F08:371
-    }
-    if (normed && lane == 0) L.c[entry_first] = solve_nrm(redL[1], s, rs, mode);     // <f,w1'> = <f,d>/s
-  }
-  __syncthreads();
-  // list position -> slot, walked through registers: lane k holds next[k]
-  const int nxt = (lane <= m1) ? L.next[lane] : 0;
-  int nl = 0, myord = 0;
-  for (int k = __builtin_amdgcn_readfirstlane(L.first); k != 0;) {
-    if (lane == nl) myord = k;
-    nl++;
-    k = __builtin_amdgcn_readlane(nxt, k);
-  }
-  if (lane < nl) ord[lane] = myord;
-  __syncthreads();
-  NKA_STAMP(ctl, 2);
-  const uint64_t listmask = (nl >= 64) ? ~0ull : ((1ull << nl) - 1);
-  uint64_t alive = listmask;
-  int capdrop = -1;
-  bool forward_done = false;
-  double ddr = 1.0;    // lane p: running pivot 1 - sum l^2 of list position p
-  double Ldr = 1.0;    // lane p: accepted pivot sqrt(hkk)
-  double yr = 0.0;     // lane p: right-hand side / solution of list position p
-  int nk = 0;
-
-  if (normed) {
-    // ---- phase 1: right-looking Cholesky with drops (F08:295-347), rows 0..nl-1,
-    //      plus the right-hand side as row nl (lane p scales row p of each column).
-    // Every LDS access of a lane's NS pairs is issued as a batch (all reads of a
-    // stage, then all uses): a lone wavefront cannot hide a ~130-cycle LDS round
-    // trip behind anything else, so NS serial read -> use chains cost NS round trips.
-    int pp[NS], qq[NS], op[NS], oq[NS];
-    const int npairs = (nl + 1) * nl / 2;
-#pragma unroll
-    for (int t = 0; t < NS; t++) {
-      const int idx = lane + kSolveThreads * t;
-      int p = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
-      while (p * (p - 1) / 2 > idx) p--;
-      while ((p + 1) * p / 2 <= idx) p++;
-      pp[t] = idx < npairs ? p : 0;                // unused pairs sit on (0,0): every address below stays valid
-      qq[t] = idx < npairs ? idx - p * (p - 1) / 2 : 0;
-    }
-#pragma unroll
-    for (int t = 0; t < NS; t++) {                 // slots of the pair's two list positions (row nl: the rhs)
-      op[t] = ord[pp[t] < nl ? pp[t] : 0];
-      oq[t] = ord[qq[t]];
-    }
-    {
-      double g[NS];
-#pragma unroll
-      for (int t = 0; t < NS; t++)
-        g[t] = (pp[t] < nl) ? L.H(oq[t], op[t])    // raw <w_q,w_p>, q newer
-                            : L.c[oq[t]];          // rhs <f,w_q>
-#pragma unroll
-      for (int t = 0; t < NS; t++)
-        if (pp[t] > qq[t]) A[pp[t] * LDA + qq[t]] = g[t];
-    }
-    __syncthreads();
-    NKA_STAMP(ctl, 3);
-    int kept = 0;
-    for (int i = 0; i < nl; i++) {
-      bool keep;
-      double Lii = 1.0;
-      if (i == 0) {
-        keep = true;                           // F08:295 h(first,first) = 1
-      } else if (kept + 1 > L.mvec) {
-        keep = false;                          // F08:301-308 capacity: i is the last entry
-        capdrop = i;
-      } else {
-        const double hkk = readlane_f64(ddr, i);
-        keep = hkk > vtol2;                    // F08:326
-        if (keep) Lii = sqrt(hkk);
-      }
-      if (!keep) {
-        alive &= ~(1ull << i);
-        if (capdrop >= 0) break;
-        continue;
-      }
-      kept++;
-      if (lane == i) Ldr = Lii;
-      if (lane > i && lane <= nl) {
-        const double l = A[lane * LDA + i] / Lii;  // F08:320 (row nl: F08:377)
-        A[lane * LDA + i] = l;
-        if (lane < nl) ddr = ddr - l * l;          // F08:321
-      }
-      __syncthreads();
-      {
-        double ap[NS], aq[NS], apq[NS];
-#pragma unroll
-        for (int t = 0; t < NS; t++) {
-          ap[t] = A[pp[t] * LDA + i];
-          aq[t] = A[qq[t] * LDA + i];
-          apq[t] = A[pp[t] * LDA + qq[t]];
-        }
-#pragma unroll
-        for (int t = 0; t < NS; t++)
-          if (qq[t] > i && pp[t] > qq[t])        // trailing entry: F08:317 (row nl: F08:374)
-            A[pp[t] * LDA + qq[t]] = apq[t] - ap[t] * aq[t];
-      }
-      __syncthreads();
-    }
-    NKA_STAMP(ctl, 4);
-    // ---- phase 2: scatter the factor back by slot; replay the drops in list order
-    {
-      double g[NS];
-#pragma unroll
-      for (int t = 0; t < NS; t++) g[t] = A[pp[t] * LDA + qq[t]];
-#pragma unroll
-      for (int t = 0; t < NS; t++) {
-        const int p = pp[t], q = qq[t];
-        if (p > q && p < nl && ((alive >> p) & 1) && ((alive >> q) & 1)) L.H(op[t], oq[t]) = g[t];
-      }
-    }
-    if (lane < nl && ((alive >> lane) & 1)) L.H(myord, myord) = Ldr;
-    if (lane < nl) yr = A[nl * LDA + lane];    // forward-substituted right-hand side of position p
-    forward_done = true;
-    for (uint64_t dm = ~alive & listmask & ~1ull; dm != 0; dm &= dm - 1) {
-      const int p = __builtin_ctzll(dm);
-      const int k = __builtin_amdgcn_readlane(myord, p);
-      if (p == capdrop) {                      // F08:303-307
-        L.next[L.last] = L.free_;
-        L.free_ = k;
-        L.last = L.prev[k];
-        L.next[L.last] = 0;
-      } else {                                 // F08:331-340
-        const int pv = L.prev[k], nx = L.next[k];
-        L.next[pv] = nx;
-        if (nx == 0) L.last = pv; else L.prev[nx] = pv;
-        L.next[k] = L.free_;
-        L.free_ = k;
-      }
-    }
-    L.subspace = 1;
-    L.pending = 0;
-    __syncthreads();
-  }
-
-  // ---- phase 3: new slot, then the substitutions on the current list
-  NKA_STAMP(ctl, 5);
-  const int slot = L.free_;                    // F08:357-358
-  L.free_ = L.next[slot];
-  if (forward_done) {
-    // back-substitution F08:382-392 in position space: the factor lies in A, its
-    // diagonal in Ldr, the forward-substituted right-hand side in yr
-    NKA_STAMP(ctl, 6);
-    for (int i = nl - 1; i >= 0; i--) {
-      if (!((alive >> i) & 1)) continue;
-      const double ci = readlane_f64(yr, i) / readlane_f64(Ldr, i);
-      if (lane == i) yr = ci;
-      if (lane < i && ((alive >> lane) & 1)) yr = yr - A[i * LDA + lane] * ci;
-    }
-    NKA_STAMP(ctl, 7);
-    nk = __builtin_popcountll(alive & listmask);
-    if (lane < nl && ((alive >> lane) & 1)) {
-      const int r = __builtin_popcountll(alive & ((1ull << lane) - 1));   // position among the kept entries
-      ctl.comb_slots()[r] = myord;
-      ctl.comb_c()[r] = yr;
-      ctl.plan_slots()[r] = myord;             // the next update's older entries: this list, in order
-      L.c[myord] = yr;
-    }
-  } else if (L.subspace) {
-    // no new pair this call (after relax / s == 0): substitute on the stored factor
-    for (int k = L.first; k != 0; k = L.next[k]) ord[nk++] = k;
-    __syncthreads();
-    for (int p = lane; p < nk; p += kSolveThreads) bb[p] = L.c[ord[p]];
-    for (int idx = lane; idx < nk * nk; idx += kSolveThreads) {
-      const int p = idx / nk, q = idx - p * nk;
-      if (p >= q) A[p * LDA + q] = L.H(ord[p], ord[q]);
-    }
-    __syncthreads();
-    for (int i = 0; i < nk; i++) {             // forward, F08:369-379
-      const double ci = bb[i] / A[i * LDA + i];
-      __syncthreads();
-      if (lane == 0) bb[i] = ci;
-      for (int j = i + 1 + lane; j < nk; j += kSolveThreads) bb[j] = bb[j] - A[j * LDA + i] * ci;
-      __syncthreads();
-    }
-    for (int i = nk - 1; i >= 0; i--) {        // backward, F08:382-392
-      const double ci = bb[i] / A[i * LDA + i];
-      __syncthreads();
-      if (lane == 0) bb[i] = ci;
-      for (int j = lane; j < i; j += kSolveThreads) bb[j] = bb[j] - A[i * LDA + j] * ci;
-      __syncthreads();
-    }
-    for (int p = lane; p < nk; p += kSolveThreads) {
-      ctl.comb_slots()[p] = ord[p];
-      ctl.comb_c()[p] = bb[p];
-      ctl.plan_slots()[p] = ord[p];
-      L.c[ord[p]] = bb[p];
-    }
-  }
-  __syncthreads();
-  lst_prepend(L, slot);                        // F08:406-417 (every lane, same values)
-  NKA_STAMP(ctl, 8);
-  // ---- state back to global memory (the plan was written above: without a subspace
-  //      the list was empty before the prepend, so the next update has no older entry)
-  __syncthreads();
-  for (int i = lane; i < nh; i += kSolveThreads) ctl.h()[i] = L.h[i];
-  for (int i = lane; i < m1 + 1; i += kSolveThreads) {
-    ctl.c()[i] = L.c[i];
-    ctl.next()[i] = L.next[i];
-    ctl.prev()[i] = L.prev[i];
-  }
-  if (lane == 0) {
-    ctl.dc[DC_S] = s;
-    if (entry_first != 0 && !normed && entry_pending) ctl.ic[IC_NRELAX] += 1;
-    ctl.ic[IC_NEW] = slot;
-    ctl.ic[IC_NCOMB] = nk;
-    ctl.ic[IC_NORMED] = normed;
-    ctl.ic[IC_SUBSPACE] = L.subspace;
-    ctl.ic[IC_PENDING] = L.pending;
-    ctl.ic[IC_FIRST] = L.first;
-    ctl.ic[IC_LAST] = L.last;
-    ctl.ic[IC_FREE] = L.free_;
-    ctl.ic[IC_PLAN_PENDING] = L.pending;
-    ctl.ic[IC_PLAN_FIRST] = L.first;
-    ctl.ic[IC_PLAN_NOLDER] = nk;
-  }
-  NKA_STAMP(ctl, 9);
-}
-
-// ---- the wavefront solve, ROW-PER-LANE --------------------------------------------------
-// Lane p keeps row p of the position-ordered matrix in REGISTERS (a[q] = entry (p,q), q < p; the
-// right-hand side is row nl), so a column step needs no LDS and no barrier: the pivot and the
-// column entries of the other rows come through v_readlane with a UNIFORM source lane (a scalar
-// broadcast -- unlike the per-lane ds_bpermute of the pair layout tried in round 3, which waits
-// on the LDS pipe for every shuffle).  Column i: l_p = a_p[i] / L_ii on every lane, then for
-// q = i+1 .. nl-1 (uniform loop) a_p[q] -= l_p * l_q with l_q = readlane(l, q) -- lanes p <= q
-// update entries nobody reads.  Every entry receives the same subtractions in the same ascending-i
-// order and the same division as in k_solve_wave2 / F08:316-321: the same bits.  NLMAX >= nl is a
-// template parameter: both loops are fully unrolled so that a[] stays in registers.
+// NLMAX >= list length is a template parameter: both loops of the factorisation are fully unrolled so
+// that the row a[] stays in registers (62 VGPRs at NLMAX = 21, 116 at 48; no scratch).  Column i:
+// l_p = a_p[i] / L_ii on every lane, then for q = i+1 .. (uniform loop) a_p[q] -= l_p * l_q with
+// l_q = readlane(l, q) -- lanes p <= q update entries nobody reads.
 template <int NLMAX>
 __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = ["lst_load", "red/plan staging + list walk", "pair setup + gather A", "factorisation loop", "scatter + drop replay",
+NAMES = ["lst_load", "red/plan staging + list order", "gather rows", "factorisation loop", "scatter + drop replay",
          "new slot + ord + gather (phase 3 head)", "backward substitution", "comb plan stores", "lst_store"]
 
 
@@ -40,7 +40,7 @@ def main():
             rows.append(np.diff(st[:10]))
     d = np.median(np.array(rows), axis=0)
     tot = d.sum()
-    print(f"k_solve_wave2 phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
+    print(f"k_solve_rows phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
     for nm, v in zip(NAMES, d):
         print(f"  {nm:<42s} {v:8.0f} cycles  {100 * v / tot:5.1f} %")
     print(f"  {'total inside the kernel':<42s} {tot:8.0f} cycles")
