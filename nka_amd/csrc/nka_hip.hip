@@ -331,7 +331,8 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   int ng = a->pb_tickets;
   if (ng < 0) ng = (ntile * T >= 64 * g) ? (words >= 22 ? 1 : 2) : 0;
   if (ng > 0 && (g % ng != 0 || ntile >= ((int64_t)1 << 31) - 2 * kMaxGrid || !a->tickets)) ng = 0;
-  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W, T>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
+  const int tail = (ntile * (kBlock * 2 * T) < a->n) ? 1 : 0;     // the ragged tail has a block of its own (k_combine_win)
+  hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W, T>), dim3((int)g + tail), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
                      ng > 0 ? a->tickets : nullptr, std::max(ng, 1));
   return (int)g;
 }
