@@ -74,8 +74,10 @@ constexpr int kMaxPerPass = 32;  // largest MAXL / MAXK instantiated
 constexpr int kStamps = 16;      // s_memtime stamps of the scalar step, written only when NKA_SOLVE_STAMPS is defined
 #ifdef NKA_SOLVE_STAMPS
 #define NKA_STAMP(ctl, i) do { if (threadIdx.x == 0) (ctl).stamps()[i] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#define NKA_STAMP0(ctl, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) (ctl).stamps()[i] = (double)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define NKA_STAMP(ctl, i) do { } while (0)
+#define NKA_STAMP0(ctl, i) do { } while (0)
 #endif
 
 struct Ctl {
@@ -111,22 +113,88 @@ struct Vecs {
 };
 
 // ---- reductions ---------------------------------------------------------------
+// Sum over the wavefront, valid in LANE 0: the butterfly x += x[lane + off], off = 32, 16, 8, 4, 2, 1 -- the tree
+// __shfl_down builds, hence the same bits -- but through REGISTERS: gfx950's v_permlane32_swap / v_permlane16_swap
+// for the two steps that cross a row of 16 lanes, DPP row_shl for the four inside row 0 (after the step with
+// offset 16 only lanes 0..15 carry partial sums that reach lane 0).  __shfl_down is two ds_bpermute_b32 and an
+// LDS wait per step: the 42 sums of a PA block took 22 k cycles (~9.5 us of a 15 us launch at n = 1e5) that way.
+__device__ __forceinline__ double swap_sum32(double A, double B);
+__device__ __forceinline__ double swap_sum16(double A, double B);
+template <int N> __device__ __forceinline__ double row_shl_sum(double x);
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-  return x;  // valid in lane 0
+  x = swap_sum32(x, x);
+  x = swap_sum16(x, x);
+  x = row_shl_sum<8>(x);
+  x = row_shl_sum<4>(x);
+  x = row_shl_sum<2>(x);
+  return row_shl_sum<1>(x);
 }
 
-// Sum NACC per-thread accumulators over the block (fixed order: lanes by
-// butterfly, then waves 0..3) and store column a at partials[a*G + block].
+// The first two butterfly steps for TWO sums at once.  swap_sum32(A, B): lanes 0..31 get A[i] + A[i+32], lanes
+// 32..63 get B[i-32] + B[i]; swap_sum16(A, B), row by row of 16 lanes: (A.r0 + A.r1, B.r0 + B.r1, A.r2 + A.r3,
+// B.r2 + B.r3).  The same pairs the butterfly of wave_sum adds, parked in the half / row that the butterfly
+// leaves idle.
+__device__ __forceinline__ double swap_sum32(double A, double B) {
+  union U { double d; unsigned u[2]; } a, b;
+  a.d = A;
+  b.d = B;
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a.u[w], b.u[w], false, false);
+    a.u[w] = r[0];
+    b.u[w] = r[1];
+  }
+  return a.d + b.d;
+}
+__device__ __forceinline__ double swap_sum16(double A, double B) {
+  union U { double d; unsigned u[2]; } a, b;
+  a.d = A;
+  b.d = B;
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a.u[w], b.u[w], false, false);
+    a.u[w] = r[0];
+    b.u[w] = r[1];
+  }
+  return a.d + b.d;
+}
+// x[i] + x[i+N] inside every row of 16 lanes (lanes whose partner is outside the row keep x + x: never used)
+template <int N> __device__ __forceinline__ double row_shl_sum(double x) {
+  union U { double d; unsigned u[2]; } a, b;
+  a.d = x;
+  b.u[0] = __builtin_amdgcn_update_dpp(a.u[0], a.u[0], 0x100 + N, 0xf, 0xf, false);
+  b.u[1] = __builtin_amdgcn_update_dpp(a.u[1], a.u[1], 0x100 + N, 0xf, 0xf, false);
+  return a.d + b.d;
+}
+
+// Sum NACC per-thread accumulators over the block (fixed order: lanes by butterfly, then waves 0..3) and store
+// column a at partials[a*G + block].  Every sum is the tree of wave_sum -- the same bits -- but the NACC
+// butterflies share their steps: the step with offset 32 folds accumulators k and k + H1 into one register
+// (lower / upper half of the wavefront), the step with offset 16 folds registers k and k + H2 (even / odd rows),
+// the four steps inside a row then serve four accumulators each.  ~NACC/4 x 6 exchange-and-add groups instead of
+// NACC x 6 (42 sums of PA at m = 20: 9.9 k -> ~3 k cycles; with __shfl_down 22 k).
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[NACC], double *partials, int G) {
   __shared__ double sm[kWavesPerBlock][NACC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int H1 = (NACC + 1) / 2, H2 = (H1 + 1) / 2;
+  double r1[H1], r2[H2];
 #pragma unroll
-  for (int a = 0; a < NACC; a++) {
-    double r = wave_sum(acc[a]);
-    if (lane == 0) sm[wv][a] = r;
+  for (int k = 0; k < H1; k++) r1[k] = swap_sum32(acc[k], acc[k + H1 < NACC ? k + H1 : k]);
+#pragma unroll
+  for (int k = 0; k < H2; k++) r2[k] = swap_sum16(r1[k], r1[k + H2 < H1 ? k + H2 : k]);
+  const int row = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < H2; k++) {
+    double x = r2[k];
+    x = row_shl_sum<8>(x);
+    x = row_shl_sum<4>(x);
+    x = row_shl_sum<2>(x);
+    x = row_shl_sum<1>(x);
+    // row 0: accumulator k; row 1: k + H2 (a register of the second half); rows 2, 3: the same + H1
+    const int reg = k + (row & 1) * H2;
+    const int a = reg + (row >> 1) * H1;
+    if ((lane & 15) == 0 && reg < H1 && a < NACC) sm[wv][a] = x;
   }
   __syncthreads();
   for (int a = threadIdx.x; a < NACC; a += kBlock) {
@@ -266,6 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   using V = typename VecT<VEC>::type;
   constexpr int NACC = 2 * MAXL + 2;
   static_assert(MAXL % W == 0, "the ring must divide the stored vectors of a tile");
+  NKA_STAMP0(ctl, 10);
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
@@ -288,6 +357,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
 #pragma unroll
     for (int j = 0; j < W; j++) ring[j] = ld<VEC>(wk[j] + e);
   }
+  NKA_STAMP0(ctl, 11);
   for (; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
     const int64_t tn = (t + G < ntile) ? t + G : t;     // the last iteration prefetches its own tile again
@@ -331,7 +401,9 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
       }
     }
   }
+  NKA_STAMP0(ctl, 12);
   block_reduce_store<NACC>(acc, partials, G);
+  NKA_STAMP0(ctl, 13);
 }
 
 // Final sums of one PA pass scattered into red[] (layout above).  One wavefront

@@ -31,6 +31,7 @@ def main():
     L = nka_amd.load()
     rng = np.random.default_rng(0)
     rows = []
+    pa_rows = []
     for t in range(m + 12):
         f = torch.from_numpy(rng.standard_normal(n)).cuda()
         acc.accel_update(f)
@@ -38,12 +39,15 @@ def main():
         L.nka_hip_get_stamps(acc._handle(), st.ctypes.data_as(C.POINTER(C.c_double)))
         if t >= m + 2:
             rows.append(np.diff(st[:10]))
+            pa_rows.append(np.diff(st[10:14]))
     d = np.median(np.array(rows), axis=0)
     tot = d.sum()
     print(f"k_solve_rows phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
     for nm, v in zip(NAMES, d):
         print(f"  {nm:<42s} {v:8.0f} cycles  {100 * v / tot:5.1f} %")
     print(f"  {'total inside the kernel':<42s} {tot:8.0f} cycles")
+    pa = np.median(np.array(pa_rows), axis=0)
+    print(f"k_dots_win block 0, n={n}: entry -> first loads issued {pa[0]:.0f}, tile loop {pa[1]:.0f}, block reduction + partial store {pa[2]:.0f} cycles")
 
 
 if __name__ == "__main__":
