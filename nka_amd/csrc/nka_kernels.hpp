@@ -339,10 +339,21 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int32_t *slots = ctl.plan_slots();
-  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
+  const int first = ctl.ic[IC_PLAN_FIRST];                 // (read whether pending or not: no branch around a load)
+  const double *w1p = vs.w + (size_t)(first - 1) * vs.stride;
+  const double *w1 = pending ? w1p : f;
+  // every plan slot is requested at once, whether the list reaches it or not (the plan array is longer than any
+  // width): written as `j < nolder ? slots[j] ...` each slot became a branch around its own s_load + s_waitcnt --
+  // twenty serial scalar round trips, 4.2 k cycles of prologue at m = 20 against 2 k at m = 5
+  int32_t sl[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; j++) sl[j] = slots[j];
   const double *wk[MAXL];
 #pragma unroll
-  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? vs.w + (size_t)(slots[j] - 1) * vs.stride : f;
+  for (int j = 0; j < MAXL; j++) {
+    const double *p = vs.w + (size_t)(sl[j] - 1) * vs.stride;
+    wk[j] = (j < nolder) ? p : f;
+  }
   double acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -417,6 +428,11 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
                                                                int pass, int ncover) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
+  // the column's partial sums are requested BEFORE the plan is known (whether the column is live only decides
+  // if its sum or a zero is stored): the two memory round trips overlap instead of following one another
+  double r = 0.0;
+  for (int b = lane; b < G; b += kFinThreads) r += partials[(size_t)c * G + b];
+  r = wave_sum(r);
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int base = pass * MAXL;
@@ -437,12 +453,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
     if (p < ctl.mvec) { dst = 2 + ctl.mvec + p; live = p < nolder; }
   }
   if (dst < 0) return;
-  double r = 0.0;
-  if (live) {
-    for (int b = lane; b < G; b += kFinThreads) r += partials[(size_t)c * G + b];
-    r = wave_sum(r);
-  }
-  if (lane == 0) ctl.red()[dst] = r;
+  if (lane == 0) ctl.red()[dst] = live ? r : 0.0;
 }
 
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------
@@ -659,13 +670,18 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 
   double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
+  int32_t sl[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; j++) {     // all slots and coefficients in one batch of scalar loads (see k_dots_win)
+    sl[j] = cs[j];
+    ck[j] = cc[j];
+  }
 #pragma unroll
   for (int j = 0; j < MAXK; j++) {
     const bool live = j < ncomb;
-    const size_t off = live ? (size_t)(cs[j] - 1) * vs.stride : 0;
+    const size_t off = (size_t)(sl[j] - 1) * vs.stride;
     wk[j] = live ? vs.w + off : f;
     vk[j] = live ? vs.v + off : f;
-    ck[j] = cc[j];
   }
   // compact storage reads w only for the pending pair that is normalised now
   const double *w0src = norm0 ? wk[0] : f;
