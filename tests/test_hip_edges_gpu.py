@@ -174,3 +174,19 @@ def test_distinct_objects_driven_from_concurrent_host_threads(torch_cuda, oracle
         run(k, alone)
         for t in range(calls):
             assert np.array_equal(outs[k][t], alone[k][t]), (k, t)
+
+
+def test_register_reductions_build_the_shuffle_butterfly_trees(torch_cuda):
+    """The reductions of every kernel (wave_sum, block_reduce_store: gfx950 v_permlane32_swap / v_permlane16_swap and
+    DPP row shifts, the butterflies of a block sharing their steps) must add the SAME pairs in the SAME order as one
+    __shfl_down butterfly per sum -- the documented fixed order of the inner products: tools/wave_sum_check compares
+    65 536 wavefront sums and the block sums for 1...66 accumulators per thread bit for bit on the device."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "wave_sum_check")
+    if not os.path.exists(exe):
+        pytest.skip("tools/wave_sum_check not built (python -c 'import __graft_entry__ as g; g.build()')")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 13 and all(" 0 of " in ln for ln in lines), p.stdout
