@@ -8,6 +8,8 @@
 #include <vector>
 #include "nka_kernels.hpp"
 
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
 __device__ __forceinline__ double wave_sum_shfl(double x) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -54,16 +56,19 @@ template <int NACC>
 int check_block(const std::vector<double> &h, double *din) {
   const int G = 64;
   double *pa, *pb;
-  hipMalloc(&pa, (size_t)NACC * G * 8); hipMalloc(&pb, (size_t)NACC * G * 8);
-  hipMemset(pa, 0xff, (size_t)NACC * G * 8); hipMemset(pb, 0, (size_t)NACC * G * 8);
+  CK(hipMalloc(&pa, (size_t)NACC * G * 8));
+  CK(hipMalloc(&pb, (size_t)NACC * G * 8));
+  CK(hipMemset(pa, 0xff, (size_t)NACC * G * 8));
+  CK(hipMemset(pb, 0, (size_t)NACC * G * 8));
   k_block<NACC><<<G, 256>>>(din, pa, pb);
   std::vector<double> ha((size_t)NACC * G), hb((size_t)NACC * G);
-  hipMemcpy(ha.data(), pa, ha.size() * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(hb.data(), pb, hb.size() * 8, hipMemcpyDeviceToHost);
+  CK(hipMemcpy(ha.data(), pa, ha.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), pb, hb.size() * 8, hipMemcpyDeviceToHost));
   int bad = 0;
   for (size_t i = 0; i < ha.size(); i++) bad += memcmp(&ha[i], &hb[i], 8) != 0;
   printf("block_reduce_store<%d>: %d of %zu block sums differ from the per-accumulator butterflies\n", NACC, bad, ha.size());
-  hipFree(pa); hipFree(pb);
+  CK(hipFree(pa));
+  CK(hipFree(pb));
   return bad;
 }
 
@@ -76,12 +81,14 @@ int main() {
     v = ((double)rand() / RAND_MAX - 0.5) * pow(2.0, e);
   }
   double *din, *da, *db;
-  hipMalloc(&din, h.size() * 8); hipMalloc(&da, nwaves * 8); hipMalloc(&db, nwaves * 8);
-  hipMemcpy(din, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+  CK(hipMalloc(&din, h.size() * 8));
+  CK(hipMalloc(&da, nwaves * 8));
+  CK(hipMalloc(&db, nwaves * 8));
+  CK(hipMemcpy(din, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   k_check<<<nwaves / 4, 256>>>(din, da, db, nwaves);
   std::vector<double> ha(nwaves), hb(nwaves);
-  hipMemcpy(ha.data(), da, nwaves * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(hb.data(), db, nwaves * 8, hipMemcpyDeviceToHost);
+  CK(hipMemcpy(ha.data(), da, nwaves * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), db, nwaves * 8, hipMemcpyDeviceToHost));
   int bad = 0;
   for (int i = 0; i < nwaves; i++) bad += memcmp(&ha[i], &hb[i], 8) != 0;
   printf("wave_sum: %d of %d wavefront sums differ from the __shfl_down butterfly\n", bad, nwaves);
