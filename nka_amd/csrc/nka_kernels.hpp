@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
       }
     }
   }
-  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+  if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fq = f[i];
       const double d = w1[i] - fq;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
       }
     }
   }
-  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+  if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fq = f[i];
       const double d = w1[i] - fq;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
     if (store_v) st(vnew + e, x);
     if (store_f) st(f + e, x);
   }
-  if (blockIdx.x == G - 1) {  // ragged tail, scalar
+  if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fin = f[i];
       double x = fin;
