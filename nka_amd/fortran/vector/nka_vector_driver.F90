@@ -32,12 +32,15 @@
 !!       with RCCL 1, the built-in RCCL hook on a one-rank communicator in front of
 !!       it (the device-side path).  Written per call: the global input, num_vec, the
 !!       digest of this rank's replicated scalar state, this rank's slices of the result.
-!!   nka_vector_driver script NFIELD NPER MVEC NOPS OUTFILE COMPACT SCRIPTFILE
+!!   nka_vector_driver script NFIELD NPER MVEC NOPS OUTFILE COMPACT SCRIPTFILE [RANK WORLD SHMFILE]
 !!       replays NOPS operations from SCRIPTFILE (stream of real64: an operation code, then
 !!       its payload -- 0 accel_update + the NFIELD*NPER input values, 1 relax, 2 restart,
 !!       3 set_vec_tol + the tolerance) on a hip_block_vector and writes, per operation,
 !!       num_vec and, after an update, the returned vector: random call sequences generated
-!!       and checked against the oracle by tools/fuzz_gpu.py --vector.
+!!       and checked against the oracle by tools/fuzz_gpu.py --vector.  With RANK WORLD SHMFILE the replay is
+!!       SHARDED like `shard`: this rank holds the slice [lo, hi) of each field (the script carries the GLOBAL
+!!       inputs), the workspace reduces through the host all-reduce of tests/c/shm_allreduce.c; written first:
+!!       lo, hi; per update: this rank's slices of the result (tools/fuzz_gpu.py --vector-sharded).
 !!   nka_vector_driver bench NFIELD NPER MVEC STEPS [COMPACT 0|1]
 !!       BASELINE config 5 (4 x 1e7, mvec 20): steady-state updates/s of the
 !!       hook-by-hook path, with the bytes it moves, 8n(12+8m) (SURVEY.md 8d).
@@ -95,6 +98,11 @@ program nka_vector_driver
     call get_command_argument(6, outfile)
     call get_command_argument(7, arg); read(arg,*) icompact
     call get_command_argument(8, scriptfile)
+    if (command_argument_count() >= 11) then
+      call get_command_argument(9, arg); read(arg,*) rank
+      call get_command_argument(10, arg); read(arg,*) world
+      call get_command_argument(11, shmfile)
+    end if
     compact = icompact /= 0
     call run_script
   case ('shard')
@@ -187,32 +195,42 @@ contains
   subroutine run_script
     type(hip_block_vector) :: f
     type(nka) :: accel
-    type(c_ptr) :: ws
-    real(r8), allocatable :: host(:)
+    type(c_ptr) :: ws, shm
+    real(r8), allocatable :: host(:), loc(:)
     real(r8) :: code, vtol
     integer :: t, k, lun, lin
-    integer(i8) :: n
+    integer(i8) :: n, lo, hi, nloc
     n = nfield * nper
+    lo = 0
+    hi = nper
     ws = hip_block_vector_workspace(0)
-    call f%init(nfield, nper, ws)
+    if (world > 1) then
+      call slice_bounds(nper, rank, lo, hi)
+      shm = shm_ar_open(trim(shmfile)//c_null_char, int(world, c_int), int(rank, c_int))
+      if (.not. c_associated(shm)) error stop 'script: cannot map the all-reduce file'
+      call hip_block_vector_set_host_allreduce(ws, c_funloc(shm_allreduce), shm)
+    end if
+    nloc = hi - lo
+    call f%init(nfield, nloc, ws)
     call accel%init(f, mvec, compact=compact)
-    allocate(host(n))
+    allocate(host(n), loc(nfield*nloc))
     open(newunit=lin, file=trim(scriptfile), access='stream', form='unformatted', status='old', action='read')
     open(newunit=lun, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    if (world > 1) write(lun) lo, hi
     do t = 1, ncalls
       read(lin) code
       select case (nint(code))
       case (0)
         read(lin) host
         do k = 1, nfield
-          call f%set_field(k, host((k-1)*nper+1:k*nper))
+          call f%set_field(k, host((k-1)*nper+lo+1:(k-1)*nper+hi))
         end do
         call accel%accel_update(f)
         do k = 1, nfield
-          call f%get_field(k, host((k-1)*nper+1:k*nper))
+          call f%get_field(k, loc((k-1)*nloc+1:k*nloc))
         end do
         write(lun) real(accel%num_vec(), r8)
-        write(lun) host
+        write(lun) loc
       case (1)
         call accel%relax
         write(lun) real(accel%num_vec(), r8)

@@ -19,6 +19,9 @@ must agree BIT FOR BIT and the two sides must have made the same number of dp ca
 included -- with the all-reduce hook staged through gloo; unsharded oracle on every rank; after every call the
 replicated state digests of all ranks must be equal.  Per-rank logs <out>.rank<r>.
 
+--vector-sharded WORLD: the --vector sequences replayed by WORLD processes sharing the GPU, each holding a contiguous slice
+of every field (nka_vector_driver script ... RANK WORLD SHMFILE; reductions through the workspace's host all-reduce hook).
+
 --vector: the same kind of sequence through the ABSTRACT-VECTOR flavour -- the Fortran accelerator of
 nka_amd/fortran/vector on a device block vector (`nka_vector_driver script`), with the norm stage fused or not
 (NKA_HIP_VEC_FUSE_NORM), the normalisation deferred or not (NKA_HIP_VEC_DEFER_SCALE), compact storage or not, lists
@@ -116,9 +119,9 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
     return key
 
 
-def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
+def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1):
     import subprocess
-    rng = np.random.default_rng(10_000 + seed)
+    rng = np.random.default_rng(10_000 + seed + (1_000_000 if world > 1 else 0))
     nfield = int(rng.integers(1, 5))
     nper = int(rng.choice([1, 2, 3, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1025, 2049, 4097, 9973])) \
         if rng.random() < 0.8 else int(rng.integers(1, 12000))
@@ -127,7 +130,8 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
     compact, fuse, defer = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
     if fuse:
         defer = 1                                           # fusing needs the deferral
-    key = f"fuzz vector seed {seed} {nfield}x{nper} m={m} compact={compact} fuse={fuse} defer={defer}"
+    key = f"fuzz vector seed {seed} {nfield}x{nper} m={m} compact={compact} fuse={fuse} defer={defer}" + \
+          (f" world {world}" if world > 1 else "")
     basis = rng.standard_normal((3, n))
     prev = rng.standard_normal(n)
     ops, script = [], []
@@ -153,21 +157,51 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
         else:
             vt = float(10.0 ** rng.uniform(-3, -0.3))
             ops.append((3, vt)); script.append(np.array([3.0, vt]))
-    sfile, ofile = os.path.join(tmpdir, "script.bin"), os.path.join(tmpdir, "out.bin")
+    sfile = os.path.join(tmpdir, "script.bin")
     np.concatenate(script).tofile(sfile)
     exe = os.path.join(ROOT, "nka_amd", "fortran", "build", "nka_vector_driver")
-    p = subprocess.run([exe, "script", str(nfield), str(nper), str(m), str(steps), ofile, str(compact), sfile],
-                       capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, NKA_HIP_VEC_FUSE_NORM=str(fuse), NKA_HIP_VEC_DEFER_SCALE=str(defer)))
-    assert p.returncode == 0, (key, p.stdout[-400:], p.stderr[-400:])
-    raw = np.fromfile(ofile, dtype=np.float64)
+    env = dict(os.environ, NKA_HIP_VEC_FUSE_NORM=str(fuse), NKA_HIP_VEC_DEFER_SCALE=str(defer))
+    ofiles = [os.path.join(tmpdir, f"out{r}.bin") for r in range(world)]
+    cmds = [[exe, "script", str(nfield), str(nper), str(m), str(steps), ofiles[r], str(compact), sfile] for r in range(world)]
+    if world > 1:                                           # ranks sharing the GPU, host all-reduce through a mapped file
+        shm = os.path.join(tmpdir, "allreduce.shm")
+        with open(shm, "wb") as fh:
+            fh.write(bytes(4096 + 8 * 64 * world))
+        cmds = [c + [str(r), str(world), shm] for r, c in enumerate(cmds)]
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for c in cmds]
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for pr, o in zip(procs, outs):
+        assert pr.returncode == 0, (key, o[-600:])
+    raws, bounds, poss = [], [], []
+    for r in range(world):
+        raw = np.fromfile(ofiles[r], dtype=np.float64)
+        if world > 1:
+            lo, hi = (int(x) for x in raw[:2].view(np.int64))
+            raw = raw[2:]
+        else:
+            lo, hi = 0, nper
+        raws.append(raw); bounds.append((lo, hi)); poss.append(0)
     ora = oracle.OracleNKA(n, m, oracle.F08_VECTOR)
     spread = P.Spread(oracle, n, m)
-    pos = 0
     for step, (code, arg) in enumerate(ops):
-        nv = int(raw[pos]); pos += 1
+        nvs = set()
+        for r in range(world):
+            nvs.add(int(raws[r][poss[r]])); poss[r] += 1
         if code == 0:
-            got = raw[pos:pos + n]; pos += n
+            got = np.empty(n)
+            for r in range(world):
+                lo, hi = bounds[r]
+                nl = hi - lo
+                loc = raws[r][poss[r]:poss[r] + nfield * nl].reshape(nfield, nl); poss[r] += nfield * nl
+                for k in range(nfield):
+                    got[k * nper + lo:k * nper + hi] = loc[k]
             f = arg.copy()
             ora.accel_update(f)
             spread.update(arg)
@@ -181,8 +215,8 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100):
             ora.restart(); spread.restart()
         else:
             ora.set_vec_tol(arg); spread.set_vec_tol(arg)
-        assert nv == ora.num_vec(), (key, step, nv, ora.num_vec())
-    assert pos == raw.size, key
+        assert nvs == {ora.num_vec()}, (key, step, nvs, ora.num_vec())
+    assert all(poss[r] == raws[r].size for r in range(world)), key
     return key
 
 
@@ -308,6 +342,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
     ap.add_argument("--vector", action="store_true")
     ap.add_argument("--hostdot", action="store_true")
+    ap.add_argument("--vector-sharded", type=int, default=0, metavar="WORLD",
+                    help="the --vector sequences on WORLD ranks sharing the GPU (slices of every field, host all-reduce hook)")
     ap.add_argument("--sharded", type=int, default=0, metavar="WORLD", help="WORLD ranks sharing cuda:0, gloo-staged hook")
     ap.add_argument("--sharded-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -338,9 +374,9 @@ def main():
     with open(args.out, "w") as out:
         while time.time() - t0 < args.seconds:
             try:
-                if args.vector:
+                if args.vector or args.vector_sharded:
                     with tempfile.TemporaryDirectory() as tmpdir:
-                        key = one_seed_vector(seed, oracle, P, S, tmpdir)
+                        key = one_seed_vector(seed, oracle, P, S, tmpdir, world=max(1, args.vector_sharded))
                 else:
                     key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot)
                 rec = P.WORST.get(key, {})
