@@ -86,7 +86,9 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
  * valid as long as the unroll widths chosen then cover the list, which is
  * guaranteed once nka_hip_capture_safe() returns 1: a pair is pending and the
  * host-side bound on the list length has reached mvec+1 (from the mvec+1-th
- * update after init/restart on).  restart()/relax() end that state. */
+ * update after init/restart on).  restart()/relax() end that state.  Never 1 in the
+ * debug mode (NKA_HIP_DEBUG=1 reads the state back after every update) or with a user
+ * dot product installed (nka_hip_set_host_dot: it runs on the host). */
 int nka_hip_capture_safe(nka_hip_t a);
 
 /* Rebind the handle to another hipStream_t (NULL = default stream).  Work already

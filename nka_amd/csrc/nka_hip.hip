@@ -545,7 +545,8 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
 
 int nka_hip_capture_safe(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
-  return (a->pending && a->list_ub >= a->mvec + 1) ? 1 : 0;
+  // (the debug mode reads the state back after every update and a user dot product runs on the host: neither can be captured)
+  return (a->pending && a->list_ub >= a->mvec + 1 && !a->debug && !a->host_dot) ? 1 : 0;
 }
 
 int nka_hip_set_stream(nka_hip_t a, void *stream) {

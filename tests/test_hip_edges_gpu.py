@@ -190,3 +190,29 @@ def test_register_reductions_build_the_shuffle_butterfly_trees(torch_cuda):
     assert p.returncode == 0, p.stdout + p.stderr
     lines = p.stdout.strip().splitlines()
     assert len(lines) == 13 and all(" 0 of " in ln for ln in lines), p.stdout
+
+
+def test_capture_safe_is_never_true_where_an_update_touches_the_host(torch_cuda, oracle, monkeypatch):
+    """nka_hip_capture_safe: a steady-state update is capturable into a hipGraph -- but not in the debug mode (state read
+    back after every update) and not with a user dot product installed (it runs on the host)."""
+    import nka_amd
+    rng = np.random.default_rng(3)
+    n, m = 1000, 3
+
+    def fill(acc):
+        for _ in range(m + 3):
+            acc.accel_update(torch_cuda.from_numpy(rng.standard_normal(n)).cuda())
+
+    plain = nka_amd.nka().init(n, m)
+    fill(plain)
+    assert plain.capture_safe()
+    hd = nka_amd.nka().init(n, m)
+    hd.set_host_dot(lambda x, y: float(np.dot(x, y)))
+    fill(hd)
+    assert not hd.capture_safe()
+    hd.set_host_dot(None)
+    assert hd.capture_safe()
+    monkeypatch.setenv("NKA_HIP_DEBUG", "1")
+    dbg = nka_amd.nka().init(n, m)
+    fill(dbg)
+    assert not dbg.capture_safe()
