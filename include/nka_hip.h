@@ -87,8 +87,10 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
  * guaranteed once nka_hip_capture_safe() returns 1: a pair is pending and the
  * host-side bound on the list length has reached mvec+1 (from the mvec+1-th
  * update after init/restart on).  restart()/relax() end that state.  Never 1 in the
- * debug mode (NKA_HIP_DEBUG=1 reads the state back after every update) or with a user
- * dot product installed (nka_hip_set_host_dot: it runs on the host). */
+ * debug mode (NKA_HIP_DEBUG=1 reads the state back after every update), with a user dot
+ * product (nka_hip_set_host_dot: it runs on the host) or with a caller's all-reduce hook
+ * (nka_hip_set_allreduce: a host callback a replay would not call again; the built-in
+ * RCCL hook only enqueues on the stream and can be captured). */
 int nka_hip_capture_safe(nka_hip_t a);
 
 /* Rebind the handle to another hipStream_t (NULL = default stream).  Work already

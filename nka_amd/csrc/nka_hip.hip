@@ -545,8 +545,11 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
 
 int nka_hip_capture_safe(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
-  // (the debug mode reads the state back after every update and a user dot product runs on the host: neither can be captured)
-  return (a->pending && a->list_ub >= a->mvec + 1 && !a->debug && !a->host_dot) ? 1 : 0;
+  // (the debug mode reads the state back after every update, a user dot product runs on the host, and a caller's all-reduce
+  //  hook is a host callback that a replay would not call again: none of them can be captured; the built-in RCCL hook only
+  //  enqueues on the stream)
+  const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce;
+  return (a->pending && a->list_ub >= a->mvec + 1 && !a->debug && !a->host_dot && !user_hook) ? 1 : 0;
 }
 
 int nka_hip_set_stream(nka_hip_t a, void *stream) {

@@ -212,6 +212,10 @@ def test_capture_safe_is_never_true_where_an_update_touches_the_host(torch_cuda,
     assert not hd.capture_safe()
     hd.set_host_dot(None)
     assert hd.capture_safe()
+    hd.set_dot_prod(lambda ptr, count, stream: None)          # a caller's all-reduce hook: a host callback
+    assert not hd.capture_safe()
+    hd.set_dot_prod(None)
+    assert hd.capture_safe()
     monkeypatch.setenv("NKA_HIP_DEBUG", "1")
     dbg = nka_amd.nka().init(n, m)
     fill(dbg)
