@@ -97,51 +97,76 @@ def attach_rccl(acc, rank: int, world_size: int, group=None):
     return acc
 
 
-def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", group=None) -> str:
+def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", group=None, data_group=None,
+                     ladder=("rccl", "torch", "staged")) -> str:
     """Install the per-update all-reduce on `acc` and PROVE it before first use.
-    `prefer` = "rccl": the library's own communicator on the accelerator's stream
-    (lowest latency); if creating it or the test all-reduce fails on ANY rank,
-    every rank drops it and installs the torch.distributed hook instead -- the
-    decision is collective, so ranks can never disagree about who reduces with
-    whom.  The order matters: ncclCommInitRank is a BLOCKING rendezvous, so what a
-    rank can fail on before reaching it (binding RCCL, selecting its device) is
-    checked locally and agreed on first (rccl_preflight + all_agree) -- an
-    asymmetric early failure then moves every rank to the torch hook instead of
-    leaving the healthy ones waiting in the rendezvous.  Returns the hook in use
-    ("rccl" or "torch").  Raises if the torch hook fails its test as well."""
+    Ladder, entered at `prefer`: "rccl" = the library's own communicator on the
+    accelerator's stream (lowest latency); "torch" = torch.distributed's all-reduce
+    on `data_group` (a callable is called -- collectively -- to create it, e.g.
+    lambda: dist.new_group(backend="nccl")); "staged" = the 336 bytes staged through
+    the host over `group` (any backend; slow but needs no RCCL at all).  A step that
+    cannot be set up or fails its test all-reduce on ANY rank is dropped by EVERY
+    rank and the next one is tried: every decision is a collective MIN over `group`
+    (all_agree), so ranks can never disagree about who reduces with whom.  Keep
+    `group` on gloo when the data path may be the thing that is broken (bench.py
+    does).  The order inside the first step matters: ncclCommInitRank is a BLOCKING
+    rendezvous, so what a rank can fail on before reaching it (binding RCCL,
+    selecting its device) is checked locally and agreed on first (rccl_preflight) --
+    an asymmetric early failure then moves every rank down the ladder instead of
+    leaving the healthy ones waiting in the rendezvous.  Returns the hook in use.
+    Raises when the last step of the ladder fails as well."""
     import sys
-    hook = prefer
-    if hook == "rccl":
-        ok = all_agree(rccl_preflight(acc), group, acc._device)
+    steps = list(ladder)
+    if prefer not in steps:
+        raise ValueError(f"unknown all-reduce hook {prefer!r}")
+    steps = steps[steps.index(prefer):]
+    dev = acc._device
+
+    def say(msg):
+        if rank == 0:
+            print(f"[nka_amd.dist] {msg}", file=sys.stderr, flush=True)
+
+    for i, hook in enumerate(steps):
+        ok = True
+        try:
+            if hook == "rccl":
+                ok = all_agree(rccl_preflight(acc), group, dev)
+                if not ok:
+                    say("RCCL pre-flight failed on at least one rank")
+                else:
+                    try:
+                        attach_rccl(acc, rank, world_size, group)
+                    except Exception as exc:      # noqa: BLE001
+                        print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr, flush=True)
+                        ok = False
+                    ok = all_agree(ok, group, dev)
+            elif hook == "torch":
+                dg = data_group
+                try:
+                    if callable(dg):
+                        dg = dg()
+                    attach_torch_allreduce(acc, dg)
+                except Exception as exc:          # noqa: BLE001
+                    print(f"[nka_amd.dist] rank {rank}: torch.distributed data group failed: {exc!r}", file=sys.stderr, flush=True)
+                    ok = False
+                ok = all_agree(ok, group, dev)
+            else:
+                attach_staged_allreduce(acc, group)
+            if ok:
+                ok = all_agree(check_allreduce(acc, rank, world_size), group, dev)
+        except Exception as exc:                  # noqa: BLE001 -- e.g. the control group itself failed: nothing left to agree with
+            raise RuntimeError(f"all-reduce hook '{hook}': the collective decision failed: {exc!r}") from exc
         if ok:
-            try:
-                attach_rccl(acc, rank, world_size, group)
-            except Exception as exc:      # noqa: BLE001
-                print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr)
-                ok = False
-            ok = all_agree(ok, group, acc._device)
-        elif rank == 0:
-            print("[nka_amd.dist] RCCL pre-flight failed on at least one rank", file=sys.stderr)
-        if ok:
-            ok = all_agree(check_allreduce(acc, rank, world_size), group, acc._device)
-        if not ok:
-            if rank == 0:
-                print("[nka_amd.dist] RCCL hook unusable on at least one rank; every rank switches to the "
-                      "torch.distributed hook", file=sys.stderr)
-            try:
+            return hook
+        try:
+            if hook == "rccl":
                 acc.drop_rccl()
-            except Exception:         # noqa: BLE001
-                pass
-            hook = "torch"
-    if hook == "torch":
-        attach_torch_allreduce(acc, group)
-        if not all_agree(check_allreduce(acc, rank, world_size), group, acc._device):
-            raise RuntimeError("the torch.distributed all-reduce hook failed its self-test")
-    if hook == "staged":                        # rehearsal only (attach_staged_allreduce)
-        attach_staged_allreduce(acc, group)
-        if not all_agree(check_allreduce(acc, rank, world_size), group, acc._device):
-            raise RuntimeError("the host-staged all-reduce hook failed its self-test")
-    return hook
+            acc.set_dot_prod(None)
+        except Exception:                         # noqa: BLE001
+            pass
+        if i + 1 < len(steps):
+            say(f"the '{hook}' all-reduce hook is unusable on at least one rank; every rank switches to '{steps[i + 1]}'")
+    raise RuntimeError(f"the '{steps[-1]}' all-reduce hook failed its self-test (no hook left)")
 
 
 def attach_torch_allreduce(acc, group=None):

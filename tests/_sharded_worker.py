@@ -67,6 +67,32 @@ def main():
         fake = FakeAcc()
         assert nd.attach_allreduce(fake, rank, world, prefer="rccl") == "torch"
         assert "torch" in fake.log
+        # the whole ladder: the torch hook cannot be set up on ONE rank either (e.g. its nccl group fails there) ->
+        # every rank ends on the host-staged hook; a self-test that fails on one rank moves everybody as well
+        saved_staged = nd.attach_staged_allreduce
+
+        def torch_hook_broken_on_rank0(acc, group=None):
+            if rank == 0:
+                raise OSError("no nccl group here")
+            acc.log.append("torch")
+        nd.attach_torch_allreduce = torch_hook_broken_on_rank0
+        nd.attach_staged_allreduce = lambda acc, group=None: acc.log.append("staged")
+        fake = FakeAcc()
+        assert nd.attach_allreduce(fake, rank, world, prefer="rccl") == "staged"
+        assert fake.log[-1] == "staged"
+        made = []
+        nd.attach_torch_allreduce = lambda acc, group=None: acc.log.append(("torch", group))
+        nd.check_allreduce = lambda acc, r, w: not (acc.log and acc.log[-1] == ("torch", "DG") and r == world - 1)
+        fake = FakeAcc()
+        assert nd.attach_allreduce(fake, rank, world, prefer="torch", data_group=lambda: made.append(1) or "DG") == "staged"
+        assert made == [1] and ("torch", "DG") in fake.log        # the data group is created on demand, once
+        # a ladder that ends before it works raises on EVERY rank
+        try:
+            nd.attach_allreduce(FakeAcc(), rank, world, prefer="torch", data_group="DG", ladder=("rccl", "torch"))
+            raise AssertionError("expected a RuntimeError")
+        except RuntimeError as exc:
+            assert "no hook left" in str(exc)
+        nd.attach_staged_allreduce = saved_staged
     finally:
         nd.rccl_preflight, nd.check_allreduce, nd.attach_torch_allreduce = saved
 

@@ -64,3 +64,56 @@ def test_committed_pmc_traffic_agrees_with_the_byte_model(bench):
         for key, name in (("k_dots", "PA_k_dots"), ("k_combine", "PB_k_combine")):
             k = pm["kernels"][key]
             assert (k["read_bytes"] + k["write_bytes"]) == pytest.approx(8.0 * n * w[name], rel=2e-3), (src, key)
+
+
+# ---- the plain launch form: `python bench.py --gpus N` supervises a child rank group (VERDICT r3 task 1) ----------
+FAKE = os.path.join(ROOT, "tests", "_fake_rank_script.py")
+
+
+def _launch(bench, capsys, extra, timeout=60, fallback=True):
+    argv = ["--gpus", "2"] + extra
+    args = bench.parse(["--gpus", "2", "--launch-timeout", str(timeout)] + ([] if fallback else ["--no-fallback"]))
+    rc = bench.launch_ranks(args, argv, script=FAKE)
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    return rc, lines
+
+
+def test_plain_form_relays_rank_zeros_line_and_exit_code(bench, capsys):
+    import json
+    rc, lines = _launch(bench, capsys, ["--mode", "ok"])
+    assert rc == 0 and len(lines) == 1                     # ONE line, the chatter is not relayed to stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "launch" not in d
+
+
+def test_plain_form_second_attempt_names_the_fallback_hook(bench, capsys):
+    import json
+    rc, lines = _launch(bench, capsys, ["--mode", "fail-unless-staged"])
+    assert rc == 0 and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["parallelism"] == "all-reduce=staged" and d["config"]["backend"] == "gloo"
+    assert "exit code" in d["launch"]["first_attempt"] and "ncclCommInitRank" in d["launch"]["last_stderr_line"]
+    # without the fallback the failure is the result: no line, the child's code
+    rc, lines = _launch(bench, capsys, ["--mode", "fail-unless-staged"], fallback=False)
+    assert rc != 0 and lines == []
+    # a failure a retry cannot cure (too few GPUs) is not retried
+    rc, lines = _launch(bench, capsys, ["--mode", "noretry"])
+    assert rc != 0 and lines == []
+
+
+def test_plain_form_watchdog_kills_the_whole_rank_group(bench, capsys, tmp_path):
+    import json
+    import time
+    pidfile = str(tmp_path / "pid")
+    t0 = time.time()
+    rc, lines = _launch(bench, capsys, ["--mode", "hang", "--pidfile", pidfile], timeout=8, fallback=False)
+    assert rc == 124 and lines == [] and time.time() - t0 < 60
+    pids = [int(open(f"{pidfile}.{r}").read()) for r in range(2)]
+    time.sleep(0.5)
+    for pid in pids:                                        # the RANKS are gone, not just torchrun
+        alive = os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[1].split()[0]
+        assert not alive, pid
+    # a hang in the first attempt, a result from the second
+    rc, lines = _launch(bench, capsys, ["--mode", "hang-unless-staged"], timeout=8)
+    assert rc == 0 and json.loads(lines[0])["launch"]["first_attempt"].startswith("watchdog expired")
