@@ -87,7 +87,9 @@ def parse(argv=None):
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the abstract-vector (BASELINE configs[4]) extra")
-    ap.add_argument("--cpu-n", type=float, default=2e7, help="vector length of the CPU sample")
+    ap.add_argument("--cpu-n", type=float, default=None,
+                    help="vector length of the CPU baseline; default: the benchmark's own n when the host has >= 48 GB "
+                         "available (BASELINE.md section 4), else 2e7")
     ap.add_argument("--flavor", choices=["default", "c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "default"),
                     help="'default' = what `call a%%init(vlen, mvec)` of the drop-in Fortran module runs (compact storage "
                          "unless NKA_HIP_FLAVOR says otherwise); or name the reference rounding mirrored")
@@ -95,6 +97,12 @@ def parse(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NKA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend.  gloo (+ --allreduce staged, NKA_BENCH_SHARE_GPU=1) is a REHEARSAL of the "
                          "multi-rank logic with all ranks on one GPU (RCCL refuses that); its numbers mean nothing")
+    ap.add_argument("--workload", choices=["full", "drops"], default="full",
+                    help="full: independent inputs, subspace full (L = k = mvec), the BASELINE workload.  drops: every "
+                         "input lies in a --drop-dim dimensional span, so every update takes a dependence drop "
+                         "(F08:326-345) and the subspace holds k = drop-dim < mvec vectors; the caller synchronises "
+                         "after every update, like a solver that reads its residual norm")
+    ap.add_argument("--drop-dim", type=int, default=12)
     ap.add_argument("--launch-timeout", type=int, default=int(os.environ.get("NKA_BENCH_LAUNCH_TIMEOUT_S", "280")),
                     help="plain form, N > 1: seconds the parent waits for the ranks before it kills their process group")
     ap.add_argument("--no-fallback", action="store_true",
@@ -102,14 +110,28 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def cpu_baseline(mvec: int, n: int, timed: int = 6):
+def host_mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(mvec: int, n: int, timed: int = 6, gen=None, note: str = ""):
     """Time the reference's own accel_update (compiled from /root/reference into
     oracle/_ref, if it travelled with the repo) or else the oracle port, serial,
-    on a bounded sample of the same workload: same generator, same mvec, steady
-    state, smaller n (cost is linear in n)."""
+    on the same workload: same generator (gen(t) -> the t-th input as a host array;
+    default: the numpy twin of the device generator), same mvec, steady state."""
     import numpy as np
     from nka_amd import synth
     from oracle import oracle_py as O
+    if gen is None:
+        def gen(t):
+            return synth.fill_numpy(SEED, t, 0, n, n)
     kind = "port"
     acc = None
     if O.have_ref():
@@ -121,13 +143,16 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6):
     if acc is None:
         acc = O.OracleNKA(n, mvec)
     t_all = time.perf_counter()
+    t_cpu = 0.0
     for t in range(mvec + 2):
-        f = synth.fill_numpy(SEED, t, 0, n, n)
+        f = gen(t)
+        t0 = time.perf_counter()
         acc.accel_update(f)
+        t_cpu += time.perf_counter() - t0
     assert acc.num_vec() == mvec
     dt = []
     for t in range(mvec + 2, mvec + 2 + timed):
-        f = synth.fill_numpy(SEED, t, 0, n, n)
+        f = gen(t)
         t0 = time.perf_counter()
         acc.accel_update(f)
         dt.append(time.perf_counter() - t0)
@@ -135,8 +160,9 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6):
     return {
         "value": 1.0 / per, "unit": "updates/s", "cores": 1, "kind": kind,
         "sample": f"n={n:d}, mvec={mvec}, {timed} steady-state updates after {mvec + 2} fill calls "
-                  f"({time.perf_counter() - t_all:.1f} s of CPU work); serial like the reference",
-        "n": n, "s_per_update": per,
+                  f"({t_cpu + sum(dt):.1f} s of CPU work in accel_update, {time.perf_counter() - t_all:.1f} s with the "
+                  f"inputs); serial like the reference" + note,
+        "n": n, "s_per_update": per, "host_mem_available_gb": host_mem_available_gb(),
         "algorithmic_GBps": 8.0 * n * (11 + 3 * mvec) / per / 1e9,
     }
 
@@ -240,7 +266,7 @@ def pmc_traffic(flavor: str, n_local: int, m: int):
     return None, None
 
 
-def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170):
+def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170, extra_args=()):
     """HBM bytes per launch measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE: separate
     passes with --kernel-trace only, units and the gfx950 FETCH_SIZE x 2 correction as MI355X_MICROARCH.md prescribes,
     tools/pmc_summary.py) over a short CHILD process of this very script -- same box, same build, same workload, a few
@@ -262,7 +288,7 @@ def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170):
         for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, sub), "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--flavor", flavor, "--steps", "4",
-                   "--vlen", str(n_local), "--mvec", str(m)]
+                   "--vlen", str(n_local), "--mvec", str(m)] + list(extra_args)
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             if p.returncode != 0:
                 return None
@@ -287,7 +313,7 @@ def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170):
         return None
 
 
-def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None):
+def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None, L=None, k=None):
     """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
     PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
     PMC counters) / mean launch duration (HIP events on the kernel stream during
@@ -297,14 +323,15 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
     schedule that moves MORE bytes than this one; its ratio to the bytes moved
     is `contract_bytes_ratio`, and `contract_GBps` = B_alg / time is a rate of
     useful work, not a bandwidth (it may exceed the peak and is never `frac`)."""
-    L = k = m
+    L = m if L is None else L          # stored vectors PA reads / pairs PB combines: mvec with the subspace full,
+    k = m if k is None else k          # fewer after dependence drops (--workload drops)
     words = words_moved(flavor, L, k)
     ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}
     if pm_live:
         pm, pm_src = pm_live, ("same run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child process of "
                                "this script after the timed region; FETCH_SIZE x 2 on gfx950")
     else:
-        pm, pm_src = pmc_traffic(flavor, n_local, m)
+        pm, pm_src = pmc_traffic(flavor, n_local, m) if (L, k) == (m, m) else (None, None)
     pmk = {"PA_k_dots": "k_dots", "PB_k_combine": "k_combine"}
     kernels = {}
     for name, w in words.items():
@@ -323,7 +350,7 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
     upd_s = mean[3] * 1e-3
     moved = 8.0 * n_local * sum(words.values())
     b_alg = 8.0 * n_local * (11 + L + 2 * k)
-    return {
+    out = {
         "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
         "kernel": dom, "achieved": kernels[dom]["achieved"], "frac": kernels[dom]["frac"],
         "traffic": kernels[dom]["traffic"], "traffic_source": pm_src,
@@ -335,12 +362,19 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
                          "traffic": pm["hbm_bytes_per_update"] if pm else None,
                          "what": "PA + scalar step + PB, first kernel start .. last kernel end"},
         "kernels": kernels,
+        "bytes_moved_per_update": moved,
         "contract_bytes_per_update": b_alg,
         "contract_bytes_ratio": b_alg / moved,
-        "contract_GBps": (b_alg / upd_s / 1e9) if upd_s > 0 else None,
         "probe_ceiling": probe,
         "device_time_stats_ms": stats,
     }
+    if flavor != "c":
+        # SURVEY 8(d)'s B_alg is a lower bound on the traffic only for the flavours that stream BOTH stored vectors of
+        # a pair (ratio 1.04): there B_alg / time is the BASELINE.md-style fraction.  Compact storage moves FEWER bytes
+        # than B_alg (ratio 1.45), so no contract rate is printed for it: it would read as > 100 % of the peak.
+        out["contract_GBps"] = (b_alg / upd_s / 1e9) if upd_s > 0 else None
+        out["contract_frac_of_peak"] = (b_alg / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None
+    return out
 
 
 NO_RETRY_MARK = "NKA_BENCH_NO_RETRY"      # a rank prints this on stderr when a second attempt could not help
@@ -567,8 +601,22 @@ def main(argv=None):
     pool = [pool_store[j, :n_local] for j in range(P)]
     refill_in_timed_region = (W_all + K) > P
 
-    def fill(j, t):
-        synth.fill_torch(pool[j], SEED, t, lo, n_global)
+    basis_box = [None]
+
+    def fill(j, t, workload="full"):
+        if workload == "full":
+            synth.fill_torch(pool[j], SEED, t, lo, n_global)
+            return
+        # drops: f_t = sum_j c_tj B_j with D fixed random vectors B_j (this rank's slices of them): every difference of
+        # two inputs lies in span(B), so the subspace can hold D vectors and every further update drops one as dependent
+        D = args.drop_dim
+        if basis_box[0] is None:
+            B = torch.empty((D, max(n_pad, 2)), dtype=torch.float64, device=dev)
+            for q in range(D):
+                synth.fill_torch(B[q, :n_local], SEED + 777, q, lo, n_global)
+            basis_box[0] = B
+        coef = torch.from_numpy(synth.fill_numpy(SEED + 60, t, 0, D, D)).to(dev)
+        torch.mv(basis_box[0][:, :n_local].t(), coef, out=pool[j])
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -578,16 +626,22 @@ def main(argv=None):
 
     ev_stride = 1 if n_local >= 50_000_000 else 4
 
-    def measure(acc):
+    def measure(acc, workload="full"):
         """W_all untimed calls (priming + warm-up), then EXACTLY K timed updates
         bracketed by barrier + synchronize; returns wall time (max over ranks),
-        mean per-phase device times (HIP events on the kernel stream), num_vec."""
+        mean per-phase device times (HIP events on the kernel stream), num_vec.
+        workload "drops": inputs confined to a low-dimensional span and ONE device
+        synchronisation per update, inside the timed region, where a solver reads its
+        residual norm -- that is what lets the host see the list word (nka_hip_list_bound)."""
+        sync_each = workload == "drops"
         for t in range(min(P, W_all + K)):     # inputs (re)generated outside the timed region
-            fill(t, t)
+            fill(t, t, workload)
         for t in range(W_all):
             if t >= P:
-                fill(t % P, t)
+                fill(t % P, t, workload)
             acc.accel_update(pool[t % P])
+            if sync_each:
+                torch.cuda.synchronize(dev)
         sync_all()
         nv0 = acc.num_vec()
         checks = [check_replicas(acc, "after warm-up")] if world > 1 or hook_box[0] != "none" else []
@@ -601,8 +655,10 @@ def main(argv=None):
         for s in range(K):
             t = W_all + s
             if t >= P:
-                fill(t % P, t)       # only when HBM cannot hold W+K inputs (reported below)
+                fill(t % P, t, workload)       # only when HBM cannot hold W+K inputs (reported below)
             acc.accel_update(pool[t % P])
+            if sync_each:
+                torch.cuda.synchronize(dev)
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -623,8 +679,9 @@ def main(argv=None):
             checks.append(check_replicas(acc, "after the timed steps"))
         return elapsed, mean, nv0, acc.num_vec(), checks, stats
 
-    elapsed, mean, nv, nv_end, replica_check, stats = measure(acc)
-    steady = (nv == m)
+    elapsed, mean, nv, nv_end, replica_check, stats = measure(acc, args.workload)
+    k_steady = m if args.workload == "full" else min(m, args.drop_dim)     # vectors the subspace holds in steady state
+    steady = (nv == k_steady)
 
     # what every rank saw: which GPU, which RCCL, how many ranks ITS communicator connected, its digest of the
     # replicated state -- so that a multi-GPU record proves by itself that RCCL reduced over N ranks
@@ -683,10 +740,41 @@ def main(argv=None):
         finally:
             a2.delete()
 
+    def with_drops_extra():
+        """The same accelerator shape with a SHRUNK subspace (VERDICT r3 task 2): every input in a drop-dim dimensional
+        span, so every update takes a dependence drop (F08:326-345) and the subspace holds k = drop-dim < mvec vectors;
+        one synchronisation per update (the solver's residual norm), inside the timed time.  The host learns the list
+        length from the list word and launches PA at exactly L = k; PB is launched one wider than it turns out to need
+        (its width is fixed before the device decides the drop of this very update) -- one dead ring slot."""
+        D = min(args.drop_dim, m)
+        a3 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor])
+        try:
+            e3, mean3, nv3, nv3_end, _, stats3 = measure(a3, "drops")
+            fl3 = FLAVOR_NAMES[a3.flavor()]
+            lb = a3.list_bound()
+            return {"workload": f"every input in a {D}-dimensional span: one dependence drop per update, num_vec = {nv3} "
+                                f"of mvec = {m}; torch.cuda.synchronize() after every update (inside the timed region)",
+                    "flavor": FLAVOR_TEXT[fl3], "value": K / e3, "unit": "updates/s", "ms_per_step": 1e3 * e3 / K,
+                    "mean_k": float(nv3 + nv3_end) / 2.0, "steady_state": bool(nv3 == D and nv3_end == D),
+                    "host_list_bound_after_the_run": lb, "list_length_on_device": nv3_end + 1,
+                    "launch_widths": {"PA": lb - 1, "PB": min(lb, m)},
+                    "roofline": roofline_block(fl3, n_local, m, mean3, None, stats3, None, L=D, k=D)}
+        finally:
+            a3.delete()
+            basis_box[0] = None
+
+    drops = None
+    headline = world == 1 and (n_global, m) == (10**8, 20) and args.workload == "full" and not args.no_cpu_baseline
+    if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+        try:
+            drops = with_drops_extra()
+        except Exception as exc:           # an extra, never the measured path
+            drops = {"value": None, "error": repr(exc)}
+
     # Secondary figure in the same run: the src-F08 rounding (two stored vectors
     # per pair, bit-faithful to F08:397), same workload, same protocol.
     also = None
-    if flavor == "c" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+    if flavor == "c" and args.workload == "full" and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
         acc.delete()
         acc = make_acc("f08")
         e2, mean2, nv2, nv2_end, _, stats2 = measure(acc)
@@ -696,8 +784,12 @@ def main(argv=None):
                 "roofline": roofline_block("f08", n_local, m, mean2, None, stats2)}
 
     if rank == 0:
-        L = k = m
-        rl = roofline_block(flavor, n_local, m, mean, None, stats)
+        Lk = k_steady
+        rl = roofline_block(flavor, n_local, m, mean, None, stats, None, L=Lk, k=Lk)
+        wl = (f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction vectors, n={n_global} "
+              f"(global), mvec={m}, fp64, subspace full (num_vec={nv})") if args.workload == "full" else \
+             (f"NOT a BASELINE config: every input in a {args.drop_dim}-dimensional span, n={n_global}, mvec={m}, fp64, one "
+              f"dependence drop and one device synchronisation per update (num_vec={nv})")
         out = {
             "metric": ("NKA updates/sec + achieved HBM GB/s at n=1e8, m=20 fp64; 1/2/4/8 GPUs"   # BASELINE.json
                        if (n_global, m) == (10**8, 20) else
@@ -705,8 +797,7 @@ def main(argv=None):
             "value": K / elapsed, "unit": "updates/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: synthetic uniform(-1,1) correction "
-                                   f"vectors, n={n_global} (global), mvec={m}, fp64, subspace full (num_vec={nv})",
+            "config": {"workload": wl,
                        "n_global": n_global, "n_local": n_local, "mvec": m,
                        "flavor": FLAVOR_TEXT[flavor],
                        "flavor_is_front_end_default": bool(is_default),
@@ -721,12 +812,10 @@ def main(argv=None):
                                       + ("; REHEARSAL: ranks share one GPU -- the numbers of this line mean nothing"
                                          if share_gpu else ""),
                        "control_plane": "torch.distributed gloo (decisions, barriers, timing, digests)" if world > 1 else None,
-                       "steady_state": bool(steady and nv_end == m), "prime_steps": prime,
+                       "steady_state": bool(steady and nv_end == k_steady), "prime_steps": prime,
                        "phase_events": f"HIP events recorded on every {ev_stride}{'st' if ev_stride == 1 else 'th'} timed update",
                        "inputs_resident": not refill_in_timed_region},
             "roofline": rl,
-            # whole-job rate in the contract's unit (SURVEY.md 8d bytes x updates/s); NOT a bandwidth
-            "aggregate_contract_GBps": 8.0 * n_global * (11 + L + 2 * k) * (K / elapsed) / 1e9,
         }
         if replica_check:
             out["replica_check"] = replica_check
@@ -736,33 +825,65 @@ def main(argv=None):
             out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:
             out["also_f08_rounding"] = also
-        if world == 1 and (n_global, m) == (10**8, 20) and not args.no_cpu_baseline:
+        if drops is not None:
+            out["with_drops"] = drops
+        if headline:
             try:
                 c2 = config2_line()
                 if c2:
                     out["config2_n1e7_m10"] = c2
             except Exception as exc:       # an extra, never the measured path
                 out["config2_n1e7_m10"] = {"error": repr(exc)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(m, int(args.cpu_n))
-                out["cpu_baseline"]["updates_per_s_scaled_to_n_global"] = \
-                    out["cpu_baseline"]["value"] * int(args.cpu_n) / n_global
-            except Exception as exc:  # the baseline is a reported extra, never the measured path
-                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
-        if world == 1 and not args.no_cpu_baseline:                # lean runs skip the child-process extras
-            del pool, pool_store           # release HBM for the child processes
+        lean = args.no_cpu_baseline or world > 1            # lean runs skip the CPU leg and the child-process extras
+        if not lean:
+            # release HBM (the child processes below need it) before the minute of CPU work
+            del pool, pool_store
             acc.delete()
             torch.cuda.empty_cache()
             pool = pool_store = None
+            try:
+                # the CPU leg runs at the benchmark's own n unless the host cannot hold the
+                # reference's 2(mvec+1) vectors (33.6 GB at n = 1e8, m = 20) with room to spare
+                avail = host_mem_available_gb()
+                need_gb = 8.0 * n_global * (2 * (m + 1) + 3) / 2**30
+                if args.cpu_n is not None:
+                    cpu_n, why = int(args.cpu_n), " (n chosen with --cpu-n)"
+                elif avail is not None and avail >= need_gb + 12.0:
+                    cpu_n, why = n_global, ""
+                else:
+                    cpu_n = min(n_global, 2 * 10**7)
+                    why = (f" (n reduced: the reference needs {need_gb:.0f} GB of host memory at n = {n_global}, "
+                           f"{avail if avail is None else round(avail)} GB available)")
+                gen, timed = None, 6
+                if cpu_n >= 5 * 10**7:            # inputs from the device generator (the numpy twin needs ~1.5 s per vector)
+                    timed = 3
+                    dbuf = torch.empty(cpu_n, dtype=torch.float64, device=dev)
+                    hbuf = torch.empty(cpu_n, dtype=torch.float64, pin_memory=True)
+
+                    def gen(t):
+                        synth.fill_torch(dbuf, SEED, t, 0, n_global)
+                        hbuf.copy_(dbuf)
+                        return hbuf.numpy()
+                out["cpu_baseline"] = cpu_baseline(m, cpu_n, timed, gen, why)
+                out["cpu_baseline"]["updates_per_s_scaled_to_n_global"] = out["cpu_baseline"]["value"] * cpu_n / n_global
+                dbuf = hbuf = None
+            except Exception as exc:  # the baseline is a reported extra, never the measured path
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+            torch.cuda.empty_cache()
             probe = probe_ceilings(min(n_local, 10**8))
             # HBM traffic of the dominant kernels by the PMC counters, measured in this run (child process under rocprofv3)
-            pm_live = pmc_same_run(flavor, n_local, m) if (n_global, m) == (10**8, 20) else None
-            rl = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live)
-            out["roofline"] = rl
+            pm_live = pmc_same_run(flavor, n_local, m) if headline else None
+            out["roofline"] = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live, L=Lk, k=Lk)
             if also is not None:
                 also["roofline"]["probe_ceiling"] = probe
-            if not args.no_config5 and (n_global, m) == (10**8, 20):
+            if drops is not None and drops.get("roofline") and headline:
+                pm_d = pmc_same_run(flavor, n_local, m, extra_args=("--workload", "drops", "--drop-dim", str(args.drop_dim)))
+                if pm_d:
+                    D = min(args.drop_dim, m)
+                    ph = drops["roofline"]["device_time_stats_ms"]
+                    mean_d = [ph[nm]["mean"] for nm in ("PA_k_dots", "k_solve", "PB_k_combine", "whole_update")]
+                    drops["roofline"] = roofline_block(flavor, n_local, m, mean_d, None, ph, pm_d, L=D, k=D)
+            if not args.no_config5 and headline:
                 out["config5_abstract_vector"] = config5_abstract_vector()
         print(json.dumps(out), flush=True)
 

@@ -85,13 +85,25 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
  * A replay re-issues the kernel instances chosen at capture time; they stay
  * valid as long as the unroll widths chosen then cover the list, which is
  * guaranteed once nka_hip_capture_safe() returns 1: a pair is pending and the
- * host-side bound on the list length has reached mvec+1 (from the mvec+1-th
- * update after init/restart on).  restart()/relax() end that state.  Never 1 in the
+ * host-side bound on the list length (nka_hip_list_bound) is mvec+1 -- from the
+ * mvec+1-th update after init/restart on, unless the device has reported a list made
+ * shorter by dependence drops.  restart()/relax() end that state.  A handle whose stream
+ * was seen capturing stops using (and publishing) the list word for good: replays change
+ * the list behind it.  Never 1 in the
  * debug mode (NKA_HIP_DEBUG=1 reads the state back after every update), with a user dot
  * product (nka_hip_set_host_dot: it runs on the host) or with a caller's all-reduce hook
  * (nka_hip_set_allreduce: a host callback a replay would not call again; the built-in
  * RCCL hook only enqueues on the stream and can be captured). */
 int nka_hip_capture_safe(nka_hip_t a);
+
+/* Upper bound on the list length (pending pair included) at the entry of the next update, as the HOST knows it
+ * without synchronising: its own count (+1 per update up to mvec+1, -1 per relax, 0 after restart) tightened by the
+ * LIST WORD -- a 64-bit word in pinned host memory that the combine pass of every update overwrites with (update
+ * number, list length at its exit).  After a dependence drop (F08:326-345) the list is shorter than the host's
+ * count; PA and PB are launched at the width of this bound, so a caller that synchronises once per iteration (every
+ * solver reads its residual norm) runs both passes at exactly the list length, never at the padded full width.
+ * A caller that never synchronises gets the plain count.  Results do not depend on the width (same bits). */
+int nka_hip_list_bound(nka_hip_t a);
 
 /* Rebind the handle to another hipStream_t (NULL = default stream).  Work already
  * enqueued on the old stream is ordered before anything enqueued on the new one. */

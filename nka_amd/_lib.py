@@ -20,6 +20,7 @@ SIGNATURES = {
     "nka_hip_destroy": (C.c_int, [C.c_void_p]),
     "nka_hip_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "nka_hip_capture_safe": (C.c_int, [C.c_void_p]),
+    "nka_hip_list_bound": (C.c_int, [C.c_void_p]),
     "nka_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update_host": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -160,6 +160,14 @@ struct nka_hip_state {
   // what the host knows without reading the device back
   bool pending = false;
   int list_ub = 0;            // upper bound on the list length
+  // ... and what the device tells it without being asked: the list word (Ctl::hw, nka_kernels.hpp), one 64-bit word
+  // in pinned host memory that PB of update number u overwrites with (u, list length at its exit).
+  unsigned long long *list_word = nullptr;
+  int64_t seq = 0;            // updates enqueued so far; the next one is number seq + 1
+  int64_t word_valid_after = 0;      // words of updates numbered <= this are stale (restart; a word of 0 = none yet)
+  std::vector<int64_t> relaxed_after;  // relax() calls that dropped a pending pair, by the number of the update before them
+  bool word_off = false;      // the handle's stream was seen capturing (replays change the list behind the word), or
+                              // the diagnostic switch "list_word" = 0
   // launch geometry
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
@@ -415,6 +423,32 @@ struct RoctxRange {
 
 constexpr int kTimingEvents = 4;
 
+// Upper bound on the list length at the entry of the NEXT update (number seq + 1), tightened -- without any
+// synchronisation -- by the newest list word the device has published.  The host's own bookkeeping only counts:
+// +1 per update, capped by mvec + 1, -1 per relax; it never learns of a dependence drop (F08:326-345), after which
+// PA / PB used to run at the full width with dead ring slots re-reading f (+20 % at m = 5 padded to 8).  The word
+// of update u says the list held `len` entries at u's exit; each later update adds at most one entry and each
+// later relax that found a pending pair removes exactly one, so at the entry of update seq + 1
+//     length <= len + (seq - u) - #{relax after update >= u}.
+// Exact whenever the caller has synchronised with the previous update (u == seq): every solver does, once per
+// iteration, to read its residual norm.  A caller that never synchronises gets the old bound.
+int list_bound_now(nka_hip_state *a) {
+  int ub = a->list_ub;
+  if (a->word_off || !a->list_word) return ub;
+  const unsigned long long w = __atomic_load_n(a->list_word, __ATOMIC_ACQUIRE);
+  const int64_t u = (int64_t)(w >> kListWordLenBits);
+  if (u <= a->word_valid_after || u > a->seq) return ub;
+  int64_t len = (int64_t)(w & ((1ull << kListWordLenBits) - 1)) + (a->seq - u);
+  size_t keep = 0;
+  for (int64_t r : a->relaxed_after)
+    if (r >= u) {
+      len--;
+      a->relaxed_after[keep++] = r;
+    }
+  a->relaxed_after.resize(keep);      // older relax calls are part of every word from now on
+  return (int)std::min<int64_t>(ub, std::max<int64_t>(len, 0));
+}
+
 constexpr size_t kMaxDynamicLds = 160 * 1024;   // gfx950: LDS per CU = per workgroup maximum
 constexpr int kMaxMvec = 140;                   // largest mvec with lst_smem_bytes(mvec) <= kMaxDynamicLds
 static_assert(lst_smem_bytes(kMaxMvec) <= kMaxDynamicLds && lst_smem_bytes(kMaxMvec + 1) > kMaxDynamicLds,
@@ -520,6 +554,24 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
   alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 2));  // NACC columns of k_dots
   alloc((void **)&a->tickets, sizeof(unsigned) * kTicketWords);
+  if (!rc) {
+    // the list word: fine-grained pinned host memory the device writes and the host polls (no synchronisation)
+    void *hw = nullptr;
+    hipError_t e = hipHostMalloc(&hw, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+      memset(hw, 0, 64);
+      void *dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, hw, 0) == hipSuccess && dp) {
+        a->list_word = static_cast<unsigned long long *>(hw);
+        a->ctl.hw = static_cast<unsigned long long *>(dp);
+      } else {
+        (void)hipGetLastError();
+        hipHostFree(hw);           // no device view of it: run without the word (the bound is then the host's own)
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   if (rc) {
     nka_hip_destroy(a);
     return rc;
@@ -549,7 +601,12 @@ int nka_hip_capture_safe(nka_hip_t a) {
   //  hook is a host callback that a replay would not call again: none of them can be captured; the built-in RCCL hook only
   //  enqueues on the stream)
   const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce;
-  return (a->pending && a->list_ub >= a->mvec + 1 && !a->debug && !a->host_dot && !user_hook) ? 1 : 0;
+  return (a->pending && list_bound_now(a) >= a->mvec + 1 && !a->debug && !a->host_dot && !user_hook) ? 1 : 0;
+}
+
+int nka_hip_list_bound(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  return list_bound_now(a);
 }
 
 int nka_hip_set_stream(nka_hip_t a, void *stream) {
@@ -579,6 +636,7 @@ int nka_hip_destroy(nka_hip_t a) {
   hipFree(a->ctl.dc);
   hipFree(a->partials);
   hipFree(a->tickets);
+  if (a->list_word) hipHostFree(a->list_word);
   hipFree(a->f_stage);
   hipFree(a->hd_scratch);
   for (auto &e : a->ev)
@@ -637,6 +695,8 @@ int nka_hip_restart(nka_hip_t a) {
   HIP_TRY(hipGetLastError());
   a->pending = false;
   a->list_ub = 0;
+  a->word_valid_after = a->seq;      // whatever the updates enqueued so far publish describes the flushed list
+  a->relaxed_after.clear();
   return 0;
 }
 
@@ -649,6 +709,7 @@ int nka_hip_relax(nka_hip_t a) {
   if (a->pending) {
     a->pending = false;
     a->list_ub = std::max(a->list_ub - 1, 0);
+    a->relaxed_after.push_back(a->seq);
   }
   return 0;
 }
@@ -860,6 +921,14 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   const int vec = aligned ? 2 : 1;
   int mode = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? kSolveRcp : 0;
   if (int rc = record(a, 0)) return rc;
+  if (!a->word_off) {
+    // a captured update is replayed with the widths and the update number of the capture: the word can neither
+    // describe the replays nor tighten them (capture_safe() asks for the full width anyway)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) a->word_off = true;
+  }
+  a->list_ub = list_bound_now(a);
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
 
   // ---- PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371) ----
@@ -889,7 +958,16 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (int rc = record(a, 2)) return rc;
 
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
-  if (int rc = enqueue_pb(a, f, vec, comb_ub)) return rc;
+  a->ctl.seq = (unsigned long long)(a->seq + 1);       // PB publishes (this number, list length at exit)
+  {
+    Ctl &c = a->ctl;
+    unsigned long long *const hw = c.hw;
+    if (a->word_off) c.hw = nullptr;
+    const int rc = enqueue_pb(a, f, vec, comb_ub);
+    c.hw = hw;
+    if (rc) return rc;
+  }
+  a->seq++;
   if (int rc = record(a, 3)) return rc;
 
   if (a->timing_this) a->timing_count++;
@@ -1242,6 +1320,8 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     a->pb_tickets = value;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
+  } else if (k == "list_word") {       // 0: the host's own bound only (the behaviour before round 4), for A/B runs
+    a->word_off = value == 0;
 
   } else {
     return fail(NKA_HIP_EINVAL, "unknown tuning key: " + k);

@@ -84,6 +84,12 @@ struct Ctl {
   int32_t *ic;         // header, then next[M1+1], prev[M1+1], plan_slots[M1+pad], comb_slots[M1+pad]
   double *dc;          // header, then h[(M1+1)^2], c[M1+1], comb_c[M1+pad], red[2+2*mvec]
   int32_t mvec;
+  // LIST WORD: one 64-bit word in pinned host memory (nullptr: none) that block 0 of PB overwrites with
+  // (number of this update << kListWordLenBits | list length at its exit), see list_word_publish; `seq` = the
+  // number the host gave this update.  The host reads it WITHOUT synchronising to learn that dependence drops
+  // (F08:326-345) have made the list shorter than its own bookkeeping says (nka_hip.hip: list_bound_now).
+  unsigned long long *hw;
+  unsigned long long seq;
   // plan_slots / comb_slots / comb_c are padded by one pass width: the unrolled
   // kernels read (and ignore) entries up to the end of their last pass.
   __host__ __device__ int m1() const { return mvec + 1; }
@@ -103,6 +109,17 @@ struct Ctl {
     return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count() + kStamps;
   }
 };
+constexpr int kListWordLenBits = 20;        // mvec + 1 <= 2^17 + 1 (nka_hip_create)
+// PB, first thread of block 0, before its first tile: the store is posted while the pass streams, so it costs the
+// update nothing and has landed long before the pass ends (a caller that synchronises once per iteration -- every
+// solver reads a residual norm -- sees the word of the update it has just waited for).  ncomb + 1 = the combined
+// entries plus the new pending pair = the list length at the exit of this update.
+__device__ __forceinline__ void list_word_publish(const Ctl &ctl, int ncomb) {
+  if (ctl.hw != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(ctl.hw, (ctl.seq << kListWordLenBits) | (unsigned long long)(ncomb + 1), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // red[] layout (raw sums of PA, d = w1 - f NOT yet divided by s):
 //   [0] sum d^2, [1] <f,d>, [2+p] <d,w_older(p)>, [2+mvec+p] <f,w_older(p)>
 
@@ -503,6 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   const bool norm0 = (pass == 0) && ctl.ic[IC_NORMED];
   const double s = ctl.dc[DC_S];
   const double rs = 1.0 / s;
+  if (pass == 0) list_word_publish(ctl, ncomb);
 
   double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
@@ -704,6 +722,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
         rv[j][q] = ld<VEC>(vk[j] + e + q * (kBlock * VEC));
       }
   }
+  list_word_publish(ctl, ncomb);               // (behind the first ring of loads: nothing waits for it)
   // ticket counter of this block's group; ticket k of group g is tile (k + 2G/ng)*ng + g
   const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
   unsigned *const my_ticket = tickets ? tickets + grp * kTicketStride : nullptr;

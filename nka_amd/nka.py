@@ -246,6 +246,14 @@ class nka:  # noqa: N801  (the reference's type name)
         (steady state: see nka_hip_capture_safe in include/nka_hip.h)."""
         return self._L.nka_hip_capture_safe(self._handle()) == 1
 
+    def list_bound(self) -> int:
+        """The host's upper bound on the list length at the entry of the next update (no synchronisation):
+        its own count tightened by the device's list word (nka_hip_list_bound)."""
+        n = self._L.nka_hip_list_bound(self._handle())
+        if n < 0:
+            _check(n, "list_bound")
+        return n
+
     def set_stream(self, stream: int):
         """Rebind to another hipStream_t; earlier work stays ordered before later work."""
         _check(self._L.nka_hip_set_stream(self._handle(), C.c_void_p(int(stream))), "set_stream")

@@ -47,7 +47,13 @@ def test_roofline_block_is_physical(bench, flavor, pa_ms, pb_ms):
     # the contract's B_alg never enters a fraction: it is a ratio and a work rate
     assert r["contract_bytes_per_update"] == 8.0 * n * (11 + 3 * m)
     assert r["contract_bytes_ratio"] == pytest.approx(8.0 * n * (11 + 3 * m) / moved)
-    assert r["contract_GBps"] == pytest.approx(r["whole_update"]["achieved"] * r["contract_bytes_ratio"])
+    assert r["bytes_moved_per_update"] == moved
+    if flavor == "c":
+        # compact storage moves FEWER bytes than B_alg: no rate that could be read as > 100 % of the peak is printed
+        assert "contract_GBps" not in r and "contract_frac_of_peak" not in r and r["contract_bytes_ratio"] > 1.4
+    else:
+        assert r["contract_GBps"] == pytest.approx(r["whole_update"]["achieved"] * r["contract_bytes_ratio"])
+        assert r["contract_frac_of_peak"] == pytest.approx(r["contract_GBps"] / 8000.0) and r["contract_bytes_ratio"] < 1.05
     if pb_ms > 2.0:                          # realistic timings: below the peak
         assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["whole_update"]["frac"] <= 1.0
         for k in ("PA_k_dots", "PB_k_combine"):
@@ -117,3 +123,13 @@ def test_plain_form_watchdog_kills_the_whole_rank_group(bench, capsys, tmp_path)
     # a hang in the first attempt, a result from the second
     rc, lines = _launch(bench, capsys, ["--mode", "hang-unless-staged"], timeout=8)
     assert rc == 0 and json.loads(lines[0])["launch"]["first_attempt"].startswith("watchdog expired")
+
+
+def test_roofline_block_at_a_shrunk_subspace(bench):
+    """--workload drops: the bytes follow the ACTUAL list (L stored vectors read by PA, k pairs combined by PB)."""
+    n, m, D = 10**8, 20, 12
+    r = bench.roofline_block("c", n, m, [1.7, 0.02, 2.4, 4.13], L=D, k=D)
+    assert r["kernels"]["PA_k_dots"]["words_per_element"] == 2 + D
+    assert r["kernels"]["PB_k_combine"]["words_per_element"] == D + 2 + 5
+    assert r["whole_update"]["bytes_moved"] == 8.0 * n * (9 + 2 * D)
+    assert r["traffic"] is None                      # the committed full-subspace PMC summary does not apply

@@ -1,0 +1,141 @@
+"""GPU tests of round 4: the LIST WORD (the device tells the host, without being asked, how long the list is after
+dependence drops; include/nka_hip.h: nka_hip_list_bound), and what hangs on it."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_util as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def span_inputs(n, calls, dim, seed):
+    """Inputs confined to a `dim`-dimensional span: every difference of two of them lies in it, so the subspace can
+    hold `dim` vectors and every further update drops one as dependent (F08:326-345)."""
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((dim, n))
+    return [rng.standard_normal(dim) @ B for _ in range(calls)]
+
+
+@pytest.mark.parametrize("flavor", [0, 2])
+@pytest.mark.parametrize("n,m,dim", [(40961, 10, 4), (100003, 20, 12), (2049, 6, 1)])
+def test_list_word_tightens_the_launch_widths_and_changes_no_bit(torch_cuda, oracle, flavor, n, m, dim):
+    """A caller that synchronises once per update (every solver does: it reads a residual norm) must see the host's
+    bound equal the TRUE list length after a dependence drop, where the host's own count (+1 per update up to mvec+1)
+    stays at the full width; the narrower launches change no bit of any output; decisions equal the oracle's."""
+    import nka_amd
+    torch = torch_cuda
+    X = span_inputs(n, m + 10, dim, seed=31 * m + flavor)
+    tight = nka_amd.nka().init(n, m, flavor=flavor)
+    loose = nka_amd.nka().init(n, m, flavor=flavor)
+    loose.set_tuning("list_word", 0)                 # the behaviour before round 4: the host's own count only
+    ora = oracle.OracleNKA(n, m, flavor)
+    spread = P.Spread(oracle, n, m)
+    seen_short = 0
+    for t, x in enumerate(X):
+        f = x.copy()
+        ora.accel_update(f)
+        spread.update(x)
+        ft, fl = torch.from_numpy(x.copy()).cuda(), torch.from_numpy(x.copy()).cuda()
+        tight.accel_update(ft)
+        loose.accel_update(fl)
+        torch.cuda.synchronize()
+        assert torch.equal(ft, fl), t                                  # same bits whatever the width
+        st = tight.state()
+        assert st.list_order() == ora.state().list_order(), t          # decisions exact
+        true_len = len(st.list_order())
+        assert tight.list_bound() == true_len, (t, tight.list_bound(), true_len)      # exact after a synchronisation
+        assert loose.list_bound() == min(t + 1, m + 1)                                # the plain count
+        seen_short += tight.list_bound() < loose.list_bound()
+        err = np.linalg.norm(ft.cpu().numpy() - f) / np.linalg.norm(x)
+        P.check(err, ora.state(), f"list word n={n} m={m} dim={dim} flavor {flavor}", base=1e-12, where=t, spread=spread.value)
+    assert seen_short >= m + 10 - (dim + 2) - 1          # from the first drop on the count is too long, the word is not
+    assert tight.num_vec() == min(dim, m)
+    assert tight.state_digest() == loose.state_digest()
+    assert not tight.capture_safe() and tight.list_bound() < m + 1     # a graph captured now would be too narrow later
+
+
+def test_list_bound_is_an_upper_bound_through_relax_restart_and_unsynchronised_runs(torch_cuda):
+    """Random call sequences with synchronisation only now and then: the bound is never below the true list length
+    (checked after the fact), equals it whenever the caller has just synchronised, relax / restart included."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    n, m, dim = 30011, 8, 3
+    B = rng.standard_normal((dim, n))
+    acc = nka_amd.nka().init(n, m)
+    synced = True
+    for t in range(150):
+        r = rng.random()
+        if r < 0.08:
+            acc.relax()
+        elif r < 0.12:
+            acc.restart()
+        elif r < 0.18:
+            acc.set_vec_tol(float(rng.choice([0.01, 0.3])))          # (synchronises)
+            synced = True
+        else:
+            x = rng.standard_normal(dim) @ B if rng.random() < 0.7 else rng.standard_normal(n)
+            acc.accel_update(torch.from_numpy(x).cuda())
+            synced = False
+        bound = acc.list_bound()                  # BEFORE looking at the device
+        if rng.random() < 0.4:
+            torch.cuda.synchronize()
+            synced = True
+            bound_synced = acc.list_bound()
+            true_len = len(acc.state().list_order())
+            assert bound_synced == true_len, (t, bound_synced, true_len)
+        true_len = len(acc.state().list_order())              # (synchronises; after the fact)
+        assert bound >= true_len, (t, bound, true_len)
+        assert acc.defined()
+
+
+def test_capture_switches_the_list_word_off_for_good(torch_cuda):
+    """A captured update is replayed with the widths of the capture: the handle stops using and publishing the word
+    the moment its stream is seen capturing; replays and later eager calls stay correct (full width)."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 20000, 4
+    rng = np.random.default_rng(3)
+    acc, ref = nka_amd.nka().init(n, m), nka_amd.nka().init(n, m)
+    xs = [rng.standard_normal(n) for _ in range(m + 6)]
+    for x in xs[:m + 2]:
+        acc.accel_update(torch.from_numpy(x.copy()).cuda())
+        ref.accel_update(torch.from_numpy(x.copy()).cuda())
+    torch.cuda.synchronize()
+    assert acc.capture_safe() and acc.list_bound() == m + 1
+    buf = torch.from_numpy(xs[m + 2].copy()).cuda()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        acc.set_stream(s.cuda_stream)
+        with torch.cuda.graph(g, stream=s):
+            acc.accel_update(buf)
+    outs = []
+    for x in xs[m + 2:m + 5]:
+        buf.copy_(torch.from_numpy(x))
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append(buf.clone())
+    for x, o in zip(xs[m + 2:m + 5], outs):
+        fr = torch.from_numpy(x.copy()).cuda()
+        ref.accel_update(fr)
+        assert torch.equal(fr, o)
+    # the word has stopped: the bound is the plain count again, and eager calls after the replays are right
+    assert acc.list_bound() == m + 1
+    fa, fr = torch.from_numpy(xs[m + 5].copy()).cuda(), torch.from_numpy(xs[m + 5].copy()).cuda()
+    with torch.cuda.stream(s):
+        acc.accel_update(fa)
+    ref.accel_update(fr)
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fr) and acc.state_digest() == ref.state_digest()
