@@ -15,19 +15,45 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ONE source, TWO instruments.  Compiled as it stands this file is the restatement in IEEE double
+ * (real_t = double: the expressions, their order and their rounding are the reference's; pinned bit for
+ * bit to the compiled reference by tests/test_oracle_golden.py).  oracle/nka_oracle_exact.c includes it
+ * with NKA_ORACLE_EXTENDED defined: the SAME statements and the SAME list logic in x87 extended
+ * precision (real_t = long double, 64-bit significand, unit roundoff 5.4e-20; every stored vector,
+ * inner product, factor entry and coefficient) under the names nka_oraclex_* -- the "exact" trajectory
+ * against which the tests measure err(reference) and err(device) (tests/parity_util.py). */
+#ifdef NKA_ORACLE_EXTENDED
+typedef long double real_t;
+#define R_SQRT sqrtl
+#define NM(x) nka_oraclex_##x
+typedef struct nka_oraclex nka_oraclex;
+#define nka_oracle nka_oraclex
+#else
+typedef double real_t;
+#define R_SQRT sqrt
+#define NM(x) nka_oracle_##x
+#endif
+
+typedef real_t (*real_dot_fn)(void *ctx, int64_t n, const real_t *x, const real_t *y);
+
 struct nka_oracle {
   int subspace, pending;
   int64_t vlen;
   int mvec, nslot; /* nslot = mvec + 1 */
   int flavor;
-  double vtol;
-  nka_oracle_dot_fn dot;
+  real_t vtol;
+  real_dot_fn dot;
   void *dot_ctx;
-  double *v, *w;   /* nslot vectors of vlen each, slot k at (k-1)*vlen */
-  double *h;       /* (nslot+1)^2, h[i*(nslot+1)+j] is the reference's h(i,j) */
-  double *c;       /* nslot+1 */
+  real_t *v, *w;   /* nslot vectors of vlen each, slot k at (k-1)*vlen */
+  real_t *h;       /* (nslot+1)^2, h[i*(nslot+1)+j] is the reference's h(i,j) */
+  real_t *c;       /* nslot+1 */
   int first, last, free_;
   int *next, *prev; /* nslot+1 */
+  /* ERROR ATTRIBUTION (never set by the parity tests' reference runs): the Gram row of the normalised new
+   * vector and the first projection from the RAW sums <d,w_k>/s, <f,d>/s with d = w1 - f, as the device
+   * path forms them (deviation ii), instead of summing fl(d_i/s)*w_k,i. */
+  int gram_from_raw_sums;
+  real_t *fx;      /* extended build: the caller's f in extended precision */
 };
 
 #define H(a, i, j) ((a)->h[(size_t)(i) * ((a)->nslot + 1) + (j)])
@@ -37,15 +63,15 @@ struct nka_oracle {
 /* Default dot product: a single sequential accumulation, the order of the C
  * reference's dot_product (src-C/nonlinear_krylov_accelerator.c:200-208) and of
  * an unvectorised DOT_PRODUCT intrinsic (src-F08/nka_type.F90:216-219). */
-static double seq_dot(void *ctx, int64_t n, const double *x, const double *y) {
+static real_t seq_dot(void *ctx, int64_t n, const real_t *x, const real_t *y) {
   (void)ctx;
-  double s = 0.0;
+  real_t s = 0.0;
   for (int64_t i = 0; i < n; i++) s += x[i] * y[i];
   return s;
 }
 
 /* src-F08/nka_type.F90:422-436 */
-void nka_oracle_restart(nka_oracle *a) {
+void NM(restart)(nka_oracle *a) {
   a->subspace = 0;
   a->pending = 0;
   a->first = 0;
@@ -56,7 +82,7 @@ void nka_oracle_restart(nka_oracle *a) {
 }
 
 /* src-F08/nka_type.F90:185-200 (init also resets vtol and dp to the defaults) */
-nka_oracle *nka_oracle_init(int64_t vlen, int mvec, int flavor) {
+nka_oracle *NM(init)(int64_t vlen, int mvec, int flavor) {
   if (mvec <= 0 || vlen < 0) return NULL;
   nka_oracle *a = (nka_oracle *)calloc(1, sizeof *a);
   if (!a) return NULL;
@@ -67,21 +93,28 @@ nka_oracle *nka_oracle_init(int64_t vlen, int mvec, int flavor) {
   a->vtol = 0.01; /* src-F08/nka_type.F90:160 */
   a->dot = seq_dot;
   size_t nv = (size_t)a->nslot * (size_t)(vlen > 0 ? vlen : 1);
-  a->v = (double *)malloc(nv * sizeof(double));
-  a->w = (double *)malloc(nv * sizeof(double));
-  a->h = (double *)calloc((size_t)(a->nslot + 1) * (a->nslot + 1), sizeof(double));
-  a->c = (double *)calloc((size_t)a->nslot + 1, sizeof(double));
+  a->v = (real_t *)malloc(nv * sizeof(real_t));
+  a->w = (real_t *)malloc(nv * sizeof(real_t));
+  a->h = (real_t *)calloc((size_t)(a->nslot + 1) * (a->nslot + 1), sizeof(real_t));
+  a->c = (real_t *)calloc((size_t)a->nslot + 1, sizeof(real_t));
+#ifdef NKA_ORACLE_EXTENDED
+  a->fx = (real_t *)malloc((size_t)(vlen > 0 ? vlen : 1) * sizeof(real_t));
+  if (!a->fx) {
+    NM(delete)(a);
+    return NULL;
+  }
+#endif
   a->next = (int *)calloc((size_t)a->nslot + 1, sizeof(int));
   a->prev = (int *)calloc((size_t)a->nslot + 1, sizeof(int));
   if (!a->v || !a->w || !a->h || !a->c || !a->next || !a->prev) {
-    nka_oracle_delete(a);
+    NM(delete)(a);
     return NULL;
   }
-  nka_oracle_restart(a);
+  NM(restart)(a);
   return a;
 }
 
-void nka_oracle_delete(nka_oracle *a) {
+void NM(delete)(nka_oracle *a) {
   if (!a) return;
   free(a->v);
   free(a->w);
@@ -89,20 +122,25 @@ void nka_oracle_delete(nka_oracle *a) {
   free(a->c);
   free(a->next);
   free(a->prev);
+  free(a->fx);
   free(a);
 }
 
 /* src-F08/nka_type.F90:202-207 */
-void nka_oracle_set_vec_tol(nka_oracle *a, double vtol) { a->vtol = vtol; }
+void NM(set_vec_tol)(nka_oracle *a, double vtol) { a->vtol = vtol; }
 
 /* src-F08/nka_type.F90:209-214 */
-void nka_oracle_set_dot_prod(nka_oracle *a, nka_oracle_dot_fn fn, void *ctx) {
+#ifndef NKA_ORACLE_EXTENDED
+void NM(set_dot_prod)(nka_oracle *a, nka_oracle_dot_fn fn, void *ctx) {
   a->dot = fn ? fn : seq_dot;
   a->dot_ctx = ctx;
 }
+/* error attribution only (see struct nka_oracle and nka_oracle_probe.c) */
+void nka_oracle_set_gram_from_raw_sums(nka_oracle *a, int on) { a->gram_from_raw_sums = on; }
+#endif
 
 /* src-F08/nka_type.F90:439-457 */
-void nka_oracle_relax(nka_oracle *a) {
+void NM(relax)(nka_oracle *a) {
   if (!a->pending) return;
   int dropped = a->first;
   a->first = a->next[dropped];
@@ -116,17 +154,17 @@ void nka_oracle_relax(nka_oracle *a) {
 }
 
 /* src-F08/nka_type.F90:221-231 */
-int nka_oracle_num_vec(const nka_oracle *a) {
+int NM(num_vec)(const nka_oracle *a) {
   int n = 0;
   for (int k = a->first; k != 0; k = a->next[k]) n++;
   return a->pending ? n - 1 : n;
 }
-int nka_oracle_max_vec(const nka_oracle *a) { return a->mvec; }
-int64_t nka_oracle_vec_len(const nka_oracle *a) { return a->vlen; }
-double nka_oracle_vec_tol(const nka_oracle *a) { return a->vtol; }
+int NM(max_vec)(const nka_oracle *a) { return a->mvec; }
+int64_t NM(vec_len)(const nka_oracle *a) { return a->vlen; }
+double NM(vec_tol)(const nka_oracle *a) { return (double)a->vtol; }
 
 /* src-F08/nka_type.F90:460-524 -- structural invariants of the two lists. */
-int nka_oracle_defined(const nka_oracle *a) {
+int NM(defined)(const nka_oracle *a) {
   if (!a || a->mvec < 1 || !a->v || !a->w || !a->h || !a->next || !a->prev) return 0;
   if (a->vtol <= 0.0) return 0;
   int n = a->nslot;
@@ -184,16 +222,16 @@ static void factor_with_drops(nka_oracle *a) {
       a->next[a->last] = 0;
       break;
     }
-    double hkk = 1.0;
+    real_t hkk = 1.0;
     for (int j = a->first; j != k; j = a->next[j]) {
-      double hkj = H(a, j, k);
+      real_t hkj = H(a, j, k);
       for (int i = a->first; i != j; i = a->next[i]) hkj = hkj - H(a, k, i) * H(a, j, i);
       hkj = hkj / H(a, j, j);
       hkk = hkk - hkj * hkj;
       H(a, k, j) = hkj;
     }
     if (hkk > a->vtol * a->vtol) {
-      H(a, k, k) = sqrt(hkk);
+      H(a, k, k) = R_SQRT(hkk);
     } else { /* w_k is (nearly) in the span of the newer vectors: unlink it */
       int p = a->prev[k], nx = a->next[k];
       a->next[p] = nx;
@@ -216,12 +254,12 @@ static void factor_with_drops(nka_oracle *a) {
  * entry, indexed by slot): src-F08/nka_type.F90:369-392. */
 static void solve_normal_equations(nka_oracle *a) {
   for (int j = a->first; j != 0; j = a->next[j]) {
-    double cj = a->c[j];
+    real_t cj = a->c[j];
     for (int i = a->first; i != j; i = a->next[i]) cj = cj - H(a, j, i) * a->c[i];
     a->c[j] = cj / H(a, j, j);
   }
   for (int j = a->last; j != 0; j = a->prev[j]) {
-    double cj = a->c[j];
+    real_t cj = a->c[j];
     for (int i = a->last; i != j; i = a->prev[i]) cj = cj - H(a, i, j) * a->c[i];
     a->c[j] = cj / H(a, j, j);
   }
@@ -240,26 +278,38 @@ static void prepend(nka_oracle *a, int slot) {
 }
 
 /* src-F08/nka_type.F90:249-419 */
-void nka_oracle_accel_update(nka_oracle *a, double *f) {
+void NM(accel_update)(nka_oracle *a, double *f_io) {
   const int64_t n = a->vlen;
-  double s = 0.0;
+  real_t s = 0.0;
+#ifdef NKA_ORACLE_EXTENDED
+  real_t *f = a->fx;        /* the caller's doubles, exactly; every statement below in extended precision */
+  for (int64_t i = 0; i < n; i++) f[i] = f_io[i];
+#else
+  double *f = f_io;
+#endif
+  real_t *hraw = NULL;      /* error attribution only (gram_from_raw_sums): <d,w_k> by slot, and <f,d> in entry 0 */
 
   if (a->pending) {
-    double *w1 = WV(a, a->first);
+    real_t *w1 = WV(a, a->first);
     if (a->flavor == NKA_ORACLE_F08_VECTOR) {
       /* update1_: a*x + this with a = -1 (src-F08-vector/nka_type.F90:237) */
       for (int64_t i = 0; i < n; i++) w1[i] = (-1.0) * f[i] + w1[i];
     } else {
       for (int64_t i = 0; i < n; i++) w1[i] = w1[i] - f[i];
     }
-    s = sqrt(a->dot(a->dot_ctx, n, w1, w1));
-    if (s == 0.0) nka_oracle_relax(a);
+    s = R_SQRT(a->dot(a->dot_ctx, n, w1, w1));
+    if (s == 0.0) NM(relax)(a);
   }
 
   if (a->pending) {
-    double *w1 = WV(a, a->first), *v1 = VV(a, a->first);
+    real_t *w1 = WV(a, a->first), *v1 = VV(a, a->first);
+    if (a->gram_from_raw_sums) {
+      hraw = (real_t *)calloc((size_t)a->nslot + 1, sizeof(real_t));
+      hraw[0] = a->dot(a->dot_ctx, n, f, w1);
+      for (int k = a->next[a->first]; k != 0; k = a->next[k]) hraw[k] = a->dot(a->dot_ctx, n, w1, WV(a, k));
+    }
     if (a->flavor == NKA_ORACLE_F08_VECTOR) {
-      const double r = 1.0 / s; /* scale(1/s): src-F08-vector/nka_type.F90:255-256 */
+      const real_t r = 1.0 / s; /* scale(1/s): src-F08-vector/nka_type.F90:255-256 */
       for (int64_t i = 0; i < n; i++) v1[i] = r * v1[i];
       for (int64_t i = 0; i < n; i++) w1[i] = r * w1[i];
     } else {
@@ -267,23 +317,27 @@ void nka_oracle_accel_update(nka_oracle *a, double *f) {
       for (int64_t i = 0; i < n; i++) w1[i] = w1[i] / s;
     }
     for (int k = a->next[a->first]; k != 0; k = a->next[k])
-      H(a, a->first, k) = a->dot(a->dot_ctx, n, w1, WV(a, k));
+      H(a, a->first, k) = hraw ? (a->flavor == NKA_ORACLE_F08_VECTOR ? (1.0 / s) * hraw[k] : hraw[k] / s)
+                               : a->dot(a->dot_ctx, n, w1, WV(a, k));
     factor_with_drops(a);
   }
 
   int slot = a->free_;
   a->free_ = a->next[slot];
-  memcpy(WV(a, slot), f, (size_t)n * sizeof(double));
+  memcpy(WV(a, slot), f, (size_t)n * sizeof(real_t));
 
   if (a->subspace) {
-    for (int j = a->first; j != 0; j = a->next[j]) a->c[j] = a->dot(a->dot_ctx, n, f, WV(a, j));
+    const int newest = hraw ? a->first : 0;      /* (factor_with_drops never drops the first entry) */
+    for (int j = a->first; j != 0; j = a->next[j])
+      a->c[j] = (j == newest) ? (a->flavor == NKA_ORACLE_F08_VECTOR ? (1.0 / s) * hraw[0] : hraw[0] / s)
+                              : a->dot(a->dot_ctx, n, f, WV(a, j));
     solve_normal_equations(a);
     for (int k = a->first; k != 0; k = a->next[k]) {
-      const double ck = a->c[k];
-      const double *wk = WV(a, k), *vk = VV(a, k);
+      const real_t ck = a->c[k];
+      const real_t *wk = WV(a, k), *vk = VV(a, k);
       switch (a->flavor) {
       case NKA_ORACLE_F08_VECTOR: { /* update3_(-c,w,c,v): a*x + b*y + this */
-        const double mck = -ck;
+        const real_t mck = -ck;
         for (int64_t i = 0; i < n; i++) f[i] = (mck * wk[i] + ck * vk[i]) + f[i];
         break;
       }
@@ -295,11 +349,16 @@ void nka_oracle_accel_update(nka_oracle *a, double *f) {
       }
     }
   }
+  free(hraw);
 
-  memcpy(VV(a, slot), f, (size_t)n * sizeof(double));
+  memcpy(VV(a, slot), f, (size_t)n * sizeof(real_t));
   prepend(a, slot);
+#ifdef NKA_ORACLE_EXTENDED
+  for (int64_t i = 0; i < n; i++) f_io[i] = (double)f[i];   /* ONE rounding, of the result */
+#endif
 }
 
+#ifndef NKA_ORACLE_EXTENDED
 /* The scalar part of one update with the dot products supplied from outside
  * (what the device "solve" kernel does between the streaming passes).
  *   had_pending  -- value of `pending` at entry of the update
@@ -309,11 +368,11 @@ void nka_oracle_accel_update(nka_oracle *a, double *f) {
  *   b_by_slot    -- <f, w_j> indexed by slot j (w_first already normalised)
  * On return a->c holds the coefficients by slot, *new_slot the slot that
  * receives the new pair, and the list has `new_slot` prepended. */
-void nka_oracle_scalar_step(nka_oracle *a, int had_pending, double s,
+void NM(scalar_step)(nka_oracle *a, int had_pending, double s,
                             const double *hrow_by_slot, const double *b_by_slot,
                             int *new_slot) {
   (void)had_pending;
-  if (a->pending && s == 0.0) nka_oracle_relax(a);
+  if (a->pending && s == 0.0) NM(relax)(a);
   if (a->pending) {
     for (int k = a->next[a->first]; k != 0; k = a->next[k]) H(a, a->first, k) = hrow_by_slot[k];
     factor_with_drops(a);
@@ -328,7 +387,9 @@ void nka_oracle_scalar_step(nka_oracle *a, int had_pending, double s,
   *new_slot = slot;
 }
 
-void nka_oracle_get_state(const nka_oracle *a, int *subspace, int *pending,
+#endif /* !NKA_ORACLE_EXTENDED */
+
+void NM(get_state)(const nka_oracle *a, int *subspace, int *pending,
                           int *first, int *last, int *free_, int *next, int *prev,
                           double *h, double *c) {
   if (subspace) *subspace = a->subspace;
@@ -339,12 +400,14 @@ void nka_oracle_get_state(const nka_oracle *a, int *subspace, int *pending,
   for (int k = 1; k <= a->nslot; k++) {
     if (next) next[k - 1] = a->next[k];
     if (prev) prev[k - 1] = a->prev[k];
-    if (c) c[k - 1] = a->c[k];
+    if (c) c[k - 1] = (double)a->c[k];
   }
   if (h)
     for (int j = 1; j <= a->nslot; j++)
-      for (int i = 1; i <= a->nslot; i++) h[(i - 1) + (size_t)(j - 1) * a->nslot] = H(a, i, j);
+      for (int i = 1; i <= a->nslot; i++) h[(i - 1) + (size_t)(j - 1) * a->nslot] = (double)H(a, i, j);
 }
 
+#ifndef NKA_ORACLE_EXTENDED
 const double *nka_oracle_w(const nka_oracle *a, int slot) { return WV(a, slot); }
 const double *nka_oracle_v(const nka_oracle *a, int slot) { return VV(a, slot); }
+#endif

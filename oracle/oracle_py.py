@@ -63,6 +63,23 @@ def lib() -> C.CDLL:
         L.nka_oracle_v.argtypes = [C.c_void_p, C.c_int]
         L.nka_oracle_v.restype = _dp
         L.nka_oracle_scalar_step.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp, _dp, _ip]
+        # the same restatement in extended precision (nka_oracle_exact.c) and the error-attribution dots (nka_oracle_probe.c)
+        L.nka_oraclex_init.restype = C.c_void_p
+        L.nka_oraclex_init.argtypes = [C.c_int64, C.c_int, C.c_int]
+        L.nka_oraclex_delete.argtypes = [C.c_void_p]
+        L.nka_oraclex_set_vec_tol.argtypes = [C.c_void_p, C.c_double]
+        L.nka_oraclex_accel_update.argtypes = [C.c_void_p, _dp]
+        L.nka_oraclex_restart.argtypes = [C.c_void_p]
+        L.nka_oraclex_relax.argtypes = [C.c_void_p]
+        for name in ("num_vec", "max_vec", "defined"):
+            getattr(L, "nka_oraclex_" + name).argtypes = [C.c_void_p]
+            getattr(L, "nka_oraclex_" + name).restype = C.c_int
+        L.nka_oraclex_vec_len.argtypes = [C.c_void_p]
+        L.nka_oraclex_vec_len.restype = C.c_int64
+        L.nka_oraclex_vec_tol.argtypes = [C.c_void_p]
+        L.nka_oraclex_vec_tol.restype = C.c_double
+        L.nka_oraclex_get_state.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp]
+        L.nka_oracle_set_gram_from_raw_sums.argtypes = [C.c_void_p, C.c_int]
         L.nka_example_solve.restype = C.c_int
         L.nka_example_solve.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
                                         C.c_double, ACCEL_FN, C.c_void_p, _dp, _dp]
@@ -173,6 +190,89 @@ class OracleNKA:
         new = C.c_int()
         self._L.nka_oracle_scalar_step(self._h, 0, s, _ptr(hrow_by_slot), _ptr(b_by_slot), C.byref(new))
         return new.value
+
+
+class OracleExact(OracleNKA):
+    """The restatement in EXTENDED precision (oracle/nka_oracle_exact.c: nka_oracle.c compiled a second time with
+    long double arithmetic -- same statements, same list logic).  The "exact" trajectory against which the parity
+    tests measure both the reference's and the device's error.  No user dot product, no stored-vector access."""
+
+    def __init__(self, vlen: int, mvec: int, flavor: int = F08):      # noqa: super().__init__ not called on purpose
+        self._L = lib()
+        self._h = self._L.nka_oraclex_init(vlen, mvec, flavor)
+        if not self._h:
+            raise ValueError("nka_oraclex_init failed")
+        self.vlen, self.mvec = vlen, mvec
+        self._cb = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.nka_oraclex_delete(self._h)
+            self._h = None
+
+    def set_vec_tol(self, vtol: float):
+        self._L.nka_oraclex_set_vec_tol(self._h, vtol)
+
+    def set_dot_prod(self, fn):
+        raise NotImplementedError("the extended-precision flavour sums in extended precision itself")
+
+    def accel_update(self, f: np.ndarray):
+        assert f.shape == (self.vlen,)
+        self._L.nka_oraclex_accel_update(self._h, _ptr(f))
+
+    def restart(self):
+        self._L.nka_oraclex_restart(self._h)
+
+    def relax(self):
+        self._L.nka_oraclex_relax(self._h)
+
+    def num_vec(self):
+        return self._L.nka_oraclex_num_vec(self._h)
+
+    def max_vec(self):
+        return self._L.nka_oraclex_max_vec(self._h)
+
+    def vec_len(self):
+        return self._L.nka_oraclex_vec_len(self._h)
+
+    def vec_tol(self):
+        return self._L.nka_oraclex_vec_tol(self._h)
+
+    def defined(self):
+        return bool(self._L.nka_oraclex_defined(self._h))
+
+    def state(self) -> State:
+        n = self.mvec + 1
+        ints = [C.c_int() for _ in range(5)]
+        nxt = np.zeros(n, np.int32)
+        prv = np.zeros(n, np.int32)
+        h = np.zeros((n, n), np.float64)
+        c = np.zeros(n, np.float64)
+        self._L.nka_oraclex_get_state(self._h, *[C.byref(i) for i in ints],
+                                      nxt.ctypes.data_as(_ip), prv.ctypes.data_as(_ip), _ptr(h), _ptr(c))
+        return State(ints[0].value, ints[1].value, ints[2].value, ints[3].value, ints[4].value,
+                     nxt, prv, h.T.copy(), c)
+
+    def w(self, slot):
+        raise NotImplementedError
+
+    v = scalar_step = w
+
+
+def attribution_oracle(vlen: int, mvec: int, flavor: int = F08, fma=False, blocked=False, raw_sums=False) -> OracleNKA:
+    """The double restatement with the device path's deliberate deviations switched on one at a time
+    (oracle/nka_oracle_probe.c): fused multiply-adds in the inner products, the device's blocked summation order,
+    the Gram row as fl(<d,w_k>/s) from raw sums.  All three = the arithmetic of the device's inner products."""
+    a = OracleNKA(vlen, mvec, flavor)
+    L = a._L
+    fn = {(False, False): None, (True, False): L.nka_oracle_dot_fma, (False, True): L.nka_oracle_dot_blocked,
+          (True, True): L.nka_oracle_dot_device}[(bool(fma), bool(blocked))]
+    if fn is not None:
+        a._cb = C.cast(fn, DOT_FN)
+        L.nka_oracle_set_dot_prod(a._h, a._cb, None)
+    if raw_sums:
+        L.nka_oracle_set_gram_from_raw_sums(a._h, 1)
+    return a
 
 
 def example_solve(nx=50, ny=50, a=0.02, nsweep=2, omega=1.4, accel=None, maxitr=999, tol=1e-6):

@@ -80,7 +80,8 @@ def main():
             digs = nd.replica_digests(acc)
             assert all(d == digs[0] for d in digs), (rank, flavor, t, digs)
             err = np.linalg.norm(out - f_full[lo:hi]) / np.linalg.norm(x)
-            P.check(err, st, f"sharded rank {rank} flavor {flavor}", where=t, spread=spread.value)
+            P.check(err, st, f"sharded rank {rank} flavor {flavor}", where=t, spread=spread.value,
+                    truth=spread.truth(out, x, sl=slice(lo, hi)))
             if t == 9:
                 acc.relax(); full.relax(); spread.relax()
         assert acc.defined()

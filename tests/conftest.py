@@ -42,8 +42,14 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for key in sorted(P.WORST):
         r = P.WORST[key]
         piv = "   -  " if r["pivot"] is None else f"{r['pivot']:6.3f}"
-        k = f"; K needed {r['k_needed']:.2f} of {P.K_SPREAD:g}" if r.get("k_needed") else ""
-        tr.write_line(f"{key:<78s} worst {r['err']:.2e} (tol {r['tol']:.1e}, pivot {piv}, rule: {r.get('rule', '-')}); "
-                      f"well-conditioned worst {r['worst_well_conditioned']:.2e}; {r['checks']} checks{k}")
+        k = f"; spread diagnostic: K {r['k_needed']:.2f}" if r.get("k_needed") else ""
+        if r.get("err_dev_exact") is not None:
+            # THE rule: device vs the extended-precision trajectory, against the reference's own distance from it
+            tr.write_line(f"{key:<78s} dev-exact {r['err_dev_exact']:.2e} | ref-exact {r['err_ref_exact']:.2e} | tol {r['tol']:.1e} "
+                          f"({r.get('rule', '-')}; used {r.get('truth_ratio', 0.0):.2f} of the allowance) | dev-ref {r['err']:.2e}, "
+                          f"pivot {piv}; {r['checks']} checks{k}")
+        else:
+            tr.write_line(f"{key:<78s} worst {r['err']:.2e} (tol {r['tol']:.1e}, pivot {piv}, rule: {r.get('rule', '-')}); "
+                          f"well-conditioned worst {r['worst_well_conditioned']:.2e}; {r['checks']} checks{k}")
     if path:
         tr.write_line(f"written to {path}")

@@ -78,10 +78,15 @@ def test_tiled_oracle_equivalence_at_baseline_sizes(torch_cuda, oracle, n0, m, f
         assert acc.num_vec() == ora.num_vec(), (t, acc.num_vec(), ora.num_vec())
         assert acc.state().list_order() == ora.state().list_order()
         ref = torch.from_numpy(f).cuda().repeat(R)
-        err = float(torch.linalg.vector_norm(big - ref) / torch.linalg.vector_norm(torch.from_numpy(x).cuda().repeat(R)))
-        P.check(err, ora.state(), f"tiled oracle n={n} m={m} flavor {flavor}", base=TOL_FULL, where=t, spread=spread.value)
+        nx = float(torch.linalg.vector_norm(torch.from_numpy(x).cuda().repeat(R)))
+        err = float(torch.linalg.vector_norm(big - ref)) / nx
+        # the truth of the big problem is the tiled truth of the small one (exact arithmetic commutes with the tiling)
+        ex = torch.from_numpy(spread.exact).cuda().repeat(R)
+        truth = (float(torch.linalg.vector_norm(big - ex)) / nx, spread.err_ref)
+        P.check(err, ora.state(), f"tiled oracle n={n} m={m} flavor {flavor}", base=TOL_FULL, where=t, spread=spread.value,
+                truth=truth)
         worst = max(worst, err)
-        del big, ref
+        del big, ref, ex
     assert acc.defined()
     print(f"n={n} m={m} flavor={flavor}: worst rel err vs tiled oracle {worst:.2e}")
 
@@ -144,6 +149,8 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
     torch = torch_cuda
     n, m, calls = 20_000_000, 20, 27
     ref = oracle.RefF08(n, m)
+    exact = oracle.OracleExact(n, m)             # the same calls in extended precision: the truth (13 GB of host memory)
+    err_ref = 0.0
     accs = {0: nka_amd.nka().init(n, m, flavor=0), 2: nka_amd.nka().init(n, m, flavor=2)}
     basis = [synth.fill_numpy(77, j, 0, n, n) for j in range(3)]
     dev = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -156,19 +163,23 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
             x = synth.fill_numpy(12345, t, 0, n, n)
         xin = torch.from_numpy(x).cuda()
         nx = float(torch.linalg.vector_norm(xin))
+        fx = x.copy()
+        exact.accel_update(fx)
+        fex = torch.from_numpy(fx).cuda()
         f = x                                  # updated in place by the reference
         ref.accel_update(f)
         fref = torch.from_numpy(f).cuda()
+        err_ref = max(err_ref, float(torch.linalg.vector_norm(fref - fex)) / nx)     # the COMPILED reference's distance
         for flavor, acc in accs.items():
             dev.copy_(xin)
             acc.accel_update(dev)
             assert acc.num_vec() == ref.num_vec(), (flavor, t, acc.num_vec(), ref.num_vec())
             err = float(torch.linalg.vector_norm(dev - fref)) / nx
-            # spread=0.0: the stated 1e-10 is asserted UNSCALED on every call, ill-conditioned ones included
+            assert err <= TOL_FULL, (flavor, t, err)      # the stated 1e-10 against the reference itself, UNSCALED, every call
             P.check(err, acc.state(), f"non-periodic n=2e7 m=20 flavor {flavor} vs compiled src-F08", base=TOL_FULL, where=t,
-                    spread=0.0)
+                    spread=0.0, truth=(float(torch.linalg.vector_norm(dev - fex)) / nx, err_ref))
             worst[flavor] = max(worst[flavor], err)
-        del xin, fref
+        del xin, fref, fex
     assert ref.num_vec() == m
     for acc in accs.values():
         assert acc.defined()
@@ -205,7 +216,7 @@ def test_abstract_vector_flavour_at_baseline_config5_size(torch_cuda, oracle, tm
         assert dev == 0.0, (t, dev)            # every tile of the result carries the same bits
         err = np.linalg.norm(got - f) / np.linalg.norm(x)
         P.check(err, ora.state(), f"abstract vector 4x1e7 m=20 compact={compact} vs tiled oracle", base=TOL_FULL, where=t,
-                spread=spread.value)
+                spread=spread.value, truth=spread.truth(got, x))
         worst = max(worst, err)
     print(f"abstract-vector flavour n={n0 * R} m={m} compact={compact}: worst rel err vs tiled oracle {worst:.2e}")
 
@@ -249,8 +260,10 @@ def test_more_than_2_to_the_31_elements(torch_cuda, oracle, flavor):
         assert acc.num_vec() == ora.num_vec(), (t, acc.num_vec(), ora.num_vec())
         assert acc.state().list_order() == ora.state().list_order()
         err = _tiled_rel_err(torch, big, torch.from_numpy(f).cuda(), torch.from_numpy(x).cuda(), reps)
+        truth = (_tiled_rel_err(torch, big, torch.from_numpy(spread.exact).cuda(), torch.from_numpy(x).cuda(), reps),
+                 spread.err_ref)
         P.check(err, ora.state(), f"n = 2^31+256 m={m} flavor {flavor} vs tiled oracle", base=TOL_FULL, where=t,
-                spread=spread.value)
+                spread=spread.value, truth=truth)
         worst = max(worst, err)
         del big
     assert acc.defined()

@@ -65,14 +65,18 @@ def test_scenarios_decisions_exact_values_within_tolerance(torch_cuda, oracle, n
     assert acc.defined()
     assert np.array_equal(trace, g["num_vec"])                       # decisions: exact
     inputs = [g["inputs"][int(i)] for op, i, _ in g["ops"] if int(op) == S.OP_UPDATE]
-    spreads = P.fixture_spreads(g)          # the three REFERENCE outputs of the same calls (tolerance rule, parity_util)
+    spreads = P.fixture_spreads(g)          # the three REFERENCE outputs of the same calls (diagnostic "K needed")
+    # THE rule (parity_util): the device against the extended-precision trajectory, allowed twice the distance the
+    # COMPILED reference's own outputs (held by the fixture) have from it
+    exact, err_ref = P.fixture_truth(g, oracle)
     for u in range(len(outs)):
+        truth = (S.rel_err(outs[u], exact[u], inputs[u]), err_ref[u])
         P.check(S.rel_err(outs[u], g[key][u], inputs[u]), states[u], f"scenario {name} flavor {flavor} vs own reference",
-                where=u, spread=spreads[u])
+                where=u, spread=spreads[u], truth=truth)
         # every flavour -- the front ends' default C/compact one included -- against the
-        # reference FORTRAN path (src-F08) on the same inputs, same tolerance
+        # reference FORTRAN path (src-F08) on the same inputs, same rule
         P.check(S.rel_err(outs[u], g["f_out_f08"][u], inputs[u]), states[u],
-                f"scenario {name} flavor {flavor} vs src-F08 reference", where=u, spread=spreads[u])
+                f"scenario {name} flavor {flavor} vs src-F08 reference", where=u, spread=spreads[u], truth=truth)
     if "first" in g.files:                                           # list state of the C reference
         for u, st in enumerate(states):
             assert (st.first, st.last, st.free) == (g["first"][u], g["last"][u], g["free"][u]), (name, u)
@@ -256,7 +260,8 @@ def test_edge_shapes_against_oracle(torch_cuda, oracle, n, m, flavor):
         assert acc.state().list_order() == ora.state().list_order()
         assert acc.state().free_order() == ora.state().free_order()
         if n:
-            P.check(S.rel_err(out, f, x), acc.state(), f"edge shape n={n} m={m} flavor {flavor}", where=t, spread=spread.value)
+            P.check(S.rel_err(out, f, x), acc.state(), f"edge shape n={n} m={m} flavor {flavor}", where=t, spread=spread.value,
+                truth=spread.truth(out, x))
     assert acc.defined()
 
 
@@ -483,7 +488,8 @@ def test_against_the_live_compiled_reference(torch_cuda, oracle, seed, flavor):
         acc.accel_update(ft)
         assert acc.num_vec() == ref.num_vec(), (seed, flavor, t)
         err = P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(),
-                      f"live src-F08 reference n={n} m={m} flavor {flavor}", where=(seed, t), spread=spread.value)
+                      f"live src-F08 reference n={n} m={m} flavor {flavor}", where=(seed, t), spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
         worst = max(worst, err)
         if t == 20:
             ref.relax(); acc.relax(); spread.relax()
@@ -639,7 +645,8 @@ def test_randomised_call_sequences_against_oracle(torch_cuda, oracle, m, seed):
             nx = np.linalg.norm(x)
             if nx > 0:
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"random call sequence m={m} seed={seed}",
-                        where=(step, nupd), spread=spread.value)
+                        where=(step, nupd), spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
         elif r < 0.88:
             acc.relax(); ora.relax(); spread.relax()
         elif r < 0.93:

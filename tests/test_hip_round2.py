@@ -104,7 +104,8 @@ def test_user_dot_product_callback_matches_the_oracles_set_dot_prod_run(torch_cu
         ft = torch_cuda.from_numpy(x.copy()).cuda()
         acc.accel_update(ft)
         P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"after set_host_dot(None) flavor {flavor}", where=t,
-                spread=spread.value)
+                spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
 
 
 def test_state_digest_tracks_the_replicated_state(torch_cuda):
@@ -148,7 +149,8 @@ def test_large_mvec_up_to_the_lds_limit(torch_cuda, oracle, m):
         assert acc.num_vec() == ora.num_vec(), t
         if t % 8 == 0 or t > m:
             assert acc.state().list_order() == ora.state().list_order(), t
-            P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t, spread=spread.value)
+            P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), f"large mvec={m} n={n}", where=t, spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
     assert acc.defined() and acc.num_vec() == ora.num_vec() and acc.num_vec() >= m - 8   # a few dependence drops
 
 
@@ -174,7 +176,8 @@ def test_mvec_beyond_the_lds_limit_works_from_global_memory(torch_cuda, oracle, 
         assert acc.num_vec() == ora.num_vec(), t
         st = acc.state()
         assert st.list_order() == ora.state().list_order() and st.free_order() == ora.state().free_order(), t
-        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"mvec={m} beyond the LDS limit, n={n}", where=t, spread=spread.value)
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"mvec={m} beyond the LDS limit, n={n}", where=t, spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
         # the scalar step given the device's own sums: bit for bit (h by slot, coefficients)
         if t == 20:
             acc.relax(); ora.relax(); spread.relax()
@@ -568,7 +571,8 @@ def test_copy_in_mid_stream_gives_two_independent_accelerators(torch_cuda, oracl
         assert acc.num_vec() == ora.num_vec(), (key, t)
         st = acc.state()
         assert st.list_order() == ora.state().list_order() and st.free_order() == ora.state().free_order(), (key, t)
-        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"deep copy flavor {flavor} object {key}", where=t, spread=spread.value)
+        P.check(S.rel_err(ft.cpu().numpy(), f, x), st, f"deep copy flavor {flavor} object {key}", where=t, spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
 
     for t in range(m + 3):
         x = rng.standard_normal(n)

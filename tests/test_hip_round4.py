@@ -58,7 +58,8 @@ def test_list_word_tightens_the_launch_widths_and_changes_no_bit(torch_cuda, ora
         assert loose.list_bound() == min(t + 1, m + 1)                                # the plain count
         seen_short += tight.list_bound() < loose.list_bound()
         err = np.linalg.norm(ft.cpu().numpy() - f) / np.linalg.norm(x)
-        P.check(err, ora.state(), f"list word n={n} m={m} dim={dim} flavor {flavor}", base=1e-12, where=t, spread=spread.value)
+        P.check(err, ora.state(), f"list word n={n} m={m} dim={dim} flavor {flavor}", base=1e-12, where=t, spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
     assert seen_short >= m + 10 - (dim + 2) - 1          # from the first drop on the count is too long, the word is not
     assert tight.num_vec() == min(dim, m)
     assert tight.state_digest() == loose.state_digest()

@@ -100,7 +100,8 @@ def _check_against_unsharded_oracle(oracle, files, nfield, nper, mvec, ncalls, k
             loc = calls[t][3].reshape(nfield, hi - lo)
             for k in range(nfield):
                 got[k * nper + lo:k * nper + hi] = loc[k]
-        P.check(S.rel_err(got, f, x), st, key, where=t, spread=spread.value)
+        P.check(S.rel_err(got, f, x), st, key, where=t, spread=spread.value,
+                truth=spread.truth(got, x))
 
 
 @pytest.fixture(scope="module")

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--mvec", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--span-dim", type=int, default=0,
+                    help="D > 0: every input in a D-dimensional span (a dependence drop per update, the subspace holds D "
+                         "vectors) and one synchronisation per update, e.g. --key list_word --values 0 1")
     a = ap.parse_args()
     import torch
     import nka_amd
@@ -34,14 +37,31 @@ def main():
     acc = nka_amd.nka().init(n, m, flavor=fl)
     P = min(m + 6, 30)
     pool = torch.empty((P, n + (n % 2)), dtype=torch.float64, device="cuda")
-    for j in range(P):
-        synth.fill_torch(pool[j, :n], 12345, j, 0, n)
+    D = a.span_dim
+    if D > 0:
+        B = torch.empty((D, n), dtype=torch.float64, device="cuda")
+        for q in range(D):
+            synth.fill_torch(B[q], 777, q, 0, n)
+
+    def fill(j, t):
+        if D > 0:
+            coef = torch.from_numpy(synth.fill_numpy(60, t, 0, D, D)).cuda()
+            torch.mv(B.t(), coef, out=pool[j, :n])
+        else:
+            synth.fill_torch(pool[j, :n], 12345, t, 0, n)
+
+    def step(t):
+        fill(t % P, t)
+        acc.accel_update(pool[t % P, :n])
+        if D > 0:
+            torch.cuda.synchronize()
+
+    k_want = min(D, m) if D > 0 else m
     t = 0
     for _ in range(m + 3):
-        synth.fill_torch(pool[t % P, :n], 12345, t, 0, n)
-        acc.accel_update(pool[t % P, :n])
+        step(t)
         t += 1
-    assert acc.num_vec() == m
+    assert acc.num_vec() == k_want
     if a.combos:
         a.values = a.combos
         a.key = "combo"
@@ -56,15 +76,18 @@ def main():
                     acc.set_tuning(k_, int(v_))
             else:
                 acc.set_tuning(a.key, v)
+            step(t)                     # (one update under the new setting before the timed ones)
+            t += 1
             for _ in range(a.steps):
-                synth.fill_torch(pool[t % P, :n], 12345, t, 0, n)
-                acc.accel_update(pool[t % P, :n])
+                step(t)
                 t += 1
             ph = [acc.timing_ms(b) for b in range(a.steps)]
             res[v]["PA"].append(statistics.mean(p[0] for p in ph))
             res[v]["PB"].append(statistics.mean(p[2] for p in ph))
             res[v]["all"].append(statistics.mean(p[3] for p in ph))
-    assert acc.num_vec() == m
+    assert acc.num_vec() == k_want
+    if D > 0:
+        print(f"inputs in a {D}-dimensional span: num_vec = {k_want} of mvec = {m}; host bound on the list: {acc.list_bound()}")
     print(f"in-process A/B  key={a.key}  flavor={a.flavor} n={n} m={m}  {a.rounds} rounds x {a.steps} updates per variant")
     for v in a.values:
         d = res[v]

@@ -40,8 +40,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SIZES = [1, 2, 3, 7, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4097, 8191, 8193,
-         16385, 32767, 65537, 70001]
+from fuzz_ops import SIZES, array_ops, array_shape  # noqa: E402,F401
 
 
 def _pairwise_dot(x, y):
@@ -49,12 +48,7 @@ def _pairwise_dot(x, y):
 
 
 def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
-    rng = np.random.default_rng(seed + (50_000 if hostdot else 0))
-    n = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 70001))
-    if hostdot:
-        n = min(n, 8193)                                   # (2 + L vectors cross PCIe per update on this path)
-    m = int(rng.integers(1, 41))
-    flavor = int(rng.integers(0, 3))
+    rng, n, m, flavor = array_shape(seed, hostdot)
     key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}"
     acc = nka_amd.nka().init(n, m, flavor=flavor)
     ora = oracle.OracleNKA(n, m, flavor)
@@ -72,21 +66,9 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
             return _pairwise_dot(x, y)
         acc.set_host_dot(dp_a)
         ora.set_dot_prod(dp_o)
-    basis = rng.standard_normal((3, n))
-    prev = rng.standard_normal(n)
-    for step in range(steps):
-        r = rng.random()
-        if r < 0.80:
-            kind = rng.random()
-            if kind < 0.55:
-                x = rng.standard_normal(n)
-            elif kind < 0.85:
-                x = rng.standard_normal(3) @ basis
-            elif kind < 0.95:
-                x = prev.copy()
-            else:
-                x = np.zeros(n)
-            prev = x
+    for step, op in enumerate(array_ops(rng, n, steps)):
+        if op[0] == "update":
+            x = op[1]
             f = x.copy()
             ora.accel_update(f)
             if not hostdot:
@@ -98,15 +80,16 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
                 assert calls[0] == calls[1], (key, step, calls)
                 P.record(0.0, 0.0, key)
             elif np.linalg.norm(x) > 0:
-                P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value)
+                P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value,
+                truth=spread.truth(ft.cpu().numpy(), x))
             else:
                 assert np.array_equal(ft.cpu().numpy(), f), (key, step)     # a zero input returns a zero
-        elif r < 0.87:
+        elif op[0] == "relax":
             acc.relax(); ora.relax(); spread.relax()
-        elif r < 0.91:
+        elif op[0] == "restart":
             acc.restart(); ora.restart(); spread.restart()
-        elif r < 0.96:
-            vt = float(10.0 ** rng.uniform(-3, -0.3))
+        elif op[0] == "set_vec_tol":
+            vt = op[1]
             acc.set_vec_tol(vt); ora.set_vec_tol(vt); spread.set_vec_tol(vt)
         else:
             acc = acc.copy()                                # the original is released; the copy carries on
@@ -206,7 +189,8 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1):
             ora.accel_update(f)
             spread.update(arg)
             if np.linalg.norm(arg) > 0:
-                P.check(S.rel_err(got, f, arg), ora.state(), key, where=step, spread=spread.value)
+                P.check(S.rel_err(got, f, arg), ora.state(), key, where=step, spread=spread.value,
+                truth=spread.truth(got, arg))
             else:
                 assert np.array_equal(got, f), (key, step)
         elif code == 1:
@@ -270,7 +254,8 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60):
             nx = np.linalg.norm(x)
             if nx > 0:
                 # this rank's share of the global error (the slices' squares add up to the whole)
-                P.check(float(np.linalg.norm(out - f[lo:hi]) / nx), acc.state(), key, where=step, spread=spread.value)
+                P.check(float(np.linalg.norm(out - f[lo:hi]) / nx), acc.state(), key, where=step, spread=spread.value,
+                        truth=spread.truth(out, x, sl=slice(lo, hi)))
             else:
                 assert np.array_equal(out, f[lo:hi]), (key, step)
         elif r < 0.87:
