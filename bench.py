@@ -648,8 +648,7 @@ def main(argv=None):
         # per-phase HIP events on the kernel stream: every update at the headline size, every 4th
         # below 5e7 elements per GPU (four event records widen an update's kernel boundaries by
         # ~15 us: 0.2 % of a 6 ms update, but 2 % of a 0.9 ms shard update)
-        acc.set_tuning("timing_stride", ev_stride)
-        acc.set_timing(min(-(-K // ev_stride), 4096))
+        acc.set_timing(min(-(-K // ev_stride), 4096), stride=ev_stride)
         sync_all()
         t0 = time.perf_counter()
         for s in range(K):
@@ -717,8 +716,7 @@ def main(argv=None):
             torch.cuda.synchronize(dev)
             if a2.num_vec() != m2:
                 return {"error": "subspace not full"}
-            a2.set_tuning("timing_stride", 4)
-            a2.set_timing(-(-steps // 4))
+            a2.set_timing(-(-steps // 4), stride=4)
             # (inputs are re-used round robin: an accelerated f is as good an input as a fresh one for the traffic)
             t0 = time.perf_counter()
             for _ in range(steps):

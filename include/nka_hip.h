@@ -163,10 +163,6 @@ int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t 
  * rows by s = sqrt(red[0]).  With these a CPU restatement of the scalar step
  * can be checked bit for bit. */
 int nka_hip_get_reductions(nka_hip_t a, double *red_out);
-/* Diagnostic builds of the library (-DNKA_SOLVE_STAMPS) stamp the phases of the
- * one-wavefront scalar step with s_memtime; this returns the 16 stamps of the most
- * recent update (zeros in a normal build).  tools/solve_phases.py prints them. */
-int nka_hip_get_stamps(nka_hip_t a, double *out16);
 /* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
 int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);
 int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);
@@ -250,32 +246,17 @@ int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx);
  * update, first kernel start -> last kernel end. */
 int nka_hip_set_timing(nka_hip_t a, int32_t capacity);
 int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
+/* With timing on, record the events of every stride-th update only (1..1024; the first update after the call is a
+ * recorded one): four event records widen the kernel boundaries of an update by ~15 us, which matters below
+ * n ~ 1e7.  get_timing then counts recorded updates. */
+int nka_hip_set_timing_stride(nka_hip_t a, int32_t stride);
 
-/* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */
-int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_per_cu);
+/* The A/B switches and measurement aids of the builder's lab (kernel-variant selection, launch geometry, phase
+ * stamps, a PA-only timer) are NOT part of this library: they exist only in the diagnostic build
+ * libnka_hip_diag.so (-DNKA_DIAGNOSTIC) and are declared in include/nka_hip_diag.h. */
 
-/* DIAGNOSTIC.  Every choice below is made automatically; the switches exist
- * for A/B measurements inside one process (same allocations, same thermal state) and for the tests
- * that hold every kernel variant to the same bits.  No environment variable selects a variant.
- * "pa_pipe" / "pb_pipe": -1 automatic (default); 0 = every load of a tile in flight
- * (k_dots / k_combine, any list length); 201..204 = rolling window (k_dots_win /
- * k_combine_win, instantiated for every width 1..32) with 1..4 blocks per CU.
- * "pb_tickets": how the blocks of the rolling-window PB
- * get their tiles: -1 automatic (default: tickets from 64 tiles per block), 0 =
- * static mapping (tile t -> block t mod G), 1, 2, 4, 8 = from that many global
- * ticket counters, so that the blocks advance as one compact front.
- * "pb_tile" (-1 automatic, 1, 2): 512- or 1024-element tiles for the shortest lists (<= 14 words
- * per element and tile), where double-width tiles let one ticket counter serve the pass.
- * "serial_solve" = 0/1: the scalar step on one wavefront (k_solve_rows) or as the reference's loops on one lane.
- * Results are bit-identical across variants.
- * "timing_stride" = s (1..1024): with nka_hip_set_timing on, record the events of every
- * s-th update only (the first one after the call included): four event records widen
- * the kernel boundaries of an update by ~15 us, which matters below n ~ 1e7. */
-int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
-/* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,
- * launched `reps` times back to back (it only writes scratch: state unchanged). */
-int nka_hip_debug_time_pa(nka_hip_t a, const double *f_dev, int32_t reps, float *ms_mean);
+
 
 const char *nka_hip_last_error(void);
 /* Device pointers that cross this ABI are checked against their allocation before any launch
@@ -297,9 +278,6 @@ int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
 int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
-/* Diagnostic A/B switch like nka_hip_set_tuning: "tickets" = -1 automatic, 0 static tile mapping,
- * 1, 2, 4, 8 ticket counters for the combine stage (update_many_keep / axpy_many_keep). */
-int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value);
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
 int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);
 int nka_hip_vec_copy(nka_hip_vec_ws_t ws, int64_t n, double *dst, const double *src);          /* copy_   */

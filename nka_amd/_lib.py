@@ -35,7 +35,6 @@ SIGNATURES = {
     "nka_hip_flavor": (C.c_int, [C.c_void_p]),
     "nka_hip_get_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp, _dp]),
     "nka_hip_get_reductions": (C.c_int, [C.c_void_p, _dp]),
-    "nka_hip_get_stamps": (C.c_int, [C.c_void_p, _dp]),
     "nka_hip_get_w": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "nka_hip_get_v": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "nka_hip_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
@@ -49,15 +48,12 @@ SIGNATURES = {
     "nka_hip_set_host_dot": (C.c_int, [C.c_void_p, HOST_DOT_FN, C.c_void_p]),
     "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
-    "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
-    "nka_hip_debug_time_pa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "nka_hip_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int32]),
     "nka_hip_last_error": (C.c_char_p, []),
     "nka_hip_invalidate_pointer_cache": (None, []),
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "nka_hip_vec_workspace_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "nka_hip_vec_workspace_destroy": (C.c_int, [C.c_void_p]),
-    "nka_hip_vec_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nka_hip_vec_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "nka_hip_vec_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_vec_copy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -112,6 +108,39 @@ SIGNATURES.update({
     "nka_ex_residual_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nka_ex_pc_ssor_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
 })
+
+
+# include/nka_hip_diag.h: only in the diagnostic build libnka_hip_diag.so (-DNKA_DIAGNOSTIC)
+DIAG_SIGNATURES = {
+    "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_debug_time_pa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "nka_hip_get_stamps": (C.c_int, [C.c_void_p, _dp]),
+    "nka_hip_vec_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+}
+_DIAG = None
+
+
+def diag_lib_path() -> str:
+    return os.environ.get("NKA_HIP_DIAG_LIB") or os.path.join(HERE, "libnka_hip_diag.so")
+
+
+def load_diag() -> C.CDLL:
+    """The diagnostic build (product + the A/B switches of include/nka_hip_diag.h): tests that hold every kernel
+    variant to the same bits and the measurement tools use it; a second, independent copy of the library in the
+    process (its own handles: never mix them with the product's)."""
+    global _DIAG
+    if _DIAG is None:
+        path = diag_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: `make -C nka_amd/csrc diag` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _DIAG = L
+    return _DIAG
 
 
 def lib_path() -> str:

@@ -8,6 +8,9 @@
 // it can know without looking: whether a pair is pending, and an upper bound on
 // the list length (used to pick the unroll width of PA/PB).
 #include "../../include/nka_hip.h"
+#ifdef NKA_DIAGNOSTIC
+#include "../../include/nka_hip_diag.h"
+#endif
 #include "nka_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -311,7 +314,9 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
   // serves it beyond that (passes of 32) -- any other width reaches it only through the diagnostic switch pb_pipe = 0
   // and is padded to 32 (same bits).  The two-vector flavours use every width below the ticket threshold (enqueue_pb).
   if constexpr (COMB == 2) {
+#ifdef NKA_DIAGNOSTIC      // (the automatic rule sends every compact list of <= 32 pairs to the window kernel)
     if (maxk <= 4) return launch_combine_1<4, VEC, COMB>(a, f, pass, last);
+#endif
     return launch_combine_1<32, VEC, COMB>(a, f, pass, last);
   }
 #define CASE(K) \
@@ -1045,6 +1050,7 @@ int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t 
   return 0;
 }
 
+#ifdef NKA_DIAGNOSTIC
 // Diagnostic builds (-DNKA_SOLVE_STAMPS): the s_memtime stamps of the last scalar step.
 int nka_hip_get_stamps(nka_hip_t a, double *out16) {
   if (!a || !out16) return fail(NKA_HIP_EINVAL, "null argument");
@@ -1053,6 +1059,7 @@ int nka_hip_get_stamps(nka_hip_t a, double *out16) {
   HIP_TRY(hipStreamSynchronize(a->stream));
   return 0;
 }
+#endif  // NKA_DIAGNOSTIC
 
 int nka_hip_get_reductions(nka_hip_t a, double *red_out) {
   if (!a || !red_out) return fail(NKA_HIP_EINVAL, "null argument");
@@ -1261,6 +1268,15 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
   return 0;
 }
 
+int nka_hip_set_timing_stride(nka_hip_t a, int32_t stride) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (stride < 1 || stride > 1024) return fail(NKA_HIP_EINVAL, "timing stride: 1..1024");
+  a->timing_stride = stride;
+  a->update_seq = 0;
+  return 0;
+}
+
+#ifdef NKA_DIAGNOSTIC      // ---- the builder's lab: only in libnka_hip_diag.so (include/nka_hip_diag.h) ----
 int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   const int32_t v[2] = {pa, pb};
@@ -1307,10 +1323,6 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && !(value > 200 && value <= 204))
       return fail(NKA_HIP_EINVAL, "pa_pipe: -1 (auto), 0 (every load of a tile in flight), 201..204 (rolling window, 1..4 blocks per CU)");
     a->pa_pipe = value;
-  } else if (k == "timing_stride") {
-    if (value < 1 || value > 1024) return fail(NKA_HIP_EINVAL, "timing_stride: 1..1024");
-    a->timing_stride = value;
-    a->update_seq = 0;
   } else if (k == "pb_tile") {
     if (value != -1 && value != 1 && value != 2) return fail(NKA_HIP_EINVAL, "pb_tile: -1 (auto), 1, 2");
     a->pb_tile = value;
@@ -1328,6 +1340,7 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   }
   return 0;
 }
+#endif  // NKA_DIAGNOSTIC
 
 int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");

@@ -941,6 +941,7 @@ int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   return 0;
 }
 
+#ifdef NKA_DIAGNOSTIC      // only in libnka_hip_diag.so (include/nka_hip_diag.h)
 int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value) {
   if (!ws || !key) return nka_detail::set_error(NKA_HIP_EINVAL, "null argument");
   if (std::string(key) == "tickets") {
@@ -951,6 +952,7 @@ int nka_hip_vec_set_tuning(nka_hip_vec_ws_t ws, const char *key, int32_t value) 
   }
   return nka_detail::set_error(NKA_HIP_EINVAL, std::string("unknown tuning key: ") + key);
 }
+#endif  // NKA_DIAGNOSTIC
 
 int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev) {
   if (!ws || !out_dev || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");

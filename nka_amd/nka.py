@@ -23,9 +23,9 @@ class NKAError(RuntimeError):
     pass
 
 
-def _check(rc: int, what: str):
+def _check(rc: int, what: str, L=None):
     if rc != 0:
-        msg = _lib.load().nka_hip_last_error()
+        msg = (L or _lib.load()).nka_hip_last_error()        # (the error text lives in the library that failed)
         raise NKAError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
@@ -55,9 +55,13 @@ class State:
 class nka:  # noqa: N801  (the reference's type name)
     """MI355X accelerator object; see module docstring."""
 
-    def __init__(self):
+    def __init__(self, diagnostic: bool = False):
+        """diagnostic=True: an object of the diagnostic build (libnka_hip_diag.so: the product plus set_tuning /
+        set_grid, include/nka_hip_diag.h) -- for the tests that hold every kernel variant to the same bits and for
+        the A/B tools."""
         self._h = None
-        self._L = _lib.load()      # raises if the HIP library is missing: no CPU path
+        self._diag = bool(diagnostic)
+        self._L = _lib.load_diag() if diagnostic else _lib.load()      # raises if the HIP library is missing: no CPU path
         self._cb = None
         self._hd = None
 
@@ -82,7 +86,7 @@ class nka:  # noqa: N801  (the reference's type name)
             stream = torch.cuda.current_stream(device).cuda_stream
         h = C.c_void_p()
         _check(self._L.nka_hip_create(C.byref(h), int(vlen), int(mvec), 0.01, int(flavor), int(device),
-                                      C.c_void_p(stream)), "nka_hip_create")
+                                      C.c_void_p(stream)), "nka_hip_create", self._L)
         self._h, self._device, self._vlen, self._mvec = h, device, int(vlen), int(mvec)
         self._stream, self._follow_torch_stream = int(stream), explicit_stream is None
         return self
@@ -93,9 +97,9 @@ class nka:  # noqa: N801  (the reference's type name)
         factor and tolerance; the two then evolve separately.  Python-level hooks
         (set_dot_prod, set_host_dot) are carried over; the built-in RCCL communicator
         is not (nka_hip_clone)."""
-        other = nka()
+        other = nka(diagnostic=self._diag)
         h = C.c_void_p()
-        _check(self._L.nka_hip_clone(self._handle(), C.byref(h)), "nka_hip_clone")
+        _check(self._L.nka_hip_clone(self._handle(), C.byref(h)), "nka_hip_clone", self._L)
         other._h, other._device, other._vlen, other._mvec = h, self._device, self._vlen, self._mvec
         other._stream, other._follow_torch_stream = self._stream, self._follow_torch_stream
         other._cb, other._hd = self._cb, self._hd          # keep the ctypes trampolines alive
@@ -124,7 +128,7 @@ class nka:  # noqa: N801  (the reference's type name)
 
     # -- call a%set_vec_tol(vtol)                     F08:202-207
     def set_vec_tol(self, vtol: float):
-        _check(self._L.nka_hip_set_vec_tol(self._handle(), float(vtol)), "set_vec_tol")
+        _check(self._L.nka_hip_set_vec_tol(self._handle(), float(vtol)), "set_vec_tol", self._L)
 
     # -- call a%set_dot_prod(dot_prod)                F08:209-214
     def set_dot_prod(self, allreduce):
@@ -135,7 +139,7 @@ class nka:  # noqa: N801  (the reference's type name)
         ordered on `stream`.  None restores the single-rank default."""
         if allreduce is None:
             self._cb = None
-            _check(self._L.nka_hip_set_allreduce(self._handle(), C.cast(None, _lib.ALLREDUCE_FN), None), "set_allreduce")
+            _check(self._L.nka_hip_set_allreduce(self._handle(), C.cast(None, _lib.ALLREDUCE_FN), None), "set_allreduce", self._L)
             return
 
         def tramp(_ctx, buf, count, stream):
@@ -148,7 +152,7 @@ class nka:  # noqa: N801  (the reference's type name)
                 return 1
 
         self._cb = _lib.ALLREDUCE_FN(tramp)
-        _check(self._L.nka_hip_set_allreduce(self._handle(), self._cb, None), "set_allreduce")
+        _check(self._L.nka_hip_set_allreduce(self._handle(), self._cb, None), "set_allreduce", self._L)
 
     def set_host_dot(self, dot):
         """Source compatibility with the reference's user dot product
@@ -159,7 +163,7 @@ class nka:  # noqa: N801  (the reference's type name)
         device sums."""
         if dot is None:
             self._hd = None
-            _check(self._L.nka_hip_set_host_dot(self._handle(), C.cast(None, _lib.HOST_DOT_FN), None), "set_host_dot")
+            _check(self._L.nka_hip_set_host_dot(self._handle(), C.cast(None, _lib.HOST_DOT_FN), None), "set_host_dot", self._L)
             return
 
         def tramp(_ctx, n, x, y):
@@ -168,21 +172,21 @@ class nka:  # noqa: N801  (the reference's type name)
             return float(dot(xa, ya))
 
         self._hd = _lib.HOST_DOT_FN(tramp)
-        _check(self._L.nka_hip_set_host_dot(self._handle(), self._hd, None), "set_host_dot")
+        _check(self._L.nka_hip_set_host_dot(self._handle(), self._hd, None), "set_host_dot", self._L)
 
     def use_rccl(self, unique_id: bytes, nranks: int, rank: int):
         """Built-in hook: ONE RCCL all-reduce per update on the object's stream."""
         buf = C.create_string_buffer(unique_id, 128)
-        _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank")
+        _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank", self._L)
 
     def comm_info(self):
         """(nranks, rank) as the handle's built-in RCCL communicator reports them; (0, -1) without one."""
         n, r = C.c_int32(), C.c_int32()
-        _check(self._L.nka_hip_comm_info(self._handle(), C.byref(n), C.byref(r)), "comm_info")
+        _check(self._L.nka_hip_comm_info(self._handle(), C.byref(n), C.byref(r)), "comm_info", self._L)
         return int(n.value), int(r.value)
 
     def drop_rccl(self):
-        _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy")
+        _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy", self._L)
 
     @staticmethod
     def default_flavor() -> int:
@@ -202,13 +206,13 @@ class nka:  # noqa: N801  (the reference's type name)
 
     def allreduce_now(self, t):
         """Run the installed all-reduce hook on a float64 CUDA tensor (in place)."""
-        _check(self._L.nka_hip_allreduce_now(self._handle(), C.c_void_p(t.data_ptr()), int(t.numel())), "allreduce_now")
+        _check(self._L.nka_hip_allreduce_now(self._handle(), C.c_void_p(t.data_ptr()), int(t.numel())), "allreduce_now", self._L)
         return t
 
     def state_digest(self) -> int:
         """Digest of the replicated scalar state; equal on every rank of a sharded run."""
         d = C.c_uint64()
-        _check(self._L.nka_hip_state_digest(self._handle(), C.byref(d)), "state_digest")
+        _check(self._L.nka_hip_state_digest(self._handle(), C.byref(d)), "state_digest", self._L)
         return int(d.value)
 
     @staticmethod
@@ -226,7 +230,7 @@ class nka:  # noqa: N801  (the reference's type name)
         if isinstance(f, np.ndarray):
             if f.dtype != np.float64 or not f.flags["C_CONTIGUOUS"] or f.size != self._vlen:
                 raise NKAError("accel_update: need a contiguous float64 array of vec_len() elements")
-            _check(self._L.nka_hip_accel_update_host(h, C.c_void_p(f.ctypes.data)), "accel_update_host")
+            _check(self._L.nka_hip_accel_update_host(h, C.c_void_p(f.ctypes.data)), "accel_update_host", self._L)
             return f
         import torch
         if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float64 and f.is_contiguous()
@@ -238,7 +242,7 @@ class nka:  # noqa: N801  (the reference's type name)
             cur = int(torch.cuda.current_stream(self._device).cuda_stream)
             if cur != self._stream:
                 self.set_stream(cur)
-        _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update")
+        _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update", self._L)
         return f
 
     def capture_safe(self) -> bool:
@@ -256,15 +260,15 @@ class nka:  # noqa: N801  (the reference's type name)
 
     def set_stream(self, stream: int):
         """Rebind to another hipStream_t; earlier work stays ordered before later work."""
-        _check(self._L.nka_hip_set_stream(self._handle(), C.c_void_p(int(stream))), "set_stream")
+        _check(self._L.nka_hip_set_stream(self._handle(), C.c_void_p(int(stream))), "set_stream", self._L)
         self._stream = int(stream)
 
     # -- call a%restart() / a%relax()                 F08:422-457
     def restart(self):
-        _check(self._L.nka_hip_restart(self._handle()), "restart")
+        _check(self._L.nka_hip_restart(self._handle()), "restart", self._L)
 
     def relax(self):
-        _check(self._L.nka_hip_relax(self._handle()), "relax")
+        _check(self._L.nka_hip_relax(self._handle()), "relax", self._L)
 
     # -- accessors                                    F08:221-246
     def num_vec(self) -> int:
@@ -300,45 +304,53 @@ class nka:  # noqa: N801  (the reference's type name)
         c = np.zeros(n, np.float64)
         _check(self._L.nka_hip_get_state(self._handle(), *[C.byref(i) for i in ints],
                                          nxt.ctypes.data_as(_lib._i32p), prv.ctypes.data_as(_lib._i32p),
-                                         h.ctypes.data_as(_lib._dp), c.ctypes.data_as(_lib._dp)), "get_state")
+                                         h.ctypes.data_as(_lib._dp), c.ctypes.data_as(_lib._dp)), "get_state", self._L)
         return State(ints[0].value, ints[1].value, ints[2].value, ints[3].value, ints[4].value, nxt, prv,
                      h.T.copy(), c)
 
     def reductions(self) -> np.ndarray:
         """[<d,d>, <f,d>, <d,w_p>..., <f,w_p>...] (d = w1 - f) of the most recent update."""
         out = np.zeros(2 + 2 * self._mvec)
-        _check(self._L.nka_hip_get_reductions(self._handle(), out.ctypes.data_as(_lib._dp)), "get_reductions")
+        _check(self._L.nka_hip_get_reductions(self._handle(), out.ctypes.data_as(_lib._dp)), "get_reductions", self._L)
         return out
 
     def w(self, slot: int) -> np.ndarray:
         out = np.zeros(self._vlen)
-        _check(self._L.nka_hip_get_w(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_w")
+        _check(self._L.nka_hip_get_w(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_w", self._L)
         return out
 
     def v(self, slot: int) -> np.ndarray:
         out = np.zeros(self._vlen)
-        _check(self._L.nka_hip_get_v(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_v")
+        _check(self._L.nka_hip_get_v(self._handle(), slot, out.ctypes.data_as(_lib._dp)), "get_v", self._L)
         return out
 
-    def set_timing(self, capacity: int = 1):
-        """Keep HIP-event timings of the last `capacity` updates (0 = off)."""
-        _check(self._L.nka_hip_set_timing(self._handle(), int(capacity)), "set_timing")
+    def set_timing(self, capacity: int = 1, stride: int = 1):
+        """Keep HIP-event timings of the last `capacity` recorded updates (0 = off); with `stride` > 1 only every
+        stride-th update is recorded (four event records widen an update by ~15 us: matters below n ~ 1e7)."""
+        _check(self._L.nka_hip_set_timing(self._handle(), int(capacity)), "set_timing", self._L)
+        _check(self._L.nka_hip_set_timing_stride(self._handle(), int(stride)), "set_timing_stride", self._L)
 
     def timing_ms(self, back: int = 0):
         """(PA dots, solve, PB combine, whole update) in ms for the update `back` calls ago."""
         ms = (C.c_float * 4)()
-        _check(self._L.nka_hip_get_timing(self._handle(), int(back), ms), "get_timing")
+        _check(self._L.nka_hip_get_timing(self._handle(), int(back), ms), "get_timing", self._L)
         return tuple(ms)
 
+    def _need_diag(self, what):
+        if not self._diag:
+            raise NKAError(f"{what} exists only in the diagnostic build: construct the object with nka(diagnostic=True)")
+
     def set_grid(self, pa=0, pb=0):
-        _check(self._L.nka_hip_set_grid(self._handle(), pa, pb), "set_grid")
+        self._need_diag("set_grid")
+        _check(self._L.nka_hip_set_grid(self._handle(), pa, pb), "set_grid", self._L)
 
     def set_tuning(self, key: str, value: int):
-        """Kernel-variant switch for in-process A/B measurements (nka_hip_set_tuning)."""
-        _check(self._L.nka_hip_set_tuning(self._handle(), key.encode(), int(value)), "set_tuning")
+        """Kernel-variant switch for in-process A/B measurements (nka_hip_set_tuning, include/nka_hip_diag.h)."""
+        self._need_diag("set_tuning")
+        _check(self._L.nka_hip_set_tuning(self._handle(), key.encode(), int(value)), "set_tuning", self._L)
 
     def device_info(self):
         name = C.create_string_buffer(64)
         ncu = C.c_int32()
-        _check(self._L.nka_hip_device_info(self._handle(), name, C.byref(ncu)), "device_info")
+        _check(self._L.nka_hip_device_info(self._handle(), name, C.byref(ncu)), "device_info", self._L)
         return name.value.decode(), ncu.value

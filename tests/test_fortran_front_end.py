@@ -143,10 +143,11 @@ def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_b
             ref.accel_update(full)
             assert nv == ref.num_vec(), (t, nv, ref.num_vec())
             # whole array, ghosts included, against the reference's own ghost handling
-            # (ghosts included: no extended-precision trajectory of the reference's grid_vector exists -- the interior is
-            #  held to the truth rule above, the whole array to the compiled reference within the spread rule)
-            P.check(S.rel_err(got.ravel(), full, x.ravel()), ora.state(), key + " whole array vs compiled reference",
-                    where=t, spread=spread.value)
+            # (ghosts included.  No extended-precision run of the reference's grid_vector exists; the interior is held
+            #  to the truth rule above -- device within 2 err_ref of the truth, the reference err_ref from it -- so the
+            #  two may differ by 3 err_ref; the ghost values see the same coefficients)
+            P.record(S.rel_err(got.ravel(), full, x.ravel()), max(1e-12, 3.0 * spread.err_ref),
+                     key + " whole array vs compiled reference")
 
 
 @pytest.mark.gpu

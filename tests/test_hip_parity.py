@@ -577,7 +577,7 @@ def test_steady_state_update_is_hipgraph_capturable(torch_cuda, n, tickets):
         t = torch.from_numpy(x.copy()).cuda()
         ref.accel_update(t)
         want.append(t.cpu().numpy())
-    acc = nka_amd.nka().init(n, m)
+    acc = nka_amd.nka(diagnostic=tickets >= 0).init(n, m)
     if tickets >= 0:
         acc.set_tuning("pb_pipe", 201)
         acc.set_tuning("pb_tickets", tickets)

@@ -352,7 +352,9 @@ def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
     X[m + 3] = X[m + 2].copy()                      # s == 0 -> relax inside the update
 
     def run(settings):
-        acc = nka_amd.nka().init(n, m, flavor=flavor)
+        # the automatic choice runs in the PRODUCT library, every forced variant in the diagnostic build of the same
+        # sources (include/nka_hip_diag.h): the two builds are thereby held to the same bits as well
+        acc = nka_amd.nka(diagnostic=bool(settings)).init(n, m, flavor=flavor)
         for k, v in settings.items():
             acc.set_tuning(k, v)
         outs = []
@@ -383,7 +385,10 @@ def test_every_kernel_variant_is_bit_identical(torch_cuda, flavor, n, m):
             assert got[1] == ref[1], settings        # digest of the whole control blocks incl. the reduced sums
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), settings
     with pytest.raises(nka_amd.NKAError):
-        nka_amd.nka().init(16, 2).set_tuning("pa_pipe", 7)
+        nka_amd.nka(diagnostic=True).init(16, 2).set_tuning("pa_pipe", 7)
+    with pytest.raises(nka_amd.NKAError):                # the product has no such switch
+        nka_amd.nka().init(16, 2).set_tuning("pa_pipe", 0)
+    assert not hasattr(nka_amd.load(), "nka_hip_set_tuning") and not hasattr(nka_amd.load(), "nka_hip_set_grid")
 
 
 @pytest.mark.parametrize("flavor", [0, 1, 2])
@@ -402,7 +407,7 @@ def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
     X[m + 2] = X[m + 1].copy()                      # s == 0 -> relax inside the update
 
     def run(tickets, tile=1):
-        acc = nka_amd.nka().init(n, m, flavor=flavor)
+        acc = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor)
         acc.set_tuning("pb_pipe", 201)
         acc.set_tuning("pb_tickets", tickets)
         acc.set_tuning("pb_tile", tile)            # 2: double-width tiles (short lists only)
@@ -426,7 +431,7 @@ def test_tile_tickets_leave_every_bit_unchanged(torch_cuda, flavor):
         assert got[1] == ref[1], (tickets, tile)
         assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), (tickets, tile)
     with pytest.raises(nka_amd.NKAError):
-        nka_amd.nka().init(16, 2).set_tuning("pb_tickets", 3)
+        nka_amd.nka(diagnostic=True).init(16, 2).set_tuning("pb_tickets", 3)
 
 
 def test_tile_tickets_soak(torch_cuda):
@@ -440,7 +445,7 @@ def test_tile_tickets_soak(torch_cuda):
     n, m = 256 * 512 * 6 + 311, 4
     accs = []
     for tickets, tile in ((0, 1), (1, 1), (2, 2)):
-        a = nka_amd.nka().init(n, m, flavor=nka_amd.FLAVOR_C)
+        a = nka_amd.nka(diagnostic=True).init(n, m, flavor=nka_amd.FLAVOR_C)
         a.set_tuning("pb_pipe", 201)
         a.set_tuning("pb_tickets", tickets)
         a.set_tuning("pb_tile", tile)
@@ -472,9 +477,9 @@ def test_automatic_tickets_at_the_threshold_sizes(torch_cuda, flavor, m, n):
     X = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1 for _ in range(m + 3)]
     outs = []
     for tickets in (0, -1):
-        acc = nka_amd.nka().init(n, m, flavor=flavor)
-        acc.set_tuning("pb_tickets", tickets)
+        acc = nka_amd.nka(diagnostic=(tickets == 0)).init(n, m, flavor=flavor)      # -1: the product's automatic choice
         if tickets == 0:
+            acc.set_tuning("pb_tickets", 0)
             acc.set_tuning("pb_pipe", 201)
             acc.set_tuning("pb_tile", 1)
         res = []

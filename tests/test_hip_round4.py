@@ -37,7 +37,7 @@ def test_list_word_tightens_the_launch_widths_and_changes_no_bit(torch_cuda, ora
     torch = torch_cuda
     X = span_inputs(n, m + 10, dim, seed=31 * m + flavor)
     tight = nka_amd.nka().init(n, m, flavor=flavor)
-    loose = nka_amd.nka().init(n, m, flavor=flavor)
+    loose = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor)       # (libnka_hip_diag.so: include/nka_hip_diag.h)
     loose.set_tuning("list_word", 0)                 # the behaviour before round 4: the host's own count only
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)

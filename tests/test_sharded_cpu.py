@@ -59,6 +59,16 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libnka_hip.so lacks {name}"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    # the builder's lab is NOT in the product: include/nka_hip_diag.h <-> libnka_hip_diag.so only
+    dh = open(os.path.join(ROOT, "include", "nka_hip_diag.h")).read()
+    lab = set(re.findall(r"\b(nka_hip_[a-z0-9_]+)\s*\(", dh))
+    assert lab == set(_lib.DIAG_SIGNATURES), lab ^ set(_lib.DIAG_SIGNATURES)
+    D = _lib.load_diag()
+    for name in sorted(lab):
+        assert hasattr(D, name), f"libnka_hip_diag.so lacks {name}"
+        assert not hasattr(L, name), f"libnka_hip.so exports the diagnostic entry {name}"
+    for name in sorted(declared):
+        assert hasattr(D, name), f"libnka_hip_diag.so lacks {name}"
 
 
 def test_c_drop_in_library_exports_the_nine_reference_symbols():

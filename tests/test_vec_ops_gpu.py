@@ -24,6 +24,20 @@ def ws():
     L.nka_hip_vec_workspace_destroy(h)
 
 
+@pytest.fixture(scope="module")
+def ws_diag():
+    """A workspace of the DIAGNOSTIC build (libnka_hip_diag.so): the tests that force the combine stage onto 0 / 1 / 2 / 8
+    ticket counters (nka_hip_vec_set_tuning, include/nka_hip_diag.h); -1 there is the product's automatic rule."""
+    import torch
+    from nka_amd import _lib
+    torch.cuda.set_device(0)
+    L = _lib.load_diag()
+    h = C.c_void_p()
+    assert L.nka_hip_vec_workspace_create(C.byref(h), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    yield L, h, torch
+    L.nka_hip_vec_workspace_destroy(h)
+
+
 def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -131,10 +145,11 @@ def test_unaligned_operands_take_the_scalar_path(ws):
                          # every unroll width of the rolling-window kernels (exact widths 1..24, ring sizes 1..23);
                          # 300 007 elements = 586 tiles over 256 blocks: the window crosses tile boundaries
                          [(300007, c, c % 2) for c in range(1, 25)])
-def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, subtract):
+def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws_diag, n, count, subtract):
     """update_norm2, scale_dot_pair_many, update_many_keep, axpy_many_keep: stored
     vectors BIT-EXACT against the sequences of deferred-hook expressions they
     fuse (F08V:237-238, 255-264, 336+374+382), reductions within tolerance."""
+    ws = ws_diag
     L, h, torch = ws
     rng = np.random.default_rng(7 * n + count)
     dp = C.POINTER(C.c_double)
@@ -206,7 +221,7 @@ def test_fused_stage_hooks_equal_the_hook_sequences_they_replace(ws, n, count, s
 @pytest.mark.parametrize("n,count,pre,tickets", [(1, 1, 1, -1), (513, 1, 0, -1), (4099, 4, 1, -1), (100003, 21, 1, -1),
                                                  (100003, 24, 0, -1), (100003, 25, 1, -1), (300007, 7, 1, 1), (1100003, 21, 1, 2),
                                                  (777, 23, 1, -1)])
-def test_deferred_normalisation_equals_the_storing_stages(ws, n, count, pre, tickets, unaligned):
+def test_deferred_normalisation_equals_the_storing_stages(ws_diag, n, count, pre, tickets, unaligned):
     """The scale-and-dot stage as a pure read (dot_pair_many_scaled) followed by a
     combine that normalises the pending pair itself (update_many_keep_pend /
     axpy_many_keep_pend) must leave EVERY bit where the storing stages
@@ -214,6 +229,7 @@ def test_deferred_normalisation_equals_the_storing_stages(ws, n, count, pre, tic
     pair, f, both kept copies, and the three rows of inner products.  `count` counts
     the pending pair; 16-byte path and (unaligned = 1) the 8-byte fallback; with
     the tiles of the combine taken from ticket counters where the size allows."""
+    ws = ws_diag
     L, h, torch = ws
     rng = np.random.default_rng(11 * n + count + pre)
     dp = C.POINTER(C.c_double)

@@ -34,7 +34,7 @@ def main():
     from nka_amd import synth
     n, m = int(a.vlen), a.mvec
     fl = {"f08": nka_amd.FLAVOR_F08, "c": nka_amd.FLAVOR_C, "f08vec": nka_amd.FLAVOR_F08_VECTOR}[a.flavor]
-    acc = nka_amd.nka().init(n, m, flavor=fl)
+    acc = nka_amd.nka(diagnostic=True).init(n, m, flavor=fl)      # libnka_hip_diag.so: the A/B switches
     P = min(m + 6, 30)
     pool = torch.empty((P, n + (n % 2)), dtype=torch.float64, device="cuda")
     D = a.span_dim

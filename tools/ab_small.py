@@ -38,7 +38,7 @@ def main():
         for nf in a.vlens:
             n = int(nf)
             B = a.block if n <= 2e7 else 16
-            acc = nka_amd.nka().init(n, m, flavor=fl)
+            acc = nka_amd.nka(diagnostic=True).init(n, m, flavor=fl)
             pool0 = torch.empty((B, n + (n % 2)), dtype=torch.float64, device="cuda")
             for j in range(B):
                 synth.fill_torch(pool0[j, :n], 12345, j, 0, n)

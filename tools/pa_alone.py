@@ -12,13 +12,13 @@ import nka_amd  # noqa: E402
 from nka_amd import synth  # noqa: E402
 
 n, m = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8, 20
-acc = nka_amd.nka().init(n, m, flavor=nka_amd.FLAVOR_C)
+acc = nka_amd.nka(diagnostic=True).init(n, m, flavor=nka_amd.FLAVOR_C)
 f = torch.empty(n, dtype=torch.float64, device="cuda")
 for t in range(m + 3):
     synth.fill_torch(f, 12345, t, 0, n)
     acc.accel_update(f)
 synth.fill_torch(f, 12345, 99, 0, n)
-L = nka_amd.load()
+L = acc._L          # libnka_hip_diag.so (nka_hip_debug_time_pa: include/nka_hip_diag.h)
 for v in [int(x) for x in (sys.argv[2:] or ["0", "201", "202"])]:
     acc.set_tuning("pa_pipe", v)
     ms = C.c_float()

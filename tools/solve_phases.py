@@ -3,7 +3,7 @@
 build of the library with s_memtime stamps:
 
   make -C nka_amd/csrc stamps
-  NKA_HIP_LIB=$PWD/nka_amd/libnka_hip_stamps.so python tools/solve_phases.py [--mvec 20] [--vlen 1e5]
+  NKA_HIP_DIAG_LIB=$PWD/nka_amd/libnka_hip_stamps.so python tools/solve_phases.py [--mvec 20] [--vlen 1e5]
 """
 import argparse
 import ctypes as C
@@ -27,8 +27,9 @@ def main():
     import torch
     import nka_amd
     n, m = int(a.vlen), a.mvec
-    acc = nka_amd.nka().init(n, m)
-    L = nka_amd.load()
+    # the stamps build IS a diagnostic build: NKA_HIP_DIAG_LIB=nka_amd/libnka_hip_stamps.so (make stamps)
+    acc = nka_amd.nka(diagnostic=True).init(n, m)
+    L = acc._L
     rng = np.random.default_rng(0)
     rows = []
     pa_rows = []
