@@ -56,6 +56,11 @@ int fail(int code, const std::string &msg) {
 namespace nka_detail {
 // shared with vec_ops.hip: one thread-local error string per library
 int set_error(int code, const std::string &msg) { return fail(code, msg); }
+std::string last_error() { return g_err; }
+bool &span_check_failed() {
+  thread_local bool flag = false;
+  return flag;
+}
 
 // A kernel reading past a caller's buffer faults the GPU (and can take the node
 // with it), so every device pointer that crosses the ABI is checked on the host
@@ -75,20 +80,33 @@ void invalidate_span_cache() { g_span_generation.fetch_add(1, std::memory_order_
 
 namespace {
 std::mutex g_reg_mu;
-std::map<uintptr_t, size_t> g_reg;     // base address -> bytes, allocations made through this library
+struct RegEntry { size_t bytes; const void *owner; };
+std::map<uintptr_t, RegEntry> g_reg;   // base address -> (bytes, owning workspace), allocations made through this library
 }  // namespace
-void register_allocation(const void *p, size_t bytes) {
+void register_allocation(const void *p, size_t bytes, const void *owner) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_reg_mu);
-  g_reg[reinterpret_cast<uintptr_t>(p)] = bytes;
+  g_reg[reinterpret_cast<uintptr_t>(p)] = RegEntry{bytes, owner};
 }
 void unregister_allocation(const void *p) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_reg_mu);
   g_reg.erase(reinterpret_cast<uintptr_t>(p));
 }
+// A workspace that goes away takes its entries with it: vectors it handed out can no longer be freed through the
+// library, so an entry left behind would vouch for whatever is allocated at that address later.
+void unregister_owner(const void *owner) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (auto it = g_reg.begin(); it != g_reg.end();) it = (it->second.owner == owner) ? g_reg.erase(it) : std::next(it);
+}
 
+static int check_device_span_impl(const void *p, int64_t n, const char *what);
 int check_device_span(const void *p, int64_t n, const char *what) {
+  const int rc = check_device_span_impl(p, n, what);
+  if (rc) span_check_failed() = true;
+  return rc;
+}
+static int check_device_span_impl(const void *p, int64_t n, const char *what) {
   static const int mode = [] {      // 0 off, 1 strict (default), 2 cached
     const char *e = getenv("NKA_HIP_CHECK_POINTERS");
     if (e && e[0] == '0') return 0;
@@ -99,15 +117,20 @@ int check_device_span(const void *p, int64_t n, const char *what) {
   if (!p) return fail(NKA_HIP_EINVAL, std::string(what) + ": NULL device pointer");
   const size_t need = (size_t)n * sizeof(double);
   const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+  bool hit_in_registry = false;
   {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_reg.upper_bound(addr);
     if (it != g_reg.begin()) {
       --it;
-      if (addr < it->first + it->second) {            // inside an allocation of this library
-        if (addr + need > it->first + it->second)
+      if (addr < it->first + it->second.bytes) {      // inside an allocation of this library
+        if (addr + need > it->first + it->second.bytes)
           return fail(NKA_HIP_EINVAL, std::string(what) + ": device buffer shorter than the vector length");
-        return 0;
+        // NKA_HIP_DEBUG=1: do not take the registry's word for it (memory released behind the library's back --
+        // hipFree, hipDeviceReset -- leaves a stale entry): ask the runtime as for a foreign pointer
+        static const bool revalidate = [] { const char *e = getenv("NKA_HIP_DEBUG"); return e && atoi(e) != 0; }();
+        if (!revalidate) return 0;
+        hit_in_registry = true;
       }
     }
   }
@@ -126,7 +149,8 @@ int check_device_span(const void *p, int64_t n, const char *what) {
   size_t size = 0;
   if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) {
     (void)hipGetLastError();
-    return fail(NKA_HIP_EINVAL, std::string(what) + ": not a device allocation");
+    return fail(NKA_HIP_EINVAL, std::string(what) + (hit_in_registry ? ": a vector of this library whose memory has been released behind its back"
+                                                                     : ": not a device allocation"));
   }
   const char *lo = static_cast<const char *>(p), *end = static_cast<const char *>(base) + size;
   if (lo < static_cast<const char *>(base) || lo + need > end)
@@ -191,6 +215,8 @@ struct nka_hip_state {
   nka_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_ctx = nullptr;
   ncclComm_t comm = nullptr;
+  bool needs_comm = false;    // a deep copy of an accelerator that reduced through the built-in RCCL communicator: the
+                              // communicator belongs to the original, and rank-local sums would be silently wrong
   nka_hip_host_dot_fn host_dot = nullptr;   // user dot product on host copies (compatibility path)
   void *host_dot_ctx = nullptr;
   // instrumentation
@@ -685,6 +711,13 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
     b->allreduce = src->allreduce;
     b->allreduce_ctx = src->allreduce_ctx;
+    b->needs_comm = src->needs_comm;
+  } else {
+    // ... and the copy must not run without one: its sums would be rank-local, the replicas would diverge and nothing
+    // would say so (the reference's deep copy keeps its dp, F08:161).  accel_update fails with NKA_HIP_ECOMM until the
+    // caller gives the copy a communicator (nka_hip_comm_init_rank, collectively) or a hook (nka_hip_set_allreduce;
+    // NULL = "this copy really is single-rank").
+    b->needs_comm = true;
   }
   b->host_dot = src->host_dot;
   b->host_dot_ctx = src->host_dot_ctx;
@@ -883,34 +916,61 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
       }
     }
   }
-  HIP_TRY(hipMemcpy(a->ctl.red(), red.data(), sizeof(double) * red.size(), hipMemcpyHostToDevice));
+  // (uploads on the handle's stream, from buffers that live until the synchronisation behind them: ordered with the
+  //  kernels whatever kind of stream the caller bound the handle to)
+  HIP_TRY(hipMemcpyAsync(a->ctl.red(), red.data(), sizeof(double) * red.size(), hipMemcpyHostToDevice, a->stream));
   // ---- device: norm, s == 0 -> relax, Gram row, Cholesky with drops (the reference's loops on one lane)
   const size_t smem = a->state_in_global ? 0 : lst_smem_bytes(a->mvec);
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
                      a->state_in_global ? 1 : 0, 1);
   HIP_TRY(hipGetLastError());
+  // Phase 1 has changed the lists, the free list, h and the flags on the device.  Whatever fails between here and
+  // phase 2 (a copy, a corrupt list, the user's dp) must not leave a half-applied update behind: the control blocks
+  // as they stood at entry (ic0, dc0: read at the top) are written back, and accel_update's promise holds -- a failed
+  // update is NOT done and the call can be repeated.
+  const std::vector<int32_t> ic0 = ic;
+  const std::vector<double> dc0 = dc;
+  auto undo = [&](int rc) {
+    const std::string msg = g_err;
+    (void)hipStreamSynchronize(a->stream);
+    (void)hipMemcpy(a->ctl.ic, ic0.data(), sizeof(int32_t) * ic0.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->ctl.dc, dc0.data(), sizeof(double) * dc0.size(), hipMemcpyHostToDevice);
+    (void)hipGetLastError();
+    g_err = msg;
+    return rc;
+  };
+#define HIP_TRY_UNDO(expr)                                                                                  \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      (void)hipGetLastError();                                                                              \
+      return undo(fail(NKA_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)));                   \
+    }                                                                                                       \
+  } while (0)
   // ---- the list after the drops; its projections in list order, first ... last (F08:369-371)
-  if (int rc = fetch_state(a, ic, dc)) return rc;
+  if (int rc = fetch_state(a, ic, dc)) return undo(rc);
   std::vector<double> c((size_t)m1 + 1, 0.0);
   if (ic[IC_SUBSPACE]) {
     const int32_t *next = ic.data() + IC_HEADER;
     int steps = 0;
     for (int j = ic[IC_FIRST]; j != 0; j = next[j]) {
-      if (j < 1 || j > m1 || ++steps > m1) return fail(NKA_HIP_ESTATE, "host dot path: corrupt list on the device");
+      if (j < 1 || j > m1 || ++steps > m1) return undo(fail(NKA_HIP_ESTATE, "host dot path: corrupt list on the device"));
       const double *wj = hk.data();
       if (normed && j == first) {
         wj = hw1.data();                          // the new w1' (not stored yet: the combine pass writes it)
       } else if (n > 0) {
-        HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(j - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+        HIP_TRY_UNDO(hipMemcpy(hk.data(), a->vs.w + (size_t)(j - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
       }
       c[(size_t)j] = a->host_dot(a->host_dot_ctx, n, hf.data(), wj);              // F08:371
     }
   }
-  HIP_TRY(hipMemcpy(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+  HIP_TRY_UNDO(hipMemcpyAsync(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice, a->stream));
   // ---- device: new slot, substitutions, plans, prepend
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
                      a->state_in_global ? 1 : 0, 2);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY_UNDO(hipGetLastError());
+  HIP_TRY_UNDO(hipStreamSynchronize(a->stream));     // (c[] and red[] above are read by the stream until here)
+#undef HIP_TRY_UNDO
   return 0;
 }
 
@@ -919,6 +979,9 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
   if (int rc = nka_detail::check_device_span(f, a->n, "accel_update: f")) return rc;   // F08:258 size(f) == vlen
+  if (a->needs_comm)
+    return fail(NKA_HIP_ECOMM, "accel_update: this accelerator is a copy of a sharded one and has no all-reduce yet: call "
+                               "nka_hip_comm_init_rank or nka_hip_set_allreduce on it first (nka_hip_clone)");
   if (a->debug && nka_hip_defined(a) != 1)                                                // F08:257 ASSERT(defined(this))
     return fail(NKA_HIP_ESTATE, "accel_update: the device state fails the defined() invariants");
   hipStream_t s = a->stream;
@@ -1125,6 +1188,7 @@ int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   a->allreduce = fn;
   a->allreduce_ctx = ctx;
+  a->needs_comm = false;       // an explicit choice, NULL (single rank) included
   return 0;
 }
 
@@ -1165,6 +1229,7 @@ int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32
   }
   a->allreduce = rccl_allreduce;
   a->allreduce_ctx = a;
+  a->needs_comm = false;
   return 0;
 }
 

@@ -36,6 +36,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "nka_kernels.hpp is written for gfx950 (CDNA4) only: v_permlane32_swap / v_permlane16_swap reductions, 160 KiB LDS, tile shapes measured on MI355X.  Build with --offload-arch=gfx950."
+#endif
+
 #ifndef NKA_NT_LOADS
 #define NKA_NT_LOADS 1      // streaming reads: non-temporal (nt) loads
 #endif

@@ -25,9 +25,12 @@ using namespace nka;
 extern "C" const char *nka_hip_last_error(void);
 namespace nka_detail {
 int set_error(int code, const std::string &msg);
+std::string last_error();
+bool &span_check_failed();   // (thread-local) set by a failing check_device_span
 int check_device_span(const void *p, int64_t n, const char *what);
 void invalidate_span_cache();
-void register_allocation(const void *p, size_t bytes);
+void register_allocation(const void *p, size_t bytes, const void *owner);
+void unregister_owner(const void *owner);
 void unregister_allocation(const void *p);
 }
 
@@ -849,6 +852,23 @@ static __global__ __launch_bounds__(kBlock) void k_finalize_rows(const double *_
 
 bool ws_parallel(const nka_hip_vec_ws *ws) { return ws->allreduce || ws->host_allreduce; }
 
+// A rank whose OWN arguments fail the pointer check must not simply return from a parallel reduction: its peers are (or
+// will be) waiting in the collective.  Every reduction entry checks its pointers before its first launch and handles an
+// empty slice (n == 0) by joining each of its collectives with zeros, so: run the entry; if it came back because of a
+// pointer check, run it once more as an empty slice -- nobody hangs -- and report the error.  The caller's error stop
+// then ends the job the usual way.
+template <class F>
+int join_on_bad_pointers(nka_hip_vec_ws_t ws, int64_t n, F &&entry) {
+  nka_detail::span_check_failed() = false;
+  const int rc = entry(n);
+  if (rc && ws && n > 0 && nka_detail::span_check_failed() && ws_parallel(ws)) {
+    const std::string msg = nka_detail::last_error();
+    (void)entry(0);
+    nka_detail::set_error(rc, msg);
+  }
+  return rc;
+}
+
 int run_host_hook(nka_hip_vec_ws_t ws, double *vals, int total) {
   if (!ws->host_allreduce || total <= 0) return 0;
   if (int rc = ws->host_allreduce(ws->host_allreduce_ctx, vals, total))
@@ -930,6 +950,7 @@ int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *st
 int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws) {
   if (!ws) return 0;
   nka_detail::invalidate_span_cache();
+  nka_detail::unregister_owner(ws);      // its vectors can no longer be freed through the library: no entry may outlive it
   hipSetDevice(ws->device);
   hipStreamSynchronize(ws->stream);
   hipFree(ws->partials);
@@ -958,7 +979,7 @@ int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev) {
   if (!ws || !out_dev || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   HIP_TRYV(hipSetDevice(ws->device));
   HIP_TRYV(hipMalloc((void **)out_dev, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
-  nka_detail::register_allocation(*out_dev, sizeof(double) * (size_t)std::max<int64_t>(n, 1));   // exact pointer checks, no HIP call
+  nka_detail::register_allocation(*out_dev, sizeof(double) * (size_t)std::max<int64_t>(n, 1), ws);   // exact pointer checks, no HIP call
   return 0;
 }
 
@@ -1003,7 +1024,7 @@ int nka_hip_vec_update4(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, con
   return run_elementwise<5>(ws, n, z, x, y, a, b, c);
 }
 
-int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result) {
+static int nka_hip_vec_dot_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result) {
   if (!ws || !host_result || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_result = 0.0;
   if (n == 0 && !ws_parallel(ws)) return 0;
@@ -1023,6 +1044,9 @@ int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const doubl
   *host_result = ws->host_results[0];
   return 0;
 }
+int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_dot_entry(ws, n_, x, y, host_result); });
+}
 
 int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *host_result) {
   double d = 0.0;
@@ -1032,7 +1056,7 @@ int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *h
 }
 
 // vals[j] = <x, ys[j]>, j < count: x is read once per group of kManyMax vectors.
-int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys, int32_t count,
+static int nka_hip_vec_dot_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys, int32_t count,
                          double *host_vals) {
   if (!ws || n < 0 || count < 0 || (count > 0 && (!ys || !host_vals))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   for (int j = 0; j < count; j++) host_vals[j] = 0.0;
@@ -1069,10 +1093,14 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
   }
   return 0;
 }
+int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys, int32_t count,
+                         double *host_vals) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_dot_many_entry(ws, n_, x, ys, count, host_vals); });
+}
 
 // vals0[j] = <x0, ys[j]>, vals1[j] = <x1, ys[j]>, *cross = <x0, x1>: both rows of
 // the Gram update in ONE pass over the stored vectors.
-int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
+static int nka_hip_vec_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
                               const double *const *ys, int32_t count, double *host_vals0, double *host_vals1,
                               double *host_cross) {
   if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals0 || !host_vals1)))
@@ -1123,6 +1151,11 @@ int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, 
     base += kManyMax;
   } while (base < count);
   return 0;
+}
+int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
+                              const double *const *ys, int32_t count, double *host_vals0, double *host_vals1,
+                              double *host_cross) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_dot_pair_many_entry(ws, n_, x0, x1, ys, count, host_vals0, host_vals1, host_cross); });
 }
 
 // z <- (a[j]*xs[j] + b[j]*ys[j]) + z for j = 0..count-1 in order; z is read and
@@ -1196,7 +1229,7 @@ int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const doubl
 
 // *host_norm = ||a*x + z||_2 ; store != 0: z <- a*x + z, else z is left as it is (the
 // caller applies the update in the next stage, nka_hip_vec_scale_dot_pair_many with pre).
-int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, int32_t store,
+static int nka_hip_vec_update_norm2_entry(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, int32_t store,
                              double *host_norm) {
   if (!ws || !host_norm || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_norm = 0.0;
@@ -1224,6 +1257,10 @@ int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a
   *host_norm = std::sqrt(ws->host_results[0]);     // the square root of the GLOBAL sum
   return 0;
 }
+int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, int32_t store,
+                             double *host_norm) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_update_norm2_entry(ws, n_, z, a, x, store, host_norm); });
+}
 
 // [pre != 0: w <- pre_a*f + w ;] w <- a*w ; v <- a*v (subtract != 0: then v <- (-1)*w + v) ;
 // with the new w: vals_w[j] = <w, ys[j]>, vals_f[j] = <f, ys[j]>, *cross = <f, w>.  One pass
@@ -1233,21 +1270,31 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
                                     double *host_vals_w, double *host_vals_f, double *host_cross, int store,
                                     double *host_dd = nullptr);
 
-int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
+static int nka_hip_vec_scale_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
                                     double *host_vals_w, double *host_vals_f, double *host_cross) {
   return scale_dot_pair_many_impl(ws, n, w, v, a, subtract, pre, pre_a, f, ys, count, host_vals_w, host_vals_f, host_cross, 1);
+}
+int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
+                                    int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
+                                    double *host_vals_w, double *host_vals_f, double *host_cross) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_scale_dot_pair_many_entry(ws, n_, w, v, a, subtract, pre, pre_a, f, ys, count, host_vals_w, host_vals_f, host_cross); });
 }
 
 // The same sums with NOTHING stored: w stays as it is (raw, or already differenced when pre == 0),
 // v is not touched; the caller hands (w, v, a, pre, pre_a) to nka_hip_vec_update_many_keep_pend /
 // nka_hip_vec_axpy_many_keep_pend, which normalise the pair while they combine.  count <= 24.
-int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
+static int nka_hip_vec_dot_pair_many_scaled_entry(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
                                      const double *f, const double *const *ys, int32_t count, double *host_vals_w,
                                      double *host_vals_f, double *host_cross) {
   if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_dot_pair_many_scaled: more than 24 vectors");
   return scale_dot_pair_many_impl(ws, n, const_cast<double *>(w), const_cast<double *>(w), a, 0, pre, pre_a, f, ys, count,
                                   host_vals_w, host_vals_f, host_cross, 0);
+}
+int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
+                                     const double *f, const double *const *ys, int32_t count, double *host_vals_w,
+                                     double *host_vals_f, double *host_cross) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_dot_pair_many_scaled_entry(ws, n_, w, a, pre, pre_a, f, ys, count, host_vals_w, host_vals_f, host_cross); });
 }
 
 // The norm stage and the scale-and-dot stage as ONE pure-read pass: with d = a*x + z (nothing stored),
@@ -1255,7 +1302,7 @@ int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const doubl
 // takes s = sqrt(<d,d>) and scales by 1/s itself (what the array flavour's pass PA does: the Gram row of the
 // normalised pair as fl(<d,w_k>/s) instead of the sum of fl(d_i/s)*w_k,i -- last-bit differences).
 // count <= 24.
-int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
+static int nka_hip_vec_diff_norm_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
                                         const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
                                         double *host_vals_x, double *host_cross) {
   if (!host_dd) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
@@ -1263,6 +1310,11 @@ int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const do
   *host_dd = 0.0;
   return scale_dot_pair_many_impl(ws, n, const_cast<double *>(z), const_cast<double *>(z), 1.0, 0, 1, a, x, ys, count,
                                   host_vals_z, host_vals_x, host_cross, 0, host_dd);
+}
+int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
+                                        const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
+                                        double *host_vals_x, double *host_cross) {
+  return join_on_bad_pointers(ws, n, [&](int64_t n_) { return nka_hip_vec_diff_norm_dot_pair_many_entry(ws, n_, z, a, x, ys, count, host_dd, host_vals_z, host_vals_x, host_cross); });
 }
 
 static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,

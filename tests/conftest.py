@@ -20,6 +20,16 @@ def pytest_sessionstart(session):
         nka_amd.build()
 
 
+@pytest.fixture(autouse=True)
+def _truth_rule_per_test():
+    """THE parity rule is per call sequence (tests/parity_util.py): whatever a test checked against the extended-
+    precision trajectory is judged when the test ends."""
+    import parity_util as P
+    P.TOUCHED.clear()
+    yield
+    P.finish()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement (checker).  Built on demand with gcc."""

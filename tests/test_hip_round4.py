@@ -140,3 +140,64 @@ def test_capture_switches_the_list_word_off_for_good(torch_cuda):
     ref.accel_update(fr)
     torch.cuda.synchronize()
     assert torch.equal(fa, fr) and acc.state_digest() == ref.state_digest()
+
+
+def test_a_copy_of_a_sharded_accelerator_refuses_to_run_without_an_all_reduce(torch_cuda):
+    """nka_hip_clone leaves the built-in RCCL communicator with the original.  The copy must not silently form
+    rank-local sums: accel_update fails with NKA_HIP_ECOMM until the caller gives it a communicator or a
+    hook -- NULL included, which says "this copy really is single-rank"."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 5000, 3
+    rng = np.random.default_rng(11)
+    a = nka_amd.nka().init(n, m)
+    a.use_rccl(nka_amd.nka.rccl_unique_id(), 1, 0)            # a one-rank communicator: the sharded path on one GPU
+    assert a.comm_info() == (1, 0)
+    xs = [rng.standard_normal(n) for _ in range(4)]
+    for x in xs[:2]:
+        a.accel_update(torch.from_numpy(x.copy()).cuda())
+    b = a.copy()
+    assert b.comm_info() == (0, -1)
+    with pytest.raises(nka_amd.NKAError, match="copy of a sharded"):
+        b.accel_update(torch.from_numpy(xs[2].copy()).cuda())
+    assert b.state_digest() == a.state_digest()               # the refused call changed nothing
+    b.set_dot_prod(None)                                      # an explicit choice: single rank
+    fa, fb = torch.from_numpy(xs[2].copy()).cuda(), torch.from_numpy(xs[2].copy()).cuda()
+    a.accel_update(fa)
+    b.accel_update(fb)
+    assert torch.equal(fa, fb)
+    c = b.copy()                                              # a copy of an unsharded accelerator runs at once
+    c.accel_update(torch.from_numpy(xs[3].copy()).cuda())
+
+
+def test_a_rank_with_a_bad_pointer_still_joins_the_collective_of_a_parallel_reduction(torch_cuda):
+    """A parallel-aware reduction hook of the device vectors (row e'): a rank whose own arguments fail the pointer check
+    must report its error AND take part in the collective (with zeros), or its peers wait for ever."""
+    import ctypes as C
+    import nka_amd
+    from nka_amd import _lib
+    torch = torch_cuda
+    L = nka_amd.load()
+    h = C.c_void_p()
+    assert L.nka_hip_vec_workspace_create(C.byref(h), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    calls = []
+
+    def hook(_ctx, vals, count):
+        calls.append([vals[i] for i in range(count)])
+        return 0
+    cb = _lib.HOST_ALLREDUCE_FN(hook)
+    assert L.nka_hip_vec_set_host_allreduce(h, cb, None) == 0
+    n = 4096
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    short = torch.ones(n // 2, dtype=torch.float64, device="cuda")          # too short for n elements
+    out = C.c_double(-1.0)
+    assert L.nka_hip_vec_dot(h, n, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.byref(out)) == 0
+    assert out.value == float(n) and len(calls) == 1
+    rc = L.nka_hip_vec_dot(h, n, C.c_void_p(x.data_ptr()), C.c_void_p(short.data_ptr()), C.byref(out))
+    assert rc != 0 and b"shorter" in L.nka_hip_last_error()
+    assert len(calls) == 2 and calls[1] == [0.0]              # joined, with zeros
+    ys = (C.c_void_p * 3)(x.data_ptr(), short.data_ptr(), x.data_ptr())
+    vals = (C.c_double * 3)()
+    rc = L.nka_hip_vec_dot_many(h, n, C.c_void_p(x.data_ptr()), ys, 3, vals)
+    assert rc != 0 and len(calls) == 3 and calls[2] == [0.0, 0.0, 0.0]
+    L.nka_hip_vec_workspace_destroy(h)

@@ -96,8 +96,62 @@ def report(title, res, out):
         out.write(text + "\n")
 
 
+def survey(nseeds, O, out):
+    """The truth rule's statistics without a GPU: for fuzz seeds 0..N-1, the worst distance from the extended-precision
+    trajectory of (a) the reference -- its three flavours, the largest -- and (b) the device-like arithmetic (all three
+    deviations on), per sequence; prints the distribution of  max err_dev / (2 max err_ref)."""
+    from fuzz_ops import array_ops, array_shape
+    rows = []
+    for seed in range(nseeds):
+        rng, n, m, flavor = array_shape(seed)
+        ops = list(array_ops(rng, n, 120))
+        refs = [O.OracleNKA(n, m, fl) for fl in (0, 1, 2)]
+        dev = O.attribution_oracle(n, m, flavor, fma=True, blocked=True, raw_sums=True)
+        exact = O.OracleExact(n, m)
+        e_ref = e_dev = 0.0
+        for op in ops:
+            everyone = refs + [dev, exact]
+            if op[0] == "update":
+                x = op[1]
+                fx = x.copy()
+                exact.accel_update(fx)
+                nx = np.linalg.norm(x)
+                for a in refs:
+                    f = x.copy()
+                    a.accel_update(f)
+                    if nx > 0:
+                        e_ref = max(e_ref, np.linalg.norm(f - fx) / nx)
+                f = x.copy()
+                dev.accel_update(f)
+                if nx > 0:
+                    e_dev = max(e_dev, np.linalg.norm(f - fx) / nx)
+            elif op[0] == "relax":
+                [a.relax() for a in everyone]
+            elif op[0] == "restart":
+                [a.restart() for a in everyone]
+            elif op[0] == "set_vec_tol":
+                [a.set_vec_tol(op[1]) for a in everyone]
+        rows.append((seed, n, m, e_dev, e_ref))
+    lines = [f"## survey: fuzz seeds 0..{nseeds - 1}, device-like arithmetic against the truth rule (CPU emulation)",
+             f"{'seed':>5s} {'n':>6s} {'m':>3s} {'max err_dev':>12s} {'max err_ref':>12s} {'dev / (2 ref)':>14s}"]
+    used = []
+    for seed, n, m, ed, er in rows:
+        r = ed / max(2 * er, 1e-300) if ed > 1e-12 else 0.0
+        used.append((r, n))
+        lines.append(f"{seed:5d} {n:6d} {m:3d} {ed:12.3e} {er:12.3e} {r:14.2f}")
+    rs = sorted(r for r, _ in used)
+    q = lambda p: rs[min(len(rs) - 1, int(p * len(rs)))]       # noqa: E731
+    lines.append(f"# share of the allowance used (0 where err_dev <= 1e-12): median {q(0.5):.2f}, 90 % {q(0.9):.2f}, largest {q(1.0):.2f}; "
+                 f"sequences above 1: {[ (round(r, 2), n) for r, n in used if r > 1]}")
+    text = "\n".join(lines) + "\n"
+    print(text)
+    if out:
+        out.write(text + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--survey", type=int, default=0, help="N > 0: the truth rule's statistics over fuzz seeds 0..N-1 (see survey)")
     ap.add_argument("--scenario", nargs="*", default=["S9_near_dependence", "S8_n7_m8"])
     ap.add_argument("--fuzz-seed", type=int, nargs="*", default=[4])
     ap.add_argument("--flavor", type=int, default=0)
@@ -113,6 +167,8 @@ def main():
         g = S.load(name)
         n, m = int(g["n"]), int(g["mvec"])
         report(f"fixture {name}: n={n} mvec={m} flavour {a.flavor}", run(scenario_ops(g), n, m, a.flavor, O), out)
+    if a.survey > 0:
+        survey(a.survey, O, out)
     for seed in a.fuzz_seed:
         rng, n, m, flavor = array_shape(seed)
         report(f"fuzz seed {seed}: n={n} mvec={m} flavour {flavor} (tools/fuzz_ops.py)", run(array_ops(rng, n, 120), n, m, flavor, O), out)

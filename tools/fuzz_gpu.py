@@ -99,6 +99,7 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
         assert sa.free_order() == so.free_order(), (key, step)
         assert (sa.subspace, sa.pending) == (so.subspace, so.pending), (key, step)
     assert acc.defined(), key
+    P.finish([key])          # the truth rule, per sequence (tests/parity_util.py)
     return key
 
 
@@ -201,6 +202,7 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1):
             ora.set_vec_tol(arg); spread.set_vec_tol(arg)
         assert nvs == {ora.num_vec()}, (key, step, nvs, ora.num_vec())
     assert all(poss[r] == raws[r].size for r in range(world)), key
+    P.finish([key])
     return key
 
 
@@ -273,6 +275,7 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60):
         digs = nd.replica_digests(acc)
         assert all(d == digs[0] for d in digs), (key, rank, step, digs)
     assert acc.defined(), key
+    P.finish([key])          # the truth rule, per sequence (tests/parity_util.py)
     return key
 
 
@@ -299,8 +302,9 @@ def sharded_worker(args):
         try:
             key = one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd)
             rec = P.WORST.get(key, {})
-            out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
-                      f"{rec.get('k_needed', 0.0):.2f})\n")
+            out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
+                      f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
+                      f"{rec.get('err', 0.0):.2e}, spread K {rec.get('k_needed', 0.0):.2f})\n")
             out.flush()
         except Exception:                                   # noqa: BLE001
             out.write(f"FAIL seed {seed} rank {rank}\n{traceback.format_exc()}\n")
@@ -365,8 +369,9 @@ def main():
                 else:
                     key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot)
                 rec = P.WORST.get(key, {})
-                out.write(f"ok   {key}: worst {rec.get('err', 0.0):.2e} (tol {rec.get('tol', 0.0):.1e}, k_needed "
-                          f"{rec.get('k_needed', 0.0):.2f})\n")
+                out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
+                          f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
+                          f"{rec.get('err', 0.0):.2e}, spread K {rec.get('k_needed', 0.0):.2f})\n")
             except Exception:                               # noqa: BLE001 -- record and carry on with the next seed
                 failed.append(seed)
                 out.write(f"FAIL seed {seed}\n{traceback.format_exc()}\n")
@@ -376,8 +381,12 @@ def main():
                 print(f"{seed - args.first_seed} seeds, {len(failed)} failed, {time.time() - t0:.0f} s", flush=True)
         kmax = max([r.get("k_needed", 0.0) for r in P.WORST.values()] + [0.0])
         wmax = max([r.get("worst_well_conditioned", 0.0) for r in P.WORST.values()] + [0.0])
+        ratios = sorted(r.get("truth_ratio", 0.0) for r in P.WORST.values() if r.get("err_dev_exact") is not None)
+        rq = (lambda q: ratios[min(len(ratios) - 1, int(q * len(ratios)))]) if ratios else (lambda q: 0.0)
         summary = (f"# seeds {args.first_seed}..{seed - 1}: {seed - args.first_seed - len(failed)} ok, {len(failed)} failed "
-                   f"{failed}; largest K needed {kmax:.2f} of {P.K_SPREAD}; well-conditioned worst {wmax:.2e}")
+                   f"{failed}; truth rule (max err_dev <= max(base, {P.TRUTH_FACTOR:g} x max err_ref) per sequence): share of the "
+                   f"allowance used -- median {rq(0.5):.2f}, 90 % {rq(0.9):.2f}, largest {rq(1.0):.2f}; spread diagnostic: largest K "
+                   f"{kmax:.2f}; well-conditioned worst dev-ref {wmax:.2e}")
         out.write(summary + "\n")
     print(summary)
     return 1 if failed else 0
