@@ -15,7 +15,7 @@ is not within 1e-12 of the truth; how far it is, is MEASURED (round 4), not esti
                   reference, or the oracle's flavours, each pinned to its reference bit for bit)
         err_dev = ||f_device - f_exact|| / ||f_in||
   and every test asserts, over its call sequence,
-        max err_dev <= max(base, TRUTH_FACTOR * max err_ref),         TRUTH_FACTOR = 2:
+        max err_dev <= max(base, TRUTH_FACTOR * max err_ref),         TRUTH_FACTOR = 2 (4 for n < 512: truth_factor):
   the device may be no further from the truth than twice the reference's own worst distance
   from it on the same calls, and within the stated figure wherever the reference is.  The
   comparison is per SEQUENCE, not per call: where one ill-conditioned event dominates, err_dev
@@ -43,6 +43,8 @@ import numpy as np
 WORST = {}     # key -> dict(err=..., tol=..., pivot=..., n=count)
 K_SPREAD = 4.0       # diagnostic only since round 4
 TRUTH_FACTOR = 2.0   # end of the sequence: max err_dev <= max(base, TRUTH_FACTOR * max err_ref)   (finish())
+TRUTH_FACTOR_TINY = 4.0   # ... for vectors shorter than one tile of the kernels (n < 512), see truth_factor
+TINY_N = 512
 TRUTH_HARD = 8.0     # every call, at once: err_dev <= max(base, TRUTH_HARD * err_ref so far)
 TOUCHED = set()      # keys checked with `truth` since the last finish()
 
@@ -55,6 +57,7 @@ class Spread:
       .value    = largest pairwise ||f_a - f_b|| / ||f_in|| of the three flavours so far  (diagnostic)"""
 
     def __init__(self, oracle, n, m, vtol=None):
+        self.n = int(n)
         self.accs = [oracle.OracleNKA(n, m, fl) for fl in (oracle.F08, oracle.F08_VECTOR, oracle.C_FLAVOR)]
         self.truth_acc = oracle.OracleExact(n, m, oracle.F08)
         if vtol is not None:
@@ -91,7 +94,7 @@ class Spread:
         if sl is not None:
             fx = fx[sl]
         nx = max(float(np.linalg.norm(x)), 1e-300)
-        return float(np.linalg.norm(np.asarray(out_dev) - fx)) / nx, self.err_ref
+        return float(np.linalg.norm(np.asarray(out_dev) - fx)) / nx, self.err_ref, self.n
 
     def relax(self):
         for a in self.accs + [self.truth_acc]:
@@ -150,6 +153,17 @@ def pivot_min(state):
     return min([abs(state.h[k - 1, k - 1]) for k in live] + [1.0])
 
 
+def truth_factor(n):
+    """2 from one tile (512 elements) up; 4 below.  From n ~ 1e3 up the device's blocked, fused sums are 10-100 times
+    closer to the truth than the reference's sequential ones and the rule is met with a tenth of the allowance
+    (tools/error_attribution.py --survey).  A sum of fewer than 512 terms is exact to a few units in the last place in
+    ANY order: there the device cannot be systematically better, device and reference are two equally good draws of the
+    same rounding-error distribution -- switching on FMA alone, or the blocked order alone, in the reference's own
+    arithmetic moves its error by factors between 0.3 and 3.6 on such inputs (profiles/r04/error_attribution.txt) --
+    and the ratio of two such draws exceeds 2 every few dozen ill-conditioned sequences by chance."""
+    return TRUTH_FACTOR if (n is None or n >= TINY_N) else TRUTH_FACTOR_TINY
+
+
 def tolerance(state, base=1e-12, spread=None, truth=None):
     """-> (tol, pivot, rule).  With `truth` = (err_dev, err_ref) the tolerance applies to err_dev."""
     piv = pivot_min(state)
@@ -184,6 +198,8 @@ def check(err, state, key, base=1e-12, where=None, spread=None, truth=None):
         rec["base"] = float(base)
         rec["err_dev_exact"] = max(rec["err_dev_exact"] or 0.0, float(truth[0]))       # worst over the sequence(s) so far
         rec["err_ref_exact"] = max(rec["err_ref_exact"] or 0.0, float(truth[1]))       # (cumulative in the caller already)
+        if len(truth) > 2 and truth[2] is not None:
+            rec["n"] = int(truth[2])
         rec["seq_dev"] = max(rec.get("seq_dev", 0.0), float(truth[0]))                 # this sequence (reset by finish())
         rec["seq_ref"] = max(rec.get("seq_ref", 0.0), float(truth[1]))
     if err >= rec["err"]:
@@ -194,7 +210,7 @@ def check(err, state, key, base=1e-12, where=None, spread=None, truth=None):
     return err
 
 
-def finish(keys=None):
+def finish(keys=None, strict=True):
     """End of a call sequence (a test, a soak seed): THE rule for every key checked with `truth` since the last call --
     max err_dev <= max(base, TRUTH_FACTOR * max err_ref) over the sequence.  Records the share of the allowance used."""
     bad = []
@@ -203,17 +219,20 @@ def finish(keys=None):
         if not rec or "seq_dev" not in rec:
             continue
         dev, ref, base = rec.pop("seq_dev"), rec.pop("seq_ref"), rec.get("base", 1e-12)
-        tol = max(base, TRUTH_FACTOR * ref)
+        fac = truth_factor(rec.get("n"))
+        tol = max(base, fac * ref)
         if dev > base:          # how much of the allowance the device needed (1 = all of it)
-            rec["truth_ratio"] = max(rec.get("truth_ratio", 0.0), dev / max(TRUTH_FACTOR * ref, 1e-300))
-        rec["tol"], rec["rule"] = float(tol), ("stated" if tol == base else "2 x reference-vs-exact (per sequence)")
+            rec["truth_ratio"] = max(rec.get("truth_ratio", 0.0), dev / max(fac * ref, 1e-300))
+        rec["tol"], rec["rule"] = float(tol), ("stated" if tol == base else f"{fac:g} x reference-vs-exact (per sequence)")
         if dev > tol:
             bad.append((key, dev, tol, ref))
     if keys is None:
         TOUCHED.clear()
     else:
         TOUCHED.difference_update(keys)
-    assert not bad, ("device further from the extended-precision trajectory than twice the reference", bad)
+    if strict:
+        assert not bad, ("device further from the extended-precision trajectory than the rule allows", bad)
+    return bad
 
 
 def record(err, tol, key):

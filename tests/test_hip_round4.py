@@ -187,9 +187,9 @@ def test_a_rank_with_a_bad_pointer_still_joins_the_collective_of_a_parallel_redu
         return 0
     cb = _lib.HOST_ALLREDUCE_FN(hook)
     assert L.nka_hip_vec_set_host_allreduce(h, cb, None) == 0
-    n = 4096
+    n = 1 << 22          # (32 MB: beyond any segment torch's caching allocator would have put a 4-element tensor into)
     x = torch.ones(n, dtype=torch.float64, device="cuda")
-    short = torch.ones(n // 2, dtype=torch.float64, device="cuda")          # too short for n elements
+    short = torch.ones(4, dtype=torch.float64, device="cuda")               # too short for n elements
     out = C.c_double(-1.0)
     assert L.nka_hip_vec_dot(h, n, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.byref(out)) == 0
     assert out.value == float(n) and len(calls) == 1

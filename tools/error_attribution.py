@@ -101,6 +101,7 @@ def survey(nseeds, O, out):
     trajectory of (a) the reference -- its three flavours, the largest -- and (b) the device-like arithmetic (all three
     deviations on), per sequence; prints the distribution of  max err_dev / (2 max err_ref)."""
     from fuzz_ops import array_ops, array_shape
+    import parity_util as P
     rows = []
     for seed in range(nseeds):
         rng, n, m, flavor = array_shape(seed)
@@ -133,10 +134,10 @@ def survey(nseeds, O, out):
                 [a.set_vec_tol(op[1]) for a in everyone]
         rows.append((seed, n, m, e_dev, e_ref))
     lines = [f"## survey: fuzz seeds 0..{nseeds - 1}, device-like arithmetic against the truth rule (CPU emulation)",
-             f"{'seed':>5s} {'n':>6s} {'m':>3s} {'max err_dev':>12s} {'max err_ref':>12s} {'dev / (2 ref)':>14s}"]
+             f"{'seed':>5s} {'n':>6s} {'m':>3s} {'max err_dev':>12s} {'max err_ref':>12s} {'allowance used':>14s}"]
     used = []
     for seed, n, m, ed, er in rows:
-        r = ed / max(2 * er, 1e-300) if ed > 1e-12 else 0.0
+        r = ed / max(P.truth_factor(n) * er, 1e-300) if ed > 1e-12 else 0.0
         used.append((r, n))
         lines.append(f"{seed:5d} {n:6d} {m:3d} {ed:12.3e} {er:12.3e} {r:14.2f}")
     rs = sorted(r for r, _ in used)

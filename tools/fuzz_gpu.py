@@ -42,12 +42,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from fuzz_ops import SIZES, array_ops, array_shape  # noqa: E402,F401
 
+BEYOND = []      # (key, err_dev, tol, err_ref) of sequences beyond the truth rule's allowance (soak runs: recorded, not fatal)
+
 
 def _pairwise_dot(x, y):
     return float(np.add.reduce(np.asarray(x) * np.asarray(y)))
 
 
-def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
+def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, strict=True):
     rng, n, m, flavor = array_shape(seed, hostdot)
     key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}"
     acc = nka_amd.nka().init(n, m, flavor=flavor)
@@ -99,11 +101,11 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False):
         assert sa.free_order() == so.free_order(), (key, step)
         assert (sa.subspace, sa.pending) == (so.subspace, so.pending), (key, step)
     assert acc.defined(), key
-    P.finish([key])          # the truth rule, per sequence (tests/parity_util.py)
+    BEYOND.extend(P.finish([key], strict))          # the truth rule, per sequence (tests/parity_util.py)
     return key
 
 
-def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1):
+def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True):
     import subprocess
     rng = np.random.default_rng(10_000 + seed + (1_000_000 if world > 1 else 0))
     nfield = int(rng.integers(1, 5))
@@ -202,7 +204,7 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1):
             ora.set_vec_tol(arg); spread.set_vec_tol(arg)
         assert nvs == {ora.num_vec()}, (key, step, nvs, ora.num_vec())
     assert all(poss[r] == raws[r].size for r in range(world)), key
-    P.finish([key])
+    BEYOND.extend(P.finish([key], strict))
     return key
 
 
@@ -211,7 +213,7 @@ class _Alias:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60):
+def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict=True):
     """Every rank draws the same sequence; each runs the HIP path on its contiguous slice (some slices are EMPTY at
     tiny n) with an all-reduce hook staged through gloo, against the unsharded oracle."""
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -275,7 +277,7 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60):
         digs = nd.replica_digests(acc)
         assert all(d == digs[0] for d in digs), (key, rank, step, digs)
     assert acc.defined(), key
-    P.finish([key])          # the truth rule, per sequence (tests/parity_util.py)
+    BEYOND.extend(P.finish([key], strict))          # the truth rule, per sequence (tests/parity_util.py)
     return key
 
 
@@ -300,7 +302,7 @@ def sharded_worker(args):
         if not int(go.item()):
             break
         try:
-            key = one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd)
+            key = one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, strict=False)
             rec = P.WORST.get(key, {})
             out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
                       f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
@@ -365,9 +367,9 @@ def main():
             try:
                 if args.vector or args.vector_sharded:
                     with tempfile.TemporaryDirectory() as tmpdir:
-                        key = one_seed_vector(seed, oracle, P, S, tmpdir, world=max(1, args.vector_sharded))
+                        key = one_seed_vector(seed, oracle, P, S, tmpdir, world=max(1, args.vector_sharded), strict=False)
                 else:
-                    key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot)
+                    key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot, strict=False)
                 rec = P.WORST.get(key, {})
                 out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
                           f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
@@ -386,7 +388,8 @@ def main():
         summary = (f"# seeds {args.first_seed}..{seed - 1}: {seed - args.first_seed - len(failed)} ok, {len(failed)} failed "
                    f"{failed}; truth rule (max err_dev <= max(base, {P.TRUTH_FACTOR:g} x max err_ref) per sequence): share of the "
                    f"allowance used -- median {rq(0.5):.2f}, 90 % {rq(0.9):.2f}, largest {rq(1.0):.2f}; spread diagnostic: largest K "
-                   f"{kmax:.2f}; well-conditioned worst dev-ref {wmax:.2e}")
+                   f"{kmax:.2f}; well-conditioned worst dev-ref {wmax:.2e}; sequences beyond the allowance (below the hard stop of "
+                   f"{P.TRUTH_HARD:g} x per call): {len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}")
         out.write(summary + "\n")
     print(summary)
     return 1 if failed else 0
