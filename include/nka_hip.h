@@ -129,6 +129,23 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out);
  * The object keeps copies, never a reference (F08:361,404). */
 int nka_hip_accel_update(nka_hip_t a, double *f_dev);
 
+/* OUT-OF-PLACE form of accel_update, opt-in: two of PB's five store streams less (8n(7+L+k) bytes per update with
+ * compact storage instead of 8n(9+L+k); 8n(6+L+2k) against 8n(8+L+2k) in the src-F08 rounding).  The reference keeps
+ * COPIES of f_in and f_out (F08:361, 404) and returns f_out in the caller's array; here the buffers themselves change
+ * hands instead of being copied:
+ *   in   *f_io  : device buffer with f (vlen_local doubles, 16-byte aligned).  The library KEEPS it -- it becomes the
+ *                 storage of w of the new pair, which is f_in itself -- until the handle is destroyed: do not write it,
+ *                 free it only after nka_hip_destroy.
+ *   out  *f_io  : a free device buffer of the library (>= vlen_local doubles, contents undefined) for the caller's NEXT
+ *                 input; it dies with the handle.
+ *   out  *f_acc : the accelerated f -- the v of the new pair, stored once -- to be READ only (solution update, next
+ *                 residual), valid until the next accel_update* / restart / destroy on this handle.
+ * Same arithmetic, same bits, same state as nka_hip_accel_update on the same inputs; the two entries can be mixed.  The
+ * buffers an update displaces are known on the device only; they reach the host with the list word's record (no
+ * synchronisation if the caller has synchronised since the previous out-of-place update, else this call waits for the
+ * stream).  Not with nka_hip_set_host_dot; not capturable into a graph. */
+int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
+
 /* Host-array compatibility entry (the reference signature takes host memory,
  * F08:252): H2D copy, update, D2H copy, stream synchronised on return. */
 int nka_hip_accel_update_host(nka_hip_t a, double *f_host);

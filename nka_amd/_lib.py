@@ -24,6 +24,7 @@ SIGNATURES = {
     "nka_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nka_hip_accel_update_host": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nka_hip_accel_update_swap": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "nka_hip_restart": (C.c_int, [C.c_void_p]),
     "nka_hip_relax": (C.c_int, [C.c_void_p]),
     "nka_hip_set_vec_tol": (C.c_int, [C.c_void_p, C.c_double]),

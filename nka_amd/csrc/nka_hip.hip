@@ -195,6 +195,13 @@ struct nka_hip_state {
   std::vector<int64_t> relaxed_after;  // relax() calls that dropped a pending pair, by the number of the update before them
   bool word_off = false;      // the handle's stream was seen capturing (replays change the list behind the word), or
                               // the diagnostic switch "list_word" = 0
+  // out-of-place updates (nka_hip_accel_update_swap): the slot -> buffer tables live on the device (Ctl::pc); the host
+  // knows only the two buffers it can hand out next
+  bool swapped = false;       // a table entry may differ from base + (slot-1)*stride: host-side accessors read the tables
+  double *spare_w = nullptr, *spare_v = nullptr;   // free buffers the host knows of (given away by the next swap update)
+  bool swap_pending = false;  // the buffers the last swap update displaced have not been collected yet (record word 3)
+  int64_t swap_seq = 0;       // number of that update
+  std::vector<void *> extra_allocs;   // the two spare buffers allocated at the first swap update (freed at destroy)
   // launch geometry
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
@@ -202,6 +209,7 @@ struct nka_hip_state {
   int pa_pipe = -1;           // form of PA: 0 = k_dots (every load of a tile in flight; any list length), 201..204 = k_dots_win
                               // (rolling window) with 1..4 blocks per CU, -1 = automatic (see enqueue_pa)
   int pb_pipe = -1;           // form of PB: 0 = k_combine, 201..204 = k_combine_win, -1 = automatic (see enqueue_pb)
+  int pb_flags = 0;           // kPbNoStoreW | kPbNoStoreF while an out-of-place update is being enqueued, else 0
   int pb_tile = -1;           // tile width of the rolling-window PB for short lists: -1 automatic (double-width tiles
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
@@ -330,7 +338,8 @@ template <int MAXK, int VEC, int COMB>
 int launch_combine_1(const nka_hip_state *a, double *f, int pass, int last) {
   static const int occ = occupancy_of(k_combine<MAXK, VEC, COMB>);
   const int g = grid_for(a, 1, VEC, occ, (COMB == 2 ? MAXK + 2 : 2 * MAXK + 1));
-  hipLaunchKernelGGL((k_combine<MAXK, VEC, COMB>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, pass, last);
+  hipLaunchKernelGGL((k_combine<MAXK, VEC, COMB>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, pass, last,
+                     a->pb_flags);
   return g;
 }
 
@@ -372,7 +381,7 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   if (ng > 0 && (g % ng != 0 || ntile >= ((int64_t)1 << 31) - 2 * kMaxGrid || !a->tickets)) ng = 0;
   const int tail = (ntile * (kBlock * 2 * T) < a->n) ? 1 : 0;     // the ragged tail has a block of its own (k_combine_win)
   hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W, T>), dim3((int)g + tail), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
-                     ng > 0 ? a->tickets : nullptr, std::max(ng, 1));
+                     ng > 0 ? a->tickets : nullptr, std::max(ng, 1), a->pb_flags);
   return (int)g;
 }
 
@@ -585,10 +594,11 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
   alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 2));  // NACC columns of k_dots
   alloc((void **)&a->tickets, sizeof(unsigned) * kTicketWords);
+  alloc((void **)&a->ctl.pc, sizeof(double *) * a->ctl.pc_count());
   if (!rc) {
     // the list word: fine-grained pinned host memory the device writes and the host polls (no synchronisation)
     void *hw = nullptr;
-    hipError_t e = hipHostMalloc(&hw, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    hipError_t e = hipHostMalloc(&hw, 64, hipHostMallocMapped | hipHostMallocCoherent);   // (a record of four words, see list_word_publish)
     if (e == hipSuccess) {
       memset(hw, 0, 64);
       void *dp = nullptr;
@@ -614,6 +624,20 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
       hipMemcpyAsync(a->ctl.dc + DC_VTOL, &a->vtol, sizeof(double), hipMemcpyHostToDevice, a->stream) != hipSuccess) {
     nka_hip_destroy(a);
     return fail(NKA_HIP_EHIP, "initialising the control block failed");
+  }
+  {
+    // slot -> buffer tables: slot k at base + (k-1)*stride of the two slot-major allocations (Ctl::pc)
+    std::vector<double *> pc((size_t)a->ctl.pc_count(), nullptr);
+    Ctl h = a->ctl;
+    h.pc = pc.data();
+    for (int k = 1; k <= mvec + 1; k++) {
+      h.wtab()[k] = a->vs.w + (size_t)(k - 1) * a->vs.stride;
+      h.vtab()[k] = a->vs.v + (size_t)(k - 1) * a->vs.stride;
+    }
+    if (hipMemcpy(a->ctl.pc, pc.data(), sizeof(double *) * pc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      nka_hip_destroy(a);
+      return fail(NKA_HIP_EHIP, "initialising the pointer block failed");
+    }
   }
   // the memcpy source is a->vtol (heap): safe until the stream reaches it; sync to be simple
   hipStreamSynchronize(a->stream);
@@ -667,6 +691,8 @@ int nka_hip_destroy(nka_hip_t a) {
   hipFree(a->ctl.dc);
   hipFree(a->partials);
   hipFree(a->tickets);
+  hipFree(a->ctl.pc);
+  for (void *p : a->extra_allocs) hipFree(p);
   if (a->list_word) hipHostFree(a->list_word);
   hipFree(a->f_stage);
   hipFree(a->hd_scratch);
@@ -675,6 +701,29 @@ int nka_hip_destroy(nka_hip_t a) {
   a->ev.clear();
   delete a;
   return 0;
+}
+
+// The slot -> buffer tables as they stand on the device (synchronises).  t.wtab()[k], t.vtab()[k] for k = 1..mvec+1.
+static int fetch_tables(nka_hip_t a, std::vector<double *> &pc, Ctl &t) {
+  pc.assign((size_t)a->ctl.pc_count(), nullptr);
+  HIP_TRY(hipMemcpyAsync(pc.data(), a->ctl.pc, sizeof(double *) * pc.size(), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  t = a->ctl;
+  t.pc = pc.data();
+  return 0;
+}
+// w / v buffer of a slot for the host-side paths (queries, the user-dot-product path, deep copies)
+static const double *slot_buffer(nka_hip_t a, const Ctl *tables, bool v, int slot) {
+  if (tables) return v ? tables->vtab()[slot] : tables->wtab()[slot];
+  return (v ? a->vs.v : a->vs.w) + (size_t)(slot - 1) * a->vs.stride;
+}
+// After the control blocks of a copy have been filled from another object: the addresses of PA's plan through THIS
+// object's tables (the combine plan is rewritten by every scalar step before PB reads it).
+static __global__ void k_plan_pointers_from_slots(Ctl ctl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = ctl.ic[IC_PLAN_NOLDER];
+  for (int j = 0; j < n; j++) ctl.plan_w()[j] = ctl.wtab()[ctl.plan_slots()[j]];
+  ctl.pc[PC_FIRST_W] = ctl.wtab()[ctl.ic[IC_PLAN_FIRST]];
 }
 
 int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
@@ -689,10 +738,31 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   }
   const size_t slot_bytes = (size_t)src->vs.stride * sizeof(double) * (size_t)(src->mvec + 1);
   hipStream_t s = src->stream;
-  hipError_t e = hipMemcpyAsync(b->vs.v, src->vs.v, slot_bytes, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(b->vs.w, src->vs.w, slot_bytes, hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipSuccess;
+  if (!src->swapped) {
+    e = hipMemcpyAsync(b->vs.v, src->vs.v, slot_bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->vs.w, src->vs.w, slot_bytes, hipMemcpyDeviceToDevice, s);
+  } else {
+    // out-of-place updates have moved src's vectors into other buffers (some of them the caller's): the copy gets
+    // its own slot-major storage, filled slot by slot through src's tables
+    std::vector<double *> pc;
+    Ctl t{};
+    if (int rc = fetch_tables(src, pc, t)) {
+      nka_hip_destroy(b);
+      return rc;
+    }
+    const size_t nb = sizeof(double) * (size_t)src->n;
+    for (int k = 1; k <= src->mvec + 1 && e == hipSuccess && nb > 0; k++) {
+      e = hipMemcpyAsync(b->vs.w + (size_t)(k - 1) * b->vs.stride, t.wtab()[k], nb, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(b->vs.v + (size_t)(k - 1) * b->vs.stride, t.vtab()[k], nb, hipMemcpyDeviceToDevice, s);
+    }
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(b->ctl.ic, src->ctl.ic, sizeof(int32_t) * src->ctl.ic_count(), hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(b->ctl.dc, src->ctl.dc, sizeof(double) * src->ctl.dc_count(), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_plan_pointers_from_slots, dim3(1), dim3(1), 0, s, b->ctl);
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) {
     nka_hip_destroy(b);
     return fail(NKA_HIP_EHIP, std::string("nka_hip_clone: ") + hipGetErrorString(e));
@@ -763,12 +833,12 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
 }
 
 // ---- the three stages of an update, enqueued on the handle's stream -------------
-static int enqueue_solve(nka_hip_t a, int mode) {
+static int enqueue_solve(nka_hip_t a, int mode, double *swap_w = nullptr, double *swap_v = nullptr) {
   hipStream_t s = a->stream;
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int nl = a->mvec + 1;
-#define ROWS(NL) hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode)
+#define ROWS(NL) hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v)
     if (nl <= 6) ROWS(6);
     else if (nl <= 11) ROWS(11);
     else if (nl <= 21) ROWS(21);
@@ -777,7 +847,7 @@ static int enqueue_solve(nka_hip_t a, int mode) {
 #undef ROWS
   } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
-                       a->state_in_global ? 1 : 0, 0);
+                       a->state_in_global ? 1 : 0, 0, swap_w, swap_v);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -888,6 +958,11 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   if (nolder < 0 || nolder > mvec + 1 || (pending && (first < 1 || first > mvec + 1)))
     return fail(NKA_HIP_ESTATE, "host dot path: corrupt dot plan on the device");
   const size_t nb = sizeof(double) * (size_t)n;
+  std::vector<double *> pcs;       // (after out-of-place updates the vectors are where the tables say)
+  Ctl tabs{};
+  if (a->swapped)
+    if (int rc = fetch_tables(a, pcs, tabs)) return rc;
+  const Ctl *tp = a->swapped ? &tabs : nullptr;
   if (pending && !a->hd_scratch) HIP_TRY(hipMalloc((void **)&a->hd_scratch, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
   const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)a->num_cu * 8));
   std::vector<double> hf((size_t)n), hw1(pending ? (size_t)n : 0), hk((size_t)n);
@@ -896,7 +971,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   bool normed = false;
   if (pending) {
     hipLaunchKernelGGL(k_hostdot_diff, dim3(g), dim3(kBlock), 0, a->stream, n,
-                       a->vs.w + (size_t)(first - 1) * a->vs.stride, f, a->hd_scratch);
+                       slot_buffer(a, tp, false, first), f, a->hd_scratch);
     HIP_TRY(hipGetLastError());
     if (n > 0) HIP_TRY(hipMemcpyAsync(hw1.data(), a->hd_scratch, nb, hipMemcpyDeviceToHost, a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));
@@ -911,7 +986,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
       for (int p = 0; p < nolder; p++) {                                          // F08:286-290, list order
         const int slot = slots[p];
         if (slot < 1 || slot > mvec + 1) return fail(NKA_HIP_ESTATE, "host dot path: slot out of range in the dot plan");
-        if (n > 0) HIP_TRY(hipMemcpy(hk.data(), a->vs.w + (size_t)(slot - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+        if (n > 0) HIP_TRY(hipMemcpy(hk.data(), slot_buffer(a, tp, false, slot), nb, hipMemcpyDeviceToHost));
         red[2 + p] = a->host_dot(a->host_dot_ctx, n, hw1.data(), hk.data());
       }
     }
@@ -922,7 +997,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   // ---- device: norm, s == 0 -> relax, Gram row, Cholesky with drops (the reference's loops on one lane)
   const size_t smem = a->state_in_global ? 0 : lst_smem_bytes(a->mvec);
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 1);
+                     a->state_in_global ? 1 : 0, 1, (double *)nullptr, (double *)nullptr);
   HIP_TRY(hipGetLastError());
   // Phase 1 has changed the lists, the free list, h and the flags on the device.  Whatever fails between here and
   // phase 2 (a copy, a corrupt list, the user's dp) must not leave a half-applied update behind: the control blocks
@@ -935,6 +1010,8 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
     (void)hipStreamSynchronize(a->stream);
     (void)hipMemcpy(a->ctl.ic, ic0.data(), sizeof(int32_t) * ic0.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->ctl.dc, dc0.data(), sizeof(double) * dc0.size(), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_plan_pointers_from_slots, dim3(1), dim3(1), 0, a->stream, a->ctl);    // (the plan's addresses too)
+    (void)hipStreamSynchronize(a->stream);
     (void)hipGetLastError();
     g_err = msg;
     return rc;
@@ -959,7 +1036,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
       if (normed && j == first) {
         wj = hw1.data();                          // the new w1' (not stored yet: the combine pass writes it)
       } else if (n > 0) {
-        HIP_TRY_UNDO(hipMemcpy(hk.data(), a->vs.w + (size_t)(j - 1) * a->vs.stride, nb, hipMemcpyDeviceToHost));
+        HIP_TRY_UNDO(hipMemcpy(hk.data(), slot_buffer(a, tp, false, j), nb, hipMemcpyDeviceToHost));
       }
       c[(size_t)j] = a->host_dot(a->host_dot_ctx, n, hf.data(), wj);              // F08:371
     }
@@ -967,14 +1044,20 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   HIP_TRY_UNDO(hipMemcpyAsync(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice, a->stream));
   // ---- device: new slot, substitutions, plans, prepend
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 2);
+                     a->state_in_global ? 1 : 0, 2, (double *)nullptr, (double *)nullptr);
   HIP_TRY_UNDO(hipGetLastError());
   HIP_TRY_UNDO(hipStreamSynchronize(a->stream));     // (c[] and red[] above are read by the stream until here)
 #undef HIP_TRY_UNDO
   return 0;
 }
 
-int nka_hip_accel_update(nka_hip_t a, double *f) {
+static int update_impl(nka_hip_t a, double *f, double *swap_w, double *swap_v);
+
+int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, nullptr, nullptr); }
+
+// One update.  swap_w / swap_v != nullptr: out of place (nka_hip_accel_update_swap) -- f (== swap_w) becomes the w buffer of
+// the new pair and swap_v its v buffer; PB then stores neither w_new nor f.
+static int update_impl(nka_hip_t a, double *f, double *swap_w, double *swap_v) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
@@ -1022,7 +1105,7 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
   RoctxRange range_tail("nka:solve + PB combine");
   if (!solved)
-    if (int rc = enqueue_solve(a, mode)) return rc;
+    if (int rc = enqueue_solve(a, mode, swap_w, swap_v)) return rc;
   if (int rc = record(a, 2)) return rc;
 
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
@@ -1031,7 +1114,9 @@ int nka_hip_accel_update(nka_hip_t a, double *f) {
     Ctl &c = a->ctl;
     unsigned long long *const hw = c.hw;
     if (a->word_off) c.hw = nullptr;
+    a->pb_flags = swap_w ? (kPbNoStoreW | kPbNoStoreF) : 0;
     const int rc = enqueue_pb(a, f, vec, comb_ub);
+    a->pb_flags = 0;
     c.hw = hw;
     if (rc) return rc;
   }
@@ -1053,6 +1138,72 @@ int nka_hip_accel_update_host(nka_hip_t a, double *f_host) {
   if (int rc = nka_hip_accel_update(a, a->f_stage)) return rc;
   HIP_TRY(hipMemcpyAsync(f_host, a->f_stage, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
+  return 0;
+}
+
+// The buffers the last out-of-place update displaced become the spares of the next one.  They are known on the device
+// (PC_OLD_W / PC_OLD_V, written by the scalar step) and reach the host with PB's record (words 1..3 of the list word's
+// cache line) -- without a synchronisation if the caller has synchronised since (every solver does, once per
+// iteration); otherwise this waits for the stream.
+static int collect_spares(nka_hip_t a) {
+  if (a->swap_pending) {
+    auto fresh = [&]() {
+      return a->list_word && !a->word_off &&
+             (int64_t)__atomic_load_n(a->list_word + 3, __ATOMIC_ACQUIRE) == a->swap_seq;
+    };
+    if (!fresh()) HIP_TRY(hipStreamSynchronize(a->stream));
+    double *ow = nullptr, *ov = nullptr;
+    if (fresh()) {
+      ow = reinterpret_cast<double *>((uintptr_t)a->list_word[1]);
+      ov = reinterpret_cast<double *>((uintptr_t)a->list_word[2]);
+    } else {                                   // no record (the word is switched off): read the pointer block itself
+      double *hdr[PC_HEADER] = {};
+      HIP_TRY(hipMemcpy(hdr, a->ctl.pc, sizeof hdr, hipMemcpyDeviceToHost));
+      ow = hdr[PC_OLD_W];
+      ov = hdr[PC_OLD_V];
+    }
+    if (!ow || !ov) return fail(NKA_HIP_ESTATE, "accel_update_swap: the displaced buffers of the previous update are missing");
+    a->spare_w = ow;
+    a->spare_v = ov;
+    a->swap_pending = false;
+  }
+  if (!a->spare_w || !a->spare_v) {            // first out-of-place update of this handle: two more buffers
+    const size_t bytes = sizeof(double) * (size_t)a->vs.stride;
+    for (double **p : {&a->spare_w, &a->spare_v}) {
+      if (*p) continue;
+      void *q = nullptr;
+      hipError_t e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NKA_HIP_ENOMEM, std::string("accel_update_swap: hipMalloc of a spare buffer: ") + hipGetErrorString(e));
+      }
+      a->extra_allocs.push_back(q);
+      *p = static_cast<double *>(q);
+    }
+  }
+  return 0;
+}
+
+int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (!f_io || !f_acc || (!*f_io && a->n > 0)) return fail(NKA_HIP_EINVAL, "accel_update_swap: null argument");
+  if (a->host_dot) return fail(NKA_HIP_ESTATE, "accel_update_swap: not with a user dot product on host copies (nka_hip_set_host_dot)");
+  if (reinterpret_cast<uintptr_t>(*f_io) % 16 != 0) return fail(NKA_HIP_EINVAL, "accel_update_swap: the buffer must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(a->device));
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(a->stream, &cs) != hipSuccess) (void)hipGetLastError();
+  else if (cs != hipStreamCaptureStatusNone)
+    return fail(NKA_HIP_ESTATE, "accel_update_swap: cannot be captured into a graph (the host chooses buffers per call)");
+  if (int rc = collect_spares(a)) return rc;
+  double *const in = *f_io, *const give_w = a->spare_w, *const vnew = a->spare_v;
+  if (in == give_w || in == vnew) return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the library's own spare");
+  if (int rc = update_impl(a, in, in, vnew)) return rc;          // (a failed update is not done: the spares stay)
+  a->swapped = true;
+  a->swap_pending = true;
+  a->swap_seq = a->seq;
+  a->spare_w = a->spare_v = nullptr;
+  *f_io = give_w;
+  *f_acc = vnew;
   return 0;
 }
 
@@ -1170,17 +1321,21 @@ int nka_hip_defined(nka_hip_t a) {
   return 1;
 }
 
-static int get_slot(nka_hip_t a, const double *base, int32_t slot, double *host_out) {
+static int get_slot(nka_hip_t a, bool v, int32_t slot, double *host_out) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (slot < 1 || slot > a->mvec + 1) return fail(NKA_HIP_EINVAL, "slot out of range");
   HIP_TRY(hipSetDevice(a->device));
-  HIP_TRY(hipMemcpyAsync(host_out, base + (size_t)(slot - 1) * a->vs.stride, sizeof(double) * (size_t)a->n,
+  std::vector<double *> pc;
+  Ctl t{};
+  if (a->swapped)
+    if (int rc = fetch_tables(a, pc, t)) return rc;
+  HIP_TRY(hipMemcpyAsync(host_out, slot_buffer(a, a->swapped ? &t : nullptr, v, slot), sizeof(double) * (size_t)a->n,
                          hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
   return 0;
 }
-int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, a ? a->vs.w : nullptr, slot, host_out); }
-int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, a ? a->vs.v : nullptr, slot, host_out); }
+int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, false, slot, host_out); }
+int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out) { return get_slot(a, true, slot, host_out); }
 
 // ---- distribution hook ---------------------------------------------------------
 

@@ -72,6 +72,15 @@ enum {
 };
 // double control block
 enum { DC_VTOL = 0, DC_S = 1, DC_HEADER = 2 };
+// pointer control block (Ctl::pc)
+enum {
+  PC_FIRST_W = 0,  // w of the pending pair at the entry of the NEXT update (PA)
+  PC_NEW_W = 1,    // w, v buffers of the slot that receives (f_in, f_out) in the current update (PB)
+  PC_NEW_V = 2,
+  PC_OLD_W = 3,    // what an out-of-place update displaced from that slot (nullptr otherwise): handed to the caller /
+  PC_OLD_V = 4,    //   kept as the library's next spare
+  PC_HEADER = 8
+};
 
 constexpr int kMaxPerPass = 32;  // largest MAXL / MAXK instantiated
 
@@ -94,6 +103,17 @@ struct Ctl {
   // (F08:326-345) have made the list shorter than its own bookkeeping says (nka_hip.hip: list_bound_now).
   unsigned long long *hw;
   unsigned long long seq;
+  // POINTER CONTROL BLOCK.  The streaming passes take the ADDRESSES of the stored vectors from here, not slot
+  // numbers: wtab / vtab map slot -> buffer (at creation slot k -> base + (k-1)*stride of the two slot-major
+  // allocations; the out-of-place entry nka_hip_accel_update_swap exchanges entries with buffers of the caller),
+  // and the scalar kernels, which alone know the slots, resolve them when they write the plans.
+  double **pc;
+  __host__ __device__ double **plan_w() const { return pc + PC_HEADER; }          // w of PA's older entries [m1p]
+  __host__ __device__ double **comb_w() const { return plan_w() + m1p(); }        // w of PB's pairs [m1p]
+  __host__ __device__ double **comb_v() const { return comb_w() + m1p(); }        // v of PB's pairs [m1p]
+  __host__ __device__ double **wtab() const { return comb_v() + m1p(); }          // slot -> w buffer [m1+1], 1-based
+  __host__ __device__ double **vtab() const { return wtab() + (m1() + 1); }       // slot -> v buffer [m1+1]
+  __host__ __device__ int pc_count() const { return PC_HEADER + 3 * m1p() + 2 * (m1() + 1); }
   // plan_slots / comb_slots / comb_c are padded by one pass width: the unrolled
   // kernels read (and ignore) entries up to the end of their last pass.
   __host__ __device__ int m1() const { return mvec + 1; }
@@ -118,10 +138,18 @@ constexpr int kListWordLenBits = 20;        // mvec + 1 <= 2^17 + 1 (nka_hip_cre
 // update nothing and has landed long before the pass ends (a caller that synchronises once per iteration -- every
 // solver reads a residual norm -- sees the word of the update it has just waited for).  ncomb + 1 = the combined
 // entries plus the new pending pair = the list length at the exit of this update.
-__device__ __forceinline__ void list_word_publish(const Ctl &ctl, int ncomb) {
-  if (ctl.hw != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+// Words 1..3 of the record belong to the out-of-place updates: the buffers the update displaced (PC_OLD_W / PC_OLD_V),
+// written BEFORE the number of that update, which is stored with release semantics; other updates leave them alone.
+__device__ __forceinline__ void list_word_publish(const Ctl &ctl, int ncomb, int swapping) {
+  if (ctl.hw != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (swapping) {      // an out-of-place update: what it displaced (words 1, 2), then its number (word 3)
+      ctl.hw[1] = (unsigned long long)(uintptr_t)ctl.pc[PC_OLD_W];
+      ctl.hw[2] = (unsigned long long)(uintptr_t)ctl.pc[PC_OLD_V];
+      __hip_atomic_store(ctl.hw + 3, ctl.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __hip_atomic_store(ctl.hw, (ctl.seq << kListWordLenBits) | (unsigned long long)(ncomb + 1), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // red[] layout (raw sums of PA, d = w1 - f NOT yet divided by s):
@@ -284,14 +312,14 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int base = pass * MAXL;
-  const int32_t *slots = ctl.plan_slots();
   // no pending pair: d = f - f = 0 and its sums are discarded by k_finalize_dots
-  const double *w1 = pending ? vs.w + (size_t)(ctl.ic[IC_PLAN_FIRST] - 1) * vs.stride : f;
+  const double *w1 = pending ? ctl.pc[PC_FIRST_W] : f;
+  double *const *pw = ctl.plan_w();
   const double *wk[MAXL];
 #pragma unroll
   for (int j = 0; j < MAXL; j++) {
     const int p = base + j;
-    wk[j] = (p < nolder) ? vs.w + (size_t)(slots[p] - 1) * vs.stride : f;
+    wk[j] = (p < nolder) ? pw[p] : f;
   }
   double acc[NACC];
 #pragma unroll
@@ -359,22 +387,18 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  const int32_t *slots = ctl.plan_slots();
-  const int first = ctl.ic[IC_PLAN_FIRST];                 // (read whether pending or not: no branch around a load)
-  const double *w1p = vs.w + (size_t)(first - 1) * vs.stride;
+  double *const *pw = ctl.plan_w();
+  const double *w1p = ctl.pc[PC_FIRST_W];                  // (read whether pending or not: no branch around a load)
   const double *w1 = pending ? w1p : f;
   // every plan slot is requested at once, whether the list reaches it or not (the plan array is longer than any
   // width): written as `j < nolder ? slots[j] ...` each slot became a branch around its own s_load + s_waitcnt --
   // twenty serial scalar round trips, 4.2 k cycles of prologue at m = 20 against 2 k at m = 5
-  int32_t sl[MAXL];
+  const double *sl[MAXL];
 #pragma unroll
-  for (int j = 0; j < MAXL; j++) sl[j] = slots[j];
+  for (int j = 0; j < MAXL; j++) sl[j] = pw[j];
   const double *wk[MAXL];
 #pragma unroll
-  for (int j = 0; j < MAXL; j++) {
-    const double *p = vs.w + (size_t)(sl[j] - 1) * vs.stride;
-    wk[j] = (j < nolder) ? p : f;
-  }
+  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? sl[j] : f;
   double acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -499,6 +523,8 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
 // pending slot, still holding the raw previous f and update -- as
 // w1' = (w1-f)/s, v1' = v1/s formed in registers and stored back.  The last pass
 // stores v_new = f_out.
+enum { kPbNoStoreW = 1, kPbNoStoreF = 2 };   // `flags` of PB in an out-of-place update (nka_hip_accel_update_swap)
+
 template <int COMB>
 __device__ __forceinline__ double comb1(double x, double c, double w, double v) {
   if (COMB == 0) return (x - c * w) + c * v;
@@ -507,24 +533,27 @@ __device__ __forceinline__ double comb1(double x, double c, double w, double v) 
 }
 
 template <int MAXK, int VEC, int COMB>
-__global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass, int last_pass) {
+__global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f, int pass, int last_pass, int flags) {
   using V = typename VecT<VEC>::type;
   constexpr bool RCP = (COMB == 1);
   constexpr bool COMPACT = (COMB == 2);
   constexpr int NW = COMPACT ? 1 : MAXK;   // w vectors loaded per tile
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
-  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
-  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
-  const int32_t *cs = ctl.comb_slots();
+  double *wnew = ctl.pc[PC_NEW_W], *vnew = ctl.pc[PC_NEW_V];
+  double *const *cw = ctl.comb_w(), *const *cv = ctl.comb_v();
   const double *cc = ctl.comb_c();
   const int base = pass * MAXK;
-  const bool store_w = (pass == 0), store_v = (last_pass != 0);
-  const bool store_f = store_v ? (ncomb > 0) : true;  // nothing to combine: f stays as it is
+  // Out-of-place update (kPbNoStoreW / kPbNoStoreF): the caller's buffer f IS w_new and must keep f_in, and f_out goes
+  // to v_new only -- so between the passes of a long list the running value lives in v_new, never in f.
+  const bool oop = (flags & kPbNoStoreF) != 0;
+  const double *src = (oop && pass > 0) ? vnew : f;
+  const bool store_w = (pass == 0) && !(flags & kPbNoStoreW), store_v = (last_pass != 0) || oop;
+  const bool store_f = !oop && (last_pass != 0 ? (ncomb > 0) : true);  // nothing to combine: f stays as it is
   const bool norm0 = (pass == 0) && ctl.ic[IC_NORMED];
   const double s = ctl.dc[DC_S];
   const double rs = 1.0 / s;
-  if (pass == 0) list_word_publish(ctl, ncomb);
+  if (pass == 0) list_word_publish(ctl, ncomb, flags & kPbNoStoreW);
 
   double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
@@ -532,16 +561,15 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   for (int j = 0; j < MAXK; j++) {
     const int k = base + j;
     const bool live = k < ncomb;
-    const size_t off = live ? (size_t)(cs[k] - 1) * vs.stride : 0;
-    wk[j] = live ? vs.w + off : f;
-    vk[j] = live ? vs.v + off : f;
+    wk[j] = live ? cw[k] : f;
+    vk[j] = live ? cv[k] : f;
     ck[j] = cc[k];
   }
 
   const int64_t ntile = vs.n / (kBlock * VEC);
   for (int64_t t = blockIdx.x; t < ntile; t += G) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    const V fin = ld<VEC>(f + e);
+    const V fin = ld<VEC>(src + e);
     V wv[NW], vv[MAXK];
     if (!COMPACT || norm0) wv[0] = ld<VEC>(wk[0] + e); else wv[0] = fin;
 #pragma unroll
@@ -578,7 +606,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   }
   if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
-      const double fin = f[i];
+      const double fin = src[i];
       double x = fin;
 #pragma unroll
       for (int j = 0; j < MAXK; j++) {
@@ -662,7 +690,7 @@ __device__ __forceinline__ void ticket_finish(unsigned *tickets, int ng, int G) 
 }
 
 template <int MAXK, int COMB, int W, int T = 1>
-__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng) {
+__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng, int flags) {
   // T = 16-byte pieces per thread, stream and tile (tile = 512*T elements, 4*T KiB per stream and
   // block): T = 2 halves the ticket rate, which is what lets SHORT lists use one counter (a
   // single counter saturates near 60-75 tickets/us; tools/hbm_probe mode i: 12 + 5 streams move
@@ -673,6 +701,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   constexpr bool COMPACT = (COMB == 2);
   constexpr int TILE = kBlock * VEC * T;
   static_assert(MAXK % W == 0, "the ring must divide the pairs of a tile");
+  NKA_STAMP0(ctl, 14);
   __shared__ unsigned s_next[2];
   // The ragged tail (n mod TILE elements, scalar) has a block of its own, the LAST of the grid, launched only when
   // there is a tail: appended to the last tile block's work it made that block -- and so the launch -- one memory
@@ -682,28 +711,28 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   const int G = (int)gridDim.x - (has_tail ? 1 : 0);       // tile blocks
   const bool tail_block = has_tail && (int)blockIdx.x == G;
   const int ncomb = ctl.ic[IC_NCOMB];
-  const size_t newoff = (size_t)(ctl.ic[IC_NEW] - 1) * vs.stride;
-  double *wnew = vs.w + newoff, *vnew = vs.v + newoff;
-  const int32_t *cs = ctl.comb_slots();
+  double *wnew = ctl.pc[PC_NEW_W], *vnew = ctl.pc[PC_NEW_V];
+  double *const *cw = ctl.comb_w(), *const *cv = ctl.comb_v();
   const double *cc = ctl.comb_c();
+  const bool store_w = !(flags & kPbNoStoreW), store_f = !(flags & kPbNoStoreF);     // (uniform: out-of-place update)
   const bool norm0 = ctl.ic[IC_NORMED] != 0;
   const double s = ctl.dc[DC_S];
   const double rs = 1.0 / s;
 
   double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
-  int32_t sl[MAXK];
+  double *slw[MAXK], *slv[MAXK];
 #pragma unroll
-  for (int j = 0; j < MAXK; j++) {     // all slots and coefficients in one batch of scalar loads (see k_dots_win)
-    sl[j] = cs[j];
+  for (int j = 0; j < MAXK; j++) {     // all addresses and coefficients in one batch of scalar loads (see k_dots_win)
+    if (!COMPACT || j == 0) slw[j] = cw[j];      // (compact storage reads w of the pending pair only)
+    slv[j] = cv[j];
     ck[j] = cc[j];
   }
 #pragma unroll
   for (int j = 0; j < MAXK; j++) {
     const bool live = j < ncomb;
-    const size_t off = (size_t)(sl[j] - 1) * vs.stride;
-    wk[j] = live ? vs.w + off : f;
-    vk[j] = live ? vs.v + off : f;
+    wk[j] = (live && (!COMPACT || j == 0)) ? slw[COMPACT ? 0 : j] : f;
+    vk[j] = live ? slv[j] : f;
   }
   // compact storage reads w only for the pending pair that is normalised now
   const double *w0src = norm0 ? wk[0] : f;
@@ -726,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
         rv[j][q] = ld<VEC>(vk[j] + e + q * (kBlock * VEC));
       }
   }
-  list_word_publish(ctl, ncomb);               // (behind the first ring of loads: nothing waits for it)
+  list_word_publish(ctl, ncomb, flags & kPbNoStoreW);      // (behind the first ring of loads: nothing waits for it)
   // ticket counter of this block's group; ticket k of group g is tile (k + 2G/ng)*ng + g
   const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
   unsigned *const my_ticket = tickets ? tickets + grp * kTicketStride : nullptr;
@@ -746,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
       fin[q] = finv[q];
       w0[q] = COMPACT ? w0v[q] : fin[q];
       x[q] = fin[q];
-      st(wnew + e + q * (kBlock * VEC), fin[q]);
+      if (store_w) st(wnew + e + q * (kBlock * VEC), fin[q]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -802,8 +831,11 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 #pragma unroll
     for (int q = 0; q < T; q++) {
       st(vnew + e + q * (kBlock * VEC), x[q]);
-      st(f + e + q * (kBlock * VEC), x[q]);
+      if (store_f) st(f + e + q * (kBlock * VEC), x[q]);
     }
+#ifdef NKA_SOLVE_STAMPS
+    if (t == (int64_t)blockIdx.x) NKA_STAMP0(ctl, 15);       // block 0: its first tile is done
+#endif
     const int64_t t2 = tickets ? ticket_publish(s_next, par, claimed, ntile) : tnext + G;
     t = tnext;
     tnext = t2;
@@ -829,9 +861,9 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
           x = COMPACT ? x + ck[j] * v : comb1<COMB>(x, ck[j], w, v);
         }
       }
-      wnew[i] = fin;
+      if (store_w) wnew[i] = fin;
       vnew[i] = x;
-      f[i] = x;
+      if (store_f) f[i] = x;
     }
   }
 }
@@ -1001,9 +1033,25 @@ __device__ inline void lst_store(Lst &L, const Ctl &ctl, int in_global = 0) {
     ctl.ic[IC_PLAN_FIRST] = L.first;
     int n = 0;
     int32_t *ps = ctl.plan_slots();
-    for (int k = L.pending ? L.next[L.first] : L.first; k != 0; k = L.next[k]) ps[n++] = k;
+    double *const *wt = ctl.wtab();
+    for (int k = L.pending ? L.next[L.first] : L.first; k != 0; k = L.next[k]) {
+      ctl.plan_w()[n] = wt[k];       // the streaming passes get addresses, not slots (Ctl::pc)
+      ps[n++] = k;
+    }
     ctl.ic[IC_PLAN_NOLDER] = n;
+    ctl.pc[PC_FIRST_W] = wt[L.first];      // (entry 0 of the table is a valid dummy: first == 0 without a list)
   }
+}
+
+// The slot that receives the new pair gets its buffers here.  An out-of-place update (swap_w / swap_v != nullptr,
+// nka_hip_accel_update_swap) EXCHANGES them: the caller's buffer, which holds f_in, becomes the slot's w -- no copy --
+// and a spare buffer of the library becomes its v; what the slot held before is reported in PC_OLD_W / PC_OLD_V.
+__device__ inline void assign_new_buffers(const Ctl &ctl, int slot, double *swap_w, double *swap_v) {
+  double **wt = ctl.wtab(), **vt = ctl.vtab();
+  if (swap_w) { ctl.pc[PC_OLD_W] = wt[slot]; wt[slot] = swap_w; }      // (other updates leave PC_OLD_* alone: the host
+  if (swap_v) { ctl.pc[PC_OLD_V] = vt[slot]; vt[slot] = swap_v; }      //  may collect them later)
+  ctl.pc[PC_NEW_W] = wt[slot];
+  ctl.pc[PC_NEW_V] = vt[slot];
 }
 
 static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_restart(Ctl ctl, int in_global) {
@@ -1037,7 +1085,8 @@ __device__ __forceinline__ double solve_nrm(double x, double s, double rs, int m
 // comes behind F08:295-347): 1 = norm, s == 0 -> relax, Gram row, factorisation with drops; 2 = new slot, the
 // substitutions on the right-hand side the host has put into c[] BY SLOT, combine plan, prepend.
 static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global,
-                                                                                       int phase) {
+                                                                                       int phase, double *swap_w,
+                                                                                       double *swap_v) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem, in_global);
@@ -1079,12 +1128,15 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
         lst_solve(L);
         for (int k = L.first; k != 0; k = L.next[k]) {
           ctl.comb_slots()[ncomb] = k;
+          ctl.comb_w()[ncomb] = ctl.wtab()[k];
+          ctl.comb_v()[ncomb] = ctl.vtab()[k];
           ctl.comb_c()[ncomb] = L.c[k];
           ncomb++;
         }
       }
       ctl.ic[IC_NCOMB] = ncomb;
       ctl.ic[IC_NEW] = slot;
+      assign_new_buffers(ctl, slot, swap_w, swap_v);     // (before lst_store resolves the next plan through the tables)
       lst_prepend(L, slot);
     }
   }
@@ -1132,7 +1184,9 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   const int nl = mvec + 1;
   size_t b = (lst_smem_bytes(mvec) + 15) / 16 * 16;
   b += (size_t)((nl + 1) * (nl + 1) + 3 * nl + (2 + 2 * mvec)) * sizeof(double);
-  b += (size_t)(3 * nl) * sizeof(int32_t);
+  b += (size_t)(3 * nl + 1) * sizeof(int32_t);                // (+1: keeps the pointer tables behind them 8-byte aligned)
+  b = (b + 7) / 8 * 8;
+  b += (size_t)(2 * (nl + 1)) * sizeof(double *);             // slot -> buffer tables (Ctl::wtab / vtab)
   return b;
 }
 
@@ -1149,7 +1203,7 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
 // l_p = a_p[i] / L_ii on every lane, then for q = i+1 .. (uniform loop) a_p[q] -= l_p * l_q with
 // l_q = readlane(l, q) -- lanes p <= q update entries nobody reads.
 template <int NLMAX>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, double *swap_w, double *swap_v) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
@@ -1165,6 +1219,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
   double *redL = bb + NL;
   int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
   int32_t *psL = ord + 2 * NL;
+  double **wtL = reinterpret_cast<double **>((reinterpret_cast<uintptr_t>(psL + NL + 1) + 7) / 8 * 8);   // [m1 + 1]
+  double **vtL = wtL + (m1 + 1);                                                                          // [m1 + 1]
   NKA_STAMP(ctl, 0);
   // ---- one global round trip: EVERY load is issued before the first is waited for (written as plain
   //      loops the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eleven serial
@@ -1177,6 +1233,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
     static_assert(kSolveWaveMax + 1 <= kSolveThreads, "lists: one load a lane");
     const double *gh = ctl.h(), *gred = ctl.red();
     double hreg[kHB], rreg[2], creg = 0.0;
+    double *wtreg = nullptr, *vtreg = nullptr;
     int32_t nreg = 0, preg = 0, psreg = 0;
 #pragma unroll
     for (int k = 0; k < kHB; k++) hreg[k] = (lane + kSolveThreads * k < nh) ? gh[lane + kSolveThreads * k] : 0.0;
@@ -1186,6 +1243,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
       creg = ctl.c()[lane];
       nreg = ctl.next()[lane];
       preg = ctl.prev()[lane];
+      wtreg = ctl.wtab()[lane];
+      vtreg = ctl.vtab()[lane];
     }
     if (lane < M) psreg = ctl.plan_slots()[lane];        // (bounded by mvec, not by the count still on its way)
 #pragma unroll
@@ -1198,6 +1257,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
       L.c[lane] = creg;
       L.next[lane] = nreg;
       L.prev[lane] = preg;
+      wtL[lane] = wtreg;
+      vtL[lane] = vtreg;
     }
     if (lane < nolder) psL[lane] = psreg;
     for (int i = lane + kSolveThreads * kHB; i < nh; i += kSolveThreads) L.h[i] = gh[i];
@@ -1339,6 +1400,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
   NKA_STAMP(ctl, 5);
   const int slot = L.free_;                    // F08:357-358
   L.free_ = L.next[slot];
+  // buffers of the new pair (every lane computes the same values; lane 0 writes them): an out-of-place update exchanges
+  // them (assign_new_buffers).  The new slot is never one of the entries combined below (it comes off the free list).
+  double *const new_w = swap_w ? swap_w : wtL[slot], *const new_v = swap_v ? swap_v : vtL[slot];
+  if (lane == 0) {
+    if (swap_w) ctl.pc[PC_OLD_W] = wtL[slot];  // (other updates leave PC_OLD_* alone: the host may collect them later)
+    if (swap_v) ctl.pc[PC_OLD_V] = vtL[slot];
+    ctl.pc[PC_NEW_W] = new_w;
+    ctl.pc[PC_NEW_V] = new_v;
+    ctl.pc[PC_FIRST_W] = new_w;                // the new pair is the pending pair of the next update
+    if (swap_w) ctl.wtab()[slot] = swap_w;
+    if (swap_v) ctl.vtab()[slot] = swap_v;
+  }
   if (forward_done) {
     // back-substitution F08:382-392 in position space: the factor lies in A, its
     // diagonal in Ldr, the forward-substituted right-hand side in yr
@@ -1363,6 +1436,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
       ctl.comb_slots()[r] = myord;
       ctl.comb_c()[r] = yr;
       ctl.plan_slots()[r] = myord;             // the next update's older entries: this list, in order
+      double *const wb = wtL[myord];
+      ctl.comb_w()[r] = wb;                    // ... and their addresses for the streaming passes (Ctl::pc)
+      ctl.comb_v()[r] = vtL[myord];
+      ctl.plan_w()[r] = wb;
       L.c[myord] = yr;
     }
   } else if (L.subspace) {
@@ -1393,6 +1470,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode)
       ctl.comb_slots()[p] = ord[p];
       ctl.comb_c()[p] = bb[p];
       ctl.plan_slots()[p] = ord[p];
+      ctl.comb_w()[p] = wtL[ord[p]];
+      ctl.comb_v()[p] = vtL[ord[p]];
+      ctl.plan_w()[p] = wtL[ord[p]];
       L.c[ord[p]] = bb[p];
     }
   }

@@ -114,6 +114,8 @@ class nka:  # noqa: N801  (the reference's type name)
         if self._h is not None:
             self._L.nka_hip_destroy(self._h)
             self._h = None
+            self.__dict__.pop("_views", None)           # (views of library buffers die with the handle)
+            self.__dict__.pop("_swap_keep", None)
 
     def __del__(self):
         try:
@@ -244,6 +246,43 @@ class nka:  # noqa: N801  (the reference's type name)
                 self.set_stream(cur)
         _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update", self._L)
         return f
+
+    def accel_update_swap(self, f):
+        """Out-of-place update (nka_hip_accel_update_swap): `f`, a float64 CUDA tensor holding the correction, is HANDED
+        to the accelerator -- it becomes the storage of the new pair's w, so it is kept alive here and must not be
+        written again.  Returns (buf, acc): `buf`, a tensor view of a free library buffer for the caller's next input;
+        `acc`, a view of the accelerated correction, to be read only, valid until the next call on this object."""
+        import torch
+        h = self._handle()
+        if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float64 and f.is_contiguous()
+                and f.numel() == self._vlen and f.device.index == self._device):
+            raise NKAError("accel_update_swap: need a contiguous float64 CUDA tensor of vec_len() elements on the accelerator's device")
+        if self._follow_torch_stream:
+            cur = int(torch.cuda.current_stream(self._device).cuda_stream)
+            if cur != self._stream:
+                self.set_stream(cur)
+        io, acc = C.c_void_p(f.data_ptr()), C.c_void_p()
+        _check(self._L.nka_hip_accel_update_swap(h, C.byref(io), C.byref(acc)), "accel_update_swap", self._L)
+        if not hasattr(self, "_swap_keep"):
+            self._swap_keep = []
+        if not any(t.data_ptr() == f.data_ptr() for t in self._swap_keep):
+            self._swap_keep.append(f)                   # the library keeps using this memory
+            self.__dict__.setdefault("_views", {}).setdefault(f.data_ptr(), f)
+        return self._view(io.value), self._view(acc.value)
+
+    def _view(self, ptr):
+        import torch
+        cache = self.__dict__.setdefault("_views", {})          # (a handful of buffers circulate: wrap each once)
+        if ptr in cache:
+            return cache[ptr]
+
+        class _Alias:
+            def __init__(self, p, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (p, False), "version": 2}
+        if self._vlen == 0:
+            return torch.empty(0, dtype=torch.float64, device=f"cuda:{self._device}")
+        cache[ptr] = torch.as_tensor(_Alias(ptr, self._vlen), device=f"cuda:{self._device}")
+        return cache[ptr]
 
     def capture_safe(self) -> bool:
         """True once an accel_update captured into a hipGraph stays valid on replay

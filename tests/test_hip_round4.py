@@ -201,3 +201,80 @@ def test_a_rank_with_a_bad_pointer_still_joins_the_collective_of_a_parallel_redu
     rc = L.nka_hip_vec_dot_many(h, n, C.c_void_p(x.data_ptr()), ys, 3, vals)
     assert rc != 0 and len(calls) == 3 and calls[2] == [0.0, 0.0, 0.0]
     L.nka_hip_vec_workspace_destroy(h)
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+@pytest.mark.parametrize("n,m", [(100003, 6), (40960, 20), (513, 3), (300007, 40)])
+def test_out_of_place_updates_give_the_same_bits_with_two_stores_less(torch_cuda, oracle, flavor, n, m):
+    """nka_hip_accel_update_swap: the caller's buffer becomes w_new, the accelerated f is stored once (as v_new) and
+    lent to the caller.  Against an accelerator driven through the in-place entry on the same inputs: every output
+    bit, the replicated state and the stored vectors of the live entries -- through growth, capacity and dependence
+    drops, a repeated input (s == 0), relax, restart, a deep copy in mid-stream and in-place calls mixed in."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(7 * m + flavor)
+    basis = rng.standard_normal((3, n))
+    X = [rng.standard_normal(3) @ basis if t % 6 == 4 else rng.standard_normal(n) for t in range(m + 14)]
+    X[m + 4] = X[m + 3].copy()
+    a = nka_amd.nka().init(n, m, flavor=flavor)        # in place
+    b = nka_amd.nka().init(n, m, flavor=flavor)        # out of place
+    ora = oracle.OracleNKA(n, m, flavor)
+    buf = torch.empty(n, dtype=torch.float64, device="cuda")
+    seen = set()
+    for t, x in enumerate(X):
+        fo = x.copy()
+        ora.accel_update(fo)
+        fa = torch.from_numpy(x.copy()).cuda()
+        a.accel_update(fa)
+        if t % 7 == 5:                                  # an in-place call in between: the entries can be mixed
+            fb = torch.from_numpy(x.copy()).cuda()
+            b.accel_update(fb)
+            acc = fb
+        else:
+            buf.copy_(torch.from_numpy(x))
+            seen.add(buf.data_ptr())
+            buf, acc = b.accel_update_swap(buf)
+            assert acc.data_ptr() != buf.data_ptr()
+        if t % 3 == 0:
+            torch.cuda.synchronize()                    # (sometimes the record is fresh, sometimes the call must wait)
+        assert torch.equal(acc, fa), (t, float((acc - fa).abs().max()))
+        assert a.state_digest() == b.state_digest(), t
+        assert b.state().list_order() == ora.state().list_order(), t
+        if t == m + 6:
+            a.relax(); b.relax(); ora.relax()
+        if t == m + 9:
+            a.restart(); b.restart(); ora.restart()
+        if t == m + 2:
+            c = b.copy()                                # deep copy of an accelerator whose vectors live in foreign buffers
+            sa, sc = a.state(), c.state()
+            assert c.state_digest() == a.state_digest()
+            for k in sa.list_order():
+                assert np.array_equal(a.w(k), c.w(k)) and np.array_equal(a.v(k), c.v(k)), (t, k)
+                assert np.array_equal(a.w(k), b.w(k)) and np.array_equal(a.v(k), b.v(k)), (t, k)
+            fc, fa2 = torch.from_numpy(X[0].copy()).cuda(), torch.from_numpy(X[0].copy()).cuda()
+            c.accel_update(fc)
+            a2 = a.copy()
+            a2.accel_update(fa2)
+            assert torch.equal(fc, fa2)
+    assert len(seen) >= 3 and a.defined() and b.defined()        # the buffers really circulate
+
+
+def test_out_of_place_update_argument_checks(torch_cuda):
+    import ctypes as C
+    import nka_amd
+    torch = torch_cuda
+    a = nka_amd.nka().init(1000, 3)
+    with pytest.raises(nka_amd.NKAError):
+        a.accel_update_swap(torch.zeros(999, dtype=torch.float64, device="cuda"))
+    odd = torch.zeros(1001, dtype=torch.float64, device="cuda")[1:]          # not 16-byte aligned
+    with pytest.raises(nka_amd.NKAError, match="aligned"):
+        a.accel_update_swap(odd)
+    a.set_host_dot(lambda x, y: float(np.dot(x, y)))
+    with pytest.raises(nka_amd.NKAError, match="user dot product"):
+        a.accel_update_swap(torch.zeros(1000, dtype=torch.float64, device="cuda"))
+    a.set_host_dot(None)
+    f = torch.ones(1000, dtype=torch.float64, device="cuda")
+    buf, acc = a.accel_update_swap(f)
+    assert torch.equal(acc, torch.ones_like(acc))         # the first update returns its input
+    buf2, acc2 = a.accel_update_swap(buf)                 # the lent buffer comes back as the next input: the normal protocol
+    assert buf2.data_ptr() not in (buf.data_ptr(), acc2.data_ptr()) and a.num_vec() == 1

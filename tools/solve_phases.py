@@ -33,6 +33,7 @@ def main():
     rng = np.random.default_rng(0)
     rows = []
     pa_rows = []
+    pb_rows = []
     for t in range(m + 12):
         f = torch.from_numpy(rng.standard_normal(n)).cuda()
         acc.accel_update(f)
@@ -41,6 +42,7 @@ def main():
         if t >= m + 2:
             rows.append(np.diff(st[:10]))
             pa_rows.append(np.diff(st[10:14]))
+            pb_rows.append((st[0] - st[13], st[14] - st[9], st[15] - st[14]))
     d = np.median(np.array(rows), axis=0)
     tot = d.sum()
     print(f"k_solve_rows phases, mvec={m} (median of {len(rows)} steady-state updates), s_memtime ticks (shader-clock cycles, ~2.1-2.4 GHz):")
@@ -49,6 +51,10 @@ def main():
     print(f"  {'total inside the kernel':<42s} {tot:8.0f} cycles")
     pa = np.median(np.array(pa_rows), axis=0)
     print(f"k_dots_win block 0, n={n}: entry -> first loads issued {pa[0]:.0f}, tile loop {pa[1]:.0f}, block reduction + partial store {pa[2]:.0f} cycles")
+    pb = np.median(np.array(pb_rows), axis=0)
+    print(f"between the kernels (one clock for all: s_memtime), n={n}: end of PA's block 0 -> entry of the scalar step {pb[0]:.0f} cycles "
+          f"(final sums + two kernel boundaries); end of the scalar step -> entry of PB's block 0 {pb[1]:.0f}; PB block 0: entry -> its "
+          f"first tile done {pb[2]:.0f}")
 
 
 if __name__ == "__main__":
