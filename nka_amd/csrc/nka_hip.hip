@@ -237,6 +237,14 @@ struct nka_hip_state {
   std::vector<hipEvent_t> ev;
 };
 
+// Entries of the address block (Ctl::pc) are offsets in doubles from vs.w (nka_kernels.hpp).
+static inline long long buffer_offset(const nka_hip_state *a, const double *p) {
+  return (long long)((reinterpret_cast<intptr_t>(p) - reinterpret_cast<intptr_t>(a->vs.w)) / (intptr_t)sizeof(double));
+}
+static inline double *buffer_at(const nka_hip_state *a, long long off) {
+  return reinterpret_cast<double *>(reinterpret_cast<intptr_t>(a->vs.w) + (intptr_t)off * (intptr_t)sizeof(double));
+}
+
 namespace {
 
 // Persistent grid: one block per resident slot (occupancy of THIS instantiation
@@ -594,7 +602,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   alloc((void **)&a->ctl.dc, sizeof(double) * a->ctl.dc_count());
   alloc((void **)&a->partials, sizeof(double) * (size_t)kMaxGrid * (2 * kMaxPerPass + 2));  // NACC columns of k_dots
   alloc((void **)&a->tickets, sizeof(unsigned) * kTicketWords);
-  alloc((void **)&a->ctl.pc, sizeof(double *) * a->ctl.pc_count());
+  alloc((void **)&a->ctl.pc, sizeof(long long) * a->ctl.pc_count());
   if (!rc) {
     // the list word: fine-grained pinned host memory the device writes and the host polls (no synchronisation)
     void *hw = nullptr;
@@ -626,15 +634,15 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     return fail(NKA_HIP_EHIP, "initialising the control block failed");
   }
   {
-    // slot -> buffer tables: slot k at base + (k-1)*stride of the two slot-major allocations (Ctl::pc)
-    std::vector<double *> pc((size_t)a->ctl.pc_count(), nullptr);
+    // slot -> buffer tables: slot k at (k-1)*stride of the two slot-major allocations, as offsets from vs.w (Ctl::pc)
+    std::vector<long long> pc((size_t)a->ctl.pc_count(), 0);
     Ctl h = a->ctl;
     h.pc = pc.data();
     for (int k = 1; k <= mvec + 1; k++) {
-      h.wtab()[k] = a->vs.w + (size_t)(k - 1) * a->vs.stride;
-      h.vtab()[k] = a->vs.v + (size_t)(k - 1) * a->vs.stride;
+      h.wtab()[k] = buffer_offset(a, a->vs.w + (size_t)(k - 1) * a->vs.stride);
+      h.vtab()[k] = buffer_offset(a, a->vs.v + (size_t)(k - 1) * a->vs.stride);
     }
-    if (hipMemcpy(a->ctl.pc, pc.data(), sizeof(double *) * pc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(a->ctl.pc, pc.data(), sizeof(long long) * pc.size(), hipMemcpyHostToDevice) != hipSuccess) {
       nka_hip_destroy(a);
       return fail(NKA_HIP_EHIP, "initialising the pointer block failed");
     }
@@ -704,9 +712,9 @@ int nka_hip_destroy(nka_hip_t a) {
 }
 
 // The slot -> buffer tables as they stand on the device (synchronises).  t.wtab()[k], t.vtab()[k] for k = 1..mvec+1.
-static int fetch_tables(nka_hip_t a, std::vector<double *> &pc, Ctl &t) {
-  pc.assign((size_t)a->ctl.pc_count(), nullptr);
-  HIP_TRY(hipMemcpyAsync(pc.data(), a->ctl.pc, sizeof(double *) * pc.size(), hipMemcpyDeviceToHost, a->stream));
+static int fetch_tables(nka_hip_t a, std::vector<long long> &pc, Ctl &t) {
+  pc.assign((size_t)a->ctl.pc_count(), 0);
+  HIP_TRY(hipMemcpyAsync(pc.data(), a->ctl.pc, sizeof(long long) * pc.size(), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
   t = a->ctl;
   t.pc = pc.data();
@@ -714,7 +722,7 @@ static int fetch_tables(nka_hip_t a, std::vector<double *> &pc, Ctl &t) {
 }
 // w / v buffer of a slot for the host-side paths (queries, the user-dot-product path, deep copies)
 static const double *slot_buffer(nka_hip_t a, const Ctl *tables, bool v, int slot) {
-  if (tables) return v ? tables->vtab()[slot] : tables->wtab()[slot];
+  if (tables) return buffer_at(a, v ? tables->vtab()[slot] : tables->wtab()[slot]);
   return (v ? a->vs.v : a->vs.w) + (size_t)(slot - 1) * a->vs.stride;
 }
 // After the control blocks of a copy have been filled from another object: the addresses of PA's plan through THIS
@@ -745,7 +753,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   } else {
     // out-of-place updates have moved src's vectors into other buffers (some of them the caller's): the copy gets
     // its own slot-major storage, filled slot by slot through src's tables
-    std::vector<double *> pc;
+    std::vector<long long> pc;
     Ctl t{};
     if (int rc = fetch_tables(src, pc, t)) {
       nka_hip_destroy(b);
@@ -753,8 +761,9 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
     }
     const size_t nb = sizeof(double) * (size_t)src->n;
     for (int k = 1; k <= src->mvec + 1 && e == hipSuccess && nb > 0; k++) {
-      e = hipMemcpyAsync(b->vs.w + (size_t)(k - 1) * b->vs.stride, t.wtab()[k], nb, hipMemcpyDeviceToDevice, s);
-      if (e == hipSuccess) e = hipMemcpyAsync(b->vs.v + (size_t)(k - 1) * b->vs.stride, t.vtab()[k], nb, hipMemcpyDeviceToDevice, s);
+      e = hipMemcpyAsync(b->vs.w + (size_t)(k - 1) * b->vs.stride, buffer_at(src, t.wtab()[k]), nb, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(b->vs.v + (size_t)(k - 1) * b->vs.stride, buffer_at(src, t.vtab()[k]), nb, hipMemcpyDeviceToDevice, s);
     }
   }
   if (e == hipSuccess) e = hipMemcpyAsync(b->ctl.ic, src->ctl.ic, sizeof(int32_t) * src->ctl.ic_count(), hipMemcpyDeviceToDevice, s);
@@ -833,7 +842,7 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
 }
 
 // ---- the three stages of an update, enqueued on the handle's stream -------------
-static int enqueue_solve(nka_hip_t a, int mode, double *swap_w = nullptr, double *swap_v = nullptr) {
+static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, long long swap_v = kNoBuffer) {
   hipStream_t s = a->stream;
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
@@ -958,7 +967,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   if (nolder < 0 || nolder > mvec + 1 || (pending && (first < 1 || first > mvec + 1)))
     return fail(NKA_HIP_ESTATE, "host dot path: corrupt dot plan on the device");
   const size_t nb = sizeof(double) * (size_t)n;
-  std::vector<double *> pcs;       // (after out-of-place updates the vectors are where the tables say)
+  std::vector<long long> pcs;      // (after out-of-place updates the vectors are where the tables say)
   Ctl tabs{};
   if (a->swapped)
     if (int rc = fetch_tables(a, pcs, tabs)) return rc;
@@ -997,7 +1006,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   // ---- device: norm, s == 0 -> relax, Gram row, Cholesky with drops (the reference's loops on one lane)
   const size_t smem = a->state_in_global ? 0 : lst_smem_bytes(a->mvec);
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 1, (double *)nullptr, (double *)nullptr);
+                     a->state_in_global ? 1 : 0, 1, kNoBuffer, kNoBuffer);
   HIP_TRY(hipGetLastError());
   // Phase 1 has changed the lists, the free list, h and the flags on the device.  Whatever fails between here and
   // phase 2 (a copy, a corrupt list, the user's dp) must not leave a half-applied update behind: the control blocks
@@ -1044,20 +1053,20 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   HIP_TRY_UNDO(hipMemcpyAsync(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice, a->stream));
   // ---- device: new slot, substitutions, plans, prepend
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 2, (double *)nullptr, (double *)nullptr);
+                     a->state_in_global ? 1 : 0, 2, kNoBuffer, kNoBuffer);
   HIP_TRY_UNDO(hipGetLastError());
   HIP_TRY_UNDO(hipStreamSynchronize(a->stream));     // (c[] and red[] above are read by the stream until here)
 #undef HIP_TRY_UNDO
   return 0;
 }
 
-static int update_impl(nka_hip_t a, double *f, double *swap_w, double *swap_v);
+static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
 
-int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, nullptr, nullptr); }
+int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, kNoBuffer, kNoBuffer); }
 
-// One update.  swap_w / swap_v != nullptr: out of place (nka_hip_accel_update_swap) -- f (== swap_w) becomes the w buffer of
-// the new pair and swap_v its v buffer; PB then stores neither w_new nor f.
-static int update_impl(nka_hip_t a, double *f, double *swap_w, double *swap_v) {
+// One update.  swap_w / swap_v != kNoBuffer (offsets from vs.w): out of place (nka_hip_accel_update_swap) -- f (== swap_w)
+// becomes the w buffer of the new pair and swap_v its v buffer; PB then stores neither w_new nor f.
+static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
@@ -1114,7 +1123,7 @@ static int update_impl(nka_hip_t a, double *f, double *swap_w, double *swap_v) {
     Ctl &c = a->ctl;
     unsigned long long *const hw = c.hw;
     if (a->word_off) c.hw = nullptr;
-    a->pb_flags = swap_w ? (kPbNoStoreW | kPbNoStoreF) : 0;
+    a->pb_flags = swap_w != kNoBuffer ? (kPbNoStoreW | kPbNoStoreF) : 0;
     const int rc = enqueue_pb(a, f, vec, comb_ub);
     a->pb_flags = 0;
     c.hw = hw;
@@ -1154,13 +1163,13 @@ static int collect_spares(nka_hip_t a) {
     if (!fresh()) HIP_TRY(hipStreamSynchronize(a->stream));
     double *ow = nullptr, *ov = nullptr;
     if (fresh()) {
-      ow = reinterpret_cast<double *>((uintptr_t)a->list_word[1]);
-      ov = reinterpret_cast<double *>((uintptr_t)a->list_word[2]);
-    } else {                                   // no record (the word is switched off): read the pointer block itself
-      double *hdr[PC_HEADER] = {};
+      ow = buffer_at(a, (long long)a->list_word[1]);
+      ov = buffer_at(a, (long long)a->list_word[2]);
+    } else {                                   // no record (the word is switched off): read the address block itself
+      long long hdr[PC_HEADER] = {};
       HIP_TRY(hipMemcpy(hdr, a->ctl.pc, sizeof hdr, hipMemcpyDeviceToHost));
-      ow = hdr[PC_OLD_W];
-      ov = hdr[PC_OLD_V];
+      ow = buffer_at(a, hdr[PC_OLD_W]);
+      ov = buffer_at(a, hdr[PC_OLD_V]);
     }
     if (!ow || !ov) return fail(NKA_HIP_ESTATE, "accel_update_swap: the displaced buffers of the previous update are missing");
     a->spare_w = ow;
@@ -1197,7 +1206,7 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
   if (int rc = collect_spares(a)) return rc;
   double *const in = *f_io, *const give_w = a->spare_w, *const vnew = a->spare_v;
   if (in == give_w || in == vnew) return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the library's own spare");
-  if (int rc = update_impl(a, in, in, vnew)) return rc;          // (a failed update is not done: the spares stay)
+  if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;   // (a failed update is not done: the spares stay)
   a->swapped = true;
   a->swap_pending = true;
   a->swap_seq = a->seq;
@@ -1325,7 +1334,7 @@ static int get_slot(nka_hip_t a, bool v, int32_t slot, double *host_out) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (slot < 1 || slot > a->mvec + 1) return fail(NKA_HIP_EINVAL, "slot out of range");
   HIP_TRY(hipSetDevice(a->device));
-  std::vector<double *> pc;
+  std::vector<long long> pc;
   Ctl t{};
   if (a->swapped)
     if (int rc = fetch_tables(a, pc, t)) return rc;

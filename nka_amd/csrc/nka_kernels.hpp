@@ -43,6 +43,13 @@
 #ifndef NKA_NT_LOADS
 #define NKA_NT_LOADS 1      // streaming reads: non-temporal (nt) loads
 #endif
+#ifndef NKA_DEAD_SLOT_TILE0
+// A launch wider than the list (the host's bound is one too high in the update that takes a dependence drop, and too high
+// by more for a caller that never synchronises) has DEAD ring slots.  In PB they re-read f: 1 = always its first tile (4 KiB
+// that stay in the caches), 0 = the tile at hand, as before round 4 -- half of which came from HBM again (PMC: 19.55 words
+// per element where the list needs 19; PB -2.5 % with the first tile, neutral without dead slots).
+#define NKA_DEAD_SLOT_TILE0 1
+#endif
 #ifndef NKA_STORE_POLICY
 #define NKA_STORE_POLICY 1  // 0 plain, 1 nt (default: +2-3% on the mixed pass), 2 write-through "sc0 sc1 nt" (inline asm)
 #endif
@@ -77,7 +84,7 @@ enum {
   PC_FIRST_W = 0,  // w of the pending pair at the entry of the NEXT update (PA)
   PC_NEW_W = 1,    // w, v buffers of the slot that receives (f_in, f_out) in the current update (PB)
   PC_NEW_V = 2,
-  PC_OLD_W = 3,    // what an out-of-place update displaced from that slot (nullptr otherwise): handed to the caller /
+  PC_OLD_W = 3,    // what an out-of-place update displaced from that slot: handed to the caller /
   PC_OLD_V = 4,    //   kept as the library's next spare
   PC_HEADER = 8
 };
@@ -103,16 +110,19 @@ struct Ctl {
   // (F08:326-345) have made the list shorter than its own bookkeeping says (nka_hip.hip: list_bound_now).
   unsigned long long *hw;
   unsigned long long seq;
-  // POINTER CONTROL BLOCK.  The streaming passes take the ADDRESSES of the stored vectors from here, not slot
-  // numbers: wtab / vtab map slot -> buffer (at creation slot k -> base + (k-1)*stride of the two slot-major
-  // allocations; the out-of-place entry nka_hip_accel_update_swap exchanges entries with buffers of the caller),
-  // and the scalar kernels, which alone know the slots, resolve them when they write the plans.
-  double **pc;
-  __host__ __device__ double **plan_w() const { return pc + PC_HEADER; }          // w of PA's older entries [m1p]
-  __host__ __device__ double **comb_w() const { return plan_w() + m1p(); }        // w of PB's pairs [m1p]
-  __host__ __device__ double **comb_v() const { return comb_w() + m1p(); }        // v of PB's pairs [m1p]
-  __host__ __device__ double **wtab() const { return comb_v() + m1p(); }          // slot -> w buffer [m1+1], 1-based
-  __host__ __device__ double **vtab() const { return wtab() + (m1() + 1); }       // slot -> v buffer [m1+1]
+  // ADDRESS CONTROL BLOCK.  The streaming passes take the ADDRESSES of the stored vectors from here, not slot numbers:
+  // wtab / vtab map slot -> buffer (at creation slot k -> (k-1)*stride of the two slot-major allocations; the out-of-place
+  // entry nka_hip_accel_update_swap exchanges entries with buffers of the caller), and the scalar kernels, which alone know
+  // the slots, resolve them when they write the plans.  Every entry is an OFFSET IN DOUBLES FROM Vecs::w (any buffer of the
+  // device, the caller's included, is some 64-bit offset from it): a pointer read from memory carries no address space and
+  // the compiler would reach it with FLAT loads -- one counter for LDS and memory, every wait a wait for everything (the
+  // first version of this block did: PB -13 %) -- while vs.w + offset is a global address like any kernel argument.
+  long long *pc;
+  __host__ __device__ long long *plan_w() const { return pc + PC_HEADER; }          // w of PA's older entries [m1p]
+  __host__ __device__ long long *comb_w() const { return plan_w() + m1p(); }        // w of PB's pairs [m1p]
+  __host__ __device__ long long *comb_v() const { return comb_w() + m1p(); }        // v of PB's pairs [m1p]
+  __host__ __device__ long long *wtab() const { return comb_v() + m1p(); }          // slot -> w buffer [m1+1], 1-based
+  __host__ __device__ long long *vtab() const { return wtab() + (m1() + 1); }       // slot -> v buffer [m1+1]
   __host__ __device__ int pc_count() const { return PC_HEADER + 3 * m1p() + 2 * (m1() + 1); }
   // plan_slots / comb_slots / comb_c are padded by one pass width: the unrolled
   // kernels read (and ignore) entries up to the end of their last pass.
@@ -133,6 +143,7 @@ struct Ctl {
     return DC_HEADER + (m1() + 1) * (m1() + 1) + (m1() + 1) + m1p() + red_count() + kStamps;
   }
 };
+constexpr long long kNoBuffer = (long long)0x8000000000000000ull;      // "no buffer" among the offsets of Ctl::pc
 constexpr int kListWordLenBits = 20;        // mvec + 1 <= 2^17 + 1 (nka_hip_create)
 // PB, first thread of block 0, before its first tile: the store is posted while the pass streams, so it costs the
 // update nothing and has landed long before the pass ends (a caller that synchronises once per iteration -- every
@@ -143,8 +154,8 @@ constexpr int kListWordLenBits = 20;        // mvec + 1 <= 2^17 + 1 (nka_hip_cre
 __device__ __forceinline__ void list_word_publish(const Ctl &ctl, int ncomb, int swapping) {
   if (ctl.hw != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     if (swapping) {      // an out-of-place update: what it displaced (words 1, 2), then its number (word 3)
-      ctl.hw[1] = (unsigned long long)(uintptr_t)ctl.pc[PC_OLD_W];
-      ctl.hw[2] = (unsigned long long)(uintptr_t)ctl.pc[PC_OLD_V];
+      ctl.hw[1] = (unsigned long long)ctl.pc[PC_OLD_W];       // (offsets from Vecs::w, like everything in the block)
+      ctl.hw[2] = (unsigned long long)ctl.pc[PC_OLD_V];
       __hip_atomic_store(ctl.hw + 3, ctl.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __hip_atomic_store(ctl.hw, (ctl.seq << kListWordLenBits) | (unsigned long long)(ncomb + 1), __ATOMIC_RELAXED,
@@ -313,13 +324,13 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int base = pass * MAXL;
   // no pending pair: d = f - f = 0 and its sums are discarded by k_finalize_dots
-  const double *w1 = pending ? ctl.pc[PC_FIRST_W] : f;
-  double *const *pw = ctl.plan_w();
+  const double *w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f;
+  const long long *pw = ctl.plan_w();
   const double *wk[MAXL];
 #pragma unroll
   for (int j = 0; j < MAXL; j++) {
     const int p = base + j;
-    wk[j] = (p < nolder) ? pw[p] : f;
+    wk[j] = (p < nolder) ? vs.w + pw[p] : f;
   }
   double acc[NACC];
 #pragma unroll
@@ -387,23 +398,28 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  double *const *pw = ctl.plan_w();
-  const double *w1p = ctl.pc[PC_FIRST_W];                  // (read whether pending or not: no branch around a load)
+  const long long *pw = ctl.plan_w();
+  const double *w1p = vs.w + ctl.pc[PC_FIRST_W];           // (read whether pending or not: no branch around a load)
   const double *w1 = pending ? w1p : f;
   // every plan slot is requested at once, whether the list reaches it or not (the plan array is longer than any
   // width): written as `j < nolder ? slots[j] ...` each slot became a branch around its own s_load + s_waitcnt --
   // twenty serial scalar round trips, 4.2 k cycles of prologue at m = 20 against 2 k at m = 5
-  const double *sl[MAXL];
+  long long sl[MAXL];
 #pragma unroll
   for (int j = 0; j < MAXL; j++) sl[j] = pw[j];
   const double *wk[MAXL];
 #pragma unroll
-  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? sl[j] : f;
+  for (int j = 0; j < MAXL; j++) wk[j] = (j < nolder) ? vs.w + sl[j] : f;
   double acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; a++) acc[a] = 0.0;
 
   const int64_t ntile = vs.n / (kBlock * VEC);
+  // (dead ring slots -- a launch wider than the list -- re-read f at the tile at hand here.  Sending them to f's first
+  //  tile, as PB does (NKA_DEAD_SLOT_TILE0), was measured in this pass too: 25 more VGPRs for the per-slot offsets and
+  //  +2...5 % of PA with NO dead slot, which is every launch of a caller that synchronises once per iteration, since PA
+  //  then runs at exactly the list length; profiles/r04/ab_dead_slot.txt)
+#define DEAD_OFF(live, off) (off)
   V fv, w1v, ring[W];
   int64_t t = blockIdx.x;
   if (t < ntile) {
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
     fv = ld<VEC>(f + e);
     w1v = ld<VEC>(w1 + e);
 #pragma unroll
-    for (int j = 0; j < W; j++) ring[j] = ld<VEC>(wk[j] + e);
+    for (int j = 0; j < W; j++) ring[j] = ld<VEC>(wk[j] + (DEAD_OFF(j < nolder, e)));
   }
   NKA_STAMP0(ctl, 11);
   for (; t < ntile; t += G) {
@@ -433,8 +449,8 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
     for (int j = 0; j < MAXL; j++) {
       const V x = ring[j % W];
       __builtin_amdgcn_sched_barrier(0);
-      if (j + W < MAXL) ring[j % W] = ld<VEC>(wk[j + W] + e);
-      else ring[j % W] = ld<VEC>(wk[j + W - MAXL] + en);
+      if (j + W < MAXL) ring[j % W] = ld<VEC>(wk[j + W] + (DEAD_OFF(j + W < nolder, e)));
+      else ring[j % W] = ld<VEC>(wk[j + W - MAXL] + (DEAD_OFF(j + W - MAXL < nolder, en)));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < VEC; q++) {
@@ -460,6 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   NKA_STAMP0(ctl, 12);
   block_reduce_store<NACC>(acc, partials, G);
   NKA_STAMP0(ctl, 13);
+#undef DEAD_OFF
 }
 
 // Final sums of one PA pass scattered into red[] (layout above).  One wavefront
@@ -540,8 +557,8 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   constexpr int NW = COMPACT ? 1 : MAXK;   // w vectors loaded per tile
   const int G = gridDim.x;
   const int ncomb = ctl.ic[IC_NCOMB];
-  double *wnew = ctl.pc[PC_NEW_W], *vnew = ctl.pc[PC_NEW_V];
-  double *const *cw = ctl.comb_w(), *const *cv = ctl.comb_v();
+  double *wnew = vs.w + ctl.pc[PC_NEW_W], *vnew = vs.w + ctl.pc[PC_NEW_V];
+  const long long *cw = ctl.comb_w(), *cv = ctl.comb_v();
   const double *cc = ctl.comb_c();
   const int base = pass * MAXK;
   // Out-of-place update (kPbNoStoreW / kPbNoStoreF): the caller's buffer f IS w_new and must keep f_in, and f_out goes
@@ -561,8 +578,8 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
   for (int j = 0; j < MAXK; j++) {
     const int k = base + j;
     const bool live = k < ncomb;
-    wk[j] = live ? cw[k] : f;
-    vk[j] = live ? cv[k] : f;
+    wk[j] = live ? vs.w + cw[k] : f;
+    vk[j] = live ? vs.w + cv[k] : f;
     ck[j] = cc[k];
   }
 
@@ -711,8 +728,8 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   const int G = (int)gridDim.x - (has_tail ? 1 : 0);       // tile blocks
   const bool tail_block = has_tail && (int)blockIdx.x == G;
   const int ncomb = ctl.ic[IC_NCOMB];
-  double *wnew = ctl.pc[PC_NEW_W], *vnew = ctl.pc[PC_NEW_V];
-  double *const *cw = ctl.comb_w(), *const *cv = ctl.comb_v();
+  double *wnew = vs.w + ctl.pc[PC_NEW_W], *vnew = vs.w + ctl.pc[PC_NEW_V];
+  const long long *cw = ctl.comb_w(), *cv = ctl.comb_v();
   const double *cc = ctl.comb_c();
   const bool store_w = !(flags & kPbNoStoreW), store_f = !(flags & kPbNoStoreF);     // (uniform: out-of-place update)
   const bool norm0 = ctl.ic[IC_NORMED] != 0;
@@ -721,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 
   double *wk[MAXK], *vk[MAXK];
   double ck[MAXK];
-  double *slw[MAXK], *slv[MAXK];
+  long long slw[MAXK], slv[MAXK];
 #pragma unroll
   for (int j = 0; j < MAXK; j++) {     // all addresses and coefficients in one batch of scalar loads (see k_dots_win)
     if (!COMPACT || j == 0) slw[j] = cw[j];      // (compact storage reads w of the pending pair only)
@@ -731,13 +748,18 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 #pragma unroll
   for (int j = 0; j < MAXK; j++) {
     const bool live = j < ncomb;
-    wk[j] = (live && (!COMPACT || j == 0)) ? slw[COMPACT ? 0 : j] : f;
-    vk[j] = live ? slv[j] : f;
+    wk[j] = (live && (!COMPACT || j == 0)) ? vs.w + slw[COMPACT ? 0 : j] : f;
+    vk[j] = live ? vs.w + slv[j] : f;
   }
   // compact storage reads w only for the pending pair that is normalised now
   const double *w0src = norm0 ? wk[0] : f;
 
   const int lane_off = threadIdx.x * VEC;                  // piece q of a tile starts q*512 elements further
+#if NKA_DEAD_SLOT_TILE0
+#define DEAD_OFF(live, off) ((live) ? (off) : (int64_t)lane_off)      // (dead ring slots: see NKA_DEAD_SLOT_TILE0)
+#else
+#define DEAD_OFF(live, off) (off)
+#endif
   V finv[T], w0v[T], rw[COMPACT ? 1 : W][T], rv[W][T];
   int64_t t = tail_block ? ntile : (int64_t)blockIdx.x;
   if (t < ntile) {
@@ -751,8 +773,8 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     for (int j = 0; j < W; j++)
 #pragma unroll
       for (int q = 0; q < T; q++) {
-        if (!COMPACT) rw[j][q] = ld<VEC>(wk[j] + e + q * (kBlock * VEC));
-        rv[j][q] = ld<VEC>(vk[j] + e + q * (kBlock * VEC));
+        if (!COMPACT) rw[j][q] = ld<VEC>(wk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
+        rv[j][q] = ld<VEC>(vk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
       }
   }
   list_word_publish(ctl, ncomb, flags & kPbNoStoreW);      // (behind the first ring of loads: nothing waits for it)
@@ -795,11 +817,11 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 #pragma unroll
       for (int q = 0; q < T; q++) {
         if (j + W < MAXK) {
-          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W] + e + q * (kBlock * VEC));
-          rv[j % W][q] = ld<VEC>(vk[j + W] + e + q * (kBlock * VEC));
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W] + DEAD_OFF(j + W < ncomb, e) + q * (kBlock * VEC));
+          rv[j % W][q] = ld<VEC>(vk[j + W] + DEAD_OFF(j + W < ncomb, e) + q * (kBlock * VEC));
         } else {
-          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W - MAXK] + en + q * (kBlock * VEC));
-          rv[j % W][q] = ld<VEC>(vk[j + W - MAXK] + en + q * (kBlock * VEC));
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W - MAXK] + DEAD_OFF(j + W - MAXK < ncomb, en) + q * (kBlock * VEC));
+          rv[j % W][q] = ld<VEC>(vk[j + W - MAXK] + DEAD_OFF(j + W - MAXK < ncomb, en) + q * (kBlock * VEC));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -866,6 +888,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
       if (store_f) f[i] = x;
     }
   }
+#undef DEAD_OFF
 }
 
 // ---- scalar kernels: list surgery + Cholesky + substitutions on one wavefront ----
@@ -1033,7 +1056,7 @@ __device__ inline void lst_store(Lst &L, const Ctl &ctl, int in_global = 0) {
     ctl.ic[IC_PLAN_FIRST] = L.first;
     int n = 0;
     int32_t *ps = ctl.plan_slots();
-    double *const *wt = ctl.wtab();
+    const long long *wt = ctl.wtab();
     for (int k = L.pending ? L.next[L.first] : L.first; k != 0; k = L.next[k]) {
       ctl.plan_w()[n] = wt[k];       // the streaming passes get addresses, not slots (Ctl::pc)
       ps[n++] = k;
@@ -1043,13 +1066,13 @@ __device__ inline void lst_store(Lst &L, const Ctl &ctl, int in_global = 0) {
   }
 }
 
-// The slot that receives the new pair gets its buffers here.  An out-of-place update (swap_w / swap_v != nullptr,
+// The slot that receives the new pair gets its buffers here.  An out-of-place update (swap_w / swap_v != kNoBuffer,
 // nka_hip_accel_update_swap) EXCHANGES them: the caller's buffer, which holds f_in, becomes the slot's w -- no copy --
 // and a spare buffer of the library becomes its v; what the slot held before is reported in PC_OLD_W / PC_OLD_V.
-__device__ inline void assign_new_buffers(const Ctl &ctl, int slot, double *swap_w, double *swap_v) {
-  double **wt = ctl.wtab(), **vt = ctl.vtab();
-  if (swap_w) { ctl.pc[PC_OLD_W] = wt[slot]; wt[slot] = swap_w; }      // (other updates leave PC_OLD_* alone: the host
-  if (swap_v) { ctl.pc[PC_OLD_V] = vt[slot]; vt[slot] = swap_v; }      //  may collect them later)
+__device__ inline void assign_new_buffers(const Ctl &ctl, int slot, long long swap_w, long long swap_v) {
+  long long *wt = ctl.wtab(), *vt = ctl.vtab();
+  if (swap_w != kNoBuffer) { ctl.pc[PC_OLD_W] = wt[slot]; wt[slot] = swap_w; }      // (other updates leave PC_OLD_* alone:
+  if (swap_v != kNoBuffer) { ctl.pc[PC_OLD_V] = vt[slot]; vt[slot] = swap_v; }      //  the host may collect them later)
   ctl.pc[PC_NEW_W] = wt[slot];
   ctl.pc[PC_NEW_V] = vt[slot];
 }
@@ -1085,8 +1108,8 @@ __device__ __forceinline__ double solve_nrm(double x, double s, double rs, int m
 // comes behind F08:295-347): 1 = norm, s == 0 -> relax, Gram row, factorisation with drops; 2 = new slot, the
 // substitutions on the right-hand side the host has put into c[] BY SLOT, combine plan, prepend.
 static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global,
-                                                                                       int phase, double *swap_w,
-                                                                                       double *swap_v) {
+                                                                                       int phase, long long swap_w,
+                                                                                       long long swap_v) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lst L;
   lst_load(L, ctl, smem, in_global);
@@ -1186,7 +1209,7 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   b += (size_t)((nl + 1) * (nl + 1) + 3 * nl + (2 + 2 * mvec)) * sizeof(double);
   b += (size_t)(3 * nl + 1) * sizeof(int32_t);                // (+1: keeps the pointer tables behind them 8-byte aligned)
   b = (b + 7) / 8 * 8;
-  b += (size_t)(2 * (nl + 1)) * sizeof(double *);             // slot -> buffer tables (Ctl::wtab / vtab)
+  b += (size_t)(2 * (nl + 1)) * sizeof(long long);            // slot -> buffer tables (Ctl::wtab / vtab)
   return b;
 }
 
@@ -1203,7 +1226,7 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
 // l_p = a_p[i] / L_ii on every lane, then for q = i+1 .. (uniform loop) a_p[q] -= l_p * l_q with
 // l_q = readlane(l, q) -- lanes p <= q update entries nobody reads.
 template <int NLMAX>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, double *swap_w, double *swap_v) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, long long swap_w, long long swap_v) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
@@ -1219,8 +1242,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode,
   double *redL = bb + NL;
   int32_t *ord = reinterpret_cast<int32_t *>(redL + (2 + 2 * M));
   int32_t *psL = ord + 2 * NL;
-  double **wtL = reinterpret_cast<double **>((reinterpret_cast<uintptr_t>(psL + NL + 1) + 7) / 8 * 8);   // [m1 + 1]
-  double **vtL = wtL + (m1 + 1);                                                                          // [m1 + 1]
+  long long *wtL = reinterpret_cast<long long *>((reinterpret_cast<uintptr_t>(psL + NL + 1) + 7) / 8 * 8);   // [m1 + 1]
+  long long *vtL = wtL + (m1 + 1);                                                                            // [m1 + 1]
   NKA_STAMP(ctl, 0);
   // ---- one global round trip: EVERY load is issued before the first is waited for (written as plain
   //      loops the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eleven serial
@@ -1233,7 +1256,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode,
     static_assert(kSolveWaveMax + 1 <= kSolveThreads, "lists: one load a lane");
     const double *gh = ctl.h(), *gred = ctl.red();
     double hreg[kHB], rreg[2], creg = 0.0;
-    double *wtreg = nullptr, *vtreg = nullptr;
+    long long wtreg = 0, vtreg = 0;
     int32_t nreg = 0, preg = 0, psreg = 0;
 #pragma unroll
     for (int k = 0; k < kHB; k++) hreg[k] = (lane + kSolveThreads * k < nh) ? gh[lane + kSolveThreads * k] : 0.0;
@@ -1402,15 +1425,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode,
   L.free_ = L.next[slot];
   // buffers of the new pair (every lane computes the same values; lane 0 writes them): an out-of-place update exchanges
   // them (assign_new_buffers).  The new slot is never one of the entries combined below (it comes off the free list).
-  double *const new_w = swap_w ? swap_w : wtL[slot], *const new_v = swap_v ? swap_v : vtL[slot];
+  const long long new_w = swap_w != kNoBuffer ? swap_w : wtL[slot], new_v = swap_v != kNoBuffer ? swap_v : vtL[slot];
   if (lane == 0) {
-    if (swap_w) ctl.pc[PC_OLD_W] = wtL[slot];  // (other updates leave PC_OLD_* alone: the host may collect them later)
-    if (swap_v) ctl.pc[PC_OLD_V] = vtL[slot];
+    if (swap_w != kNoBuffer) ctl.pc[PC_OLD_W] = wtL[slot];  // (other updates leave PC_OLD_* alone: the host may collect them later)
+    if (swap_v != kNoBuffer) ctl.pc[PC_OLD_V] = vtL[slot];
     ctl.pc[PC_NEW_W] = new_w;
     ctl.pc[PC_NEW_V] = new_v;
     ctl.pc[PC_FIRST_W] = new_w;                // the new pair is the pending pair of the next update
-    if (swap_w) ctl.wtab()[slot] = swap_w;
-    if (swap_v) ctl.vtab()[slot] = swap_v;
+    if (swap_w != kNoBuffer) ctl.wtab()[slot] = swap_w;
+    if (swap_v != kNoBuffer) ctl.vtab()[slot] = swap_v;
   }
   if (forward_done) {
     // back-substitution F08:382-392 in position space: the factor lies in A, its
@@ -1436,7 +1459,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode,
       ctl.comb_slots()[r] = myord;
       ctl.comb_c()[r] = yr;
       ctl.plan_slots()[r] = myord;             // the next update's older entries: this list, in order
-      double *const wb = wtL[myord];
+      const long long wb = wtL[myord];
       ctl.comb_w()[r] = wb;                    // ... and their addresses for the streaming passes (Ctl::pc)
       ctl.comb_v()[r] = vtL[myord];
       ctl.plan_w()[r] = wb;

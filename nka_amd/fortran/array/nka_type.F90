@@ -73,6 +73,8 @@ module nka_type
     procedure :: vec_tol
     procedure :: accel_update
     procedure :: accel_update_dev
+    procedure :: accel_update_swap
+    procedure :: list_bound
     procedure :: relax
     procedure :: restart
     procedure :: defined
@@ -223,6 +225,24 @@ contains
     type(c_ptr), intent(in) :: f_dev
     call nka_hip_check(nka_hip_accel_update(this%handle, f_dev), 'nka%accel_update_dev')
   end subroutine
+
+  !! Out-of-place form of accel_update_dev (nka_hip_accel_update_swap, include/nka_hip.h): F_IO enters with the
+  !! device buffer that holds f -- the accelerator KEEPS it (it becomes the storage of w of the new pair) -- and
+  !! returns with a free buffer for the caller's next input; F_ACC is the accelerated f, to be read only, valid
+  !! until the next update.  Two of the five store streams of the combine pass less; same bits.
+  subroutine accel_update_swap(this, f_io, f_acc)
+    class(nka), intent(inout) :: this
+    type(c_ptr), intent(inout) :: f_io
+    type(c_ptr), intent(out) :: f_acc
+    call nka_hip_check(nka_hip_accel_update_swap(this%handle, f_io, f_acc), 'nka%accel_update_swap')
+  end subroutine accel_update_swap
+
+  !! Upper bound on the list length (pending pair included) as the host knows it without synchronising: its own
+  !! count tightened by the device's list word (nka_hip_list_bound).
+  integer function list_bound(this)
+    class(nka), intent(in) :: this
+    list_bound = nka_hip_list_bound(this%handle)
+  end function list_bound
 
   subroutine restart(this)                                    ! F08:422-436
     class(nka), intent(inout) :: this

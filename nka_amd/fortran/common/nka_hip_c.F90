@@ -34,6 +34,16 @@ module nka_hip_c
       import :: c_int, c_ptr
       type(c_ptr), value :: handle, f_dev
     end function
+    integer(c_int) function nka_hip_accel_update_swap(handle, f_io, f_acc) bind(C)   ! out of place: include/nka_hip.h
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      type(c_ptr), intent(inout) :: f_io      ! in: the caller's buffer with f (kept by the library); out: a free buffer
+      type(c_ptr), intent(out) :: f_acc       ! the accelerated f, to be read only, valid until the next update
+    end function
+    integer(c_int) function nka_hip_list_bound(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
     integer(c_int) function nka_hip_accel_update_host(handle, f_host) bind(C)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: handle
