@@ -316,8 +316,9 @@ def sharded_worker(args):
         seed += 1
         if rank == 0 and (seed - args.first_seed) % 20 == 0:
             print(f"{seed - args.first_seed} seeds, {time.time() - t0:.0f} s", flush=True)
-    kmax = max([r.get("k_needed", 0.0) for r in P.WORST.values()] + [0.0])
-    out.write(f"# rank {rank}: seeds {args.first_seed}..{seed - 1} ok; largest K needed {kmax:.2f} of {P.K_SPREAD}\n")
+    rmax = max([r.get("truth_ratio", 0.0) for r in P.WORST.values()] + [0.0])
+    out.write(f"# rank {rank}: seeds {args.first_seed}..{seed - 1} ok; truth rule: largest share of the allowance used {rmax:.2f}; "
+              f"sequences beyond it (below the hard stop): {len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}\n")
     out.close()
     if rank == 0:
         print(f"# seeds {args.first_seed}..{seed - 1} ok on {dist.get_world_size()} ranks; largest K needed (rank 0) {kmax:.2f}")
