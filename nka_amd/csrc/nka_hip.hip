@@ -847,7 +847,9 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int nl = a->mvec + 1;
-#define ROWS(NL) hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v)
+    const long long id_stride = a->swapped ? 0 : (long long)a->vs.stride, id_vbase = buffer_offset(a, a->vs.v);
+#define ROWS(NL) \
+  hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v, id_stride, id_vbase)
     if (nl <= 6) ROWS(6);
     else if (nl <= 11) ROWS(11);
     else if (nl <= 21) ROWS(21);

@@ -1226,7 +1226,8 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
 // l_p = a_p[i] / L_ii on every lane, then for q = i+1 .. (uniform loop) a_p[q] -= l_p * l_q with
 // l_q = readlane(l, q) -- lanes p <= q update entries nobody reads.
 template <int NLMAX>
-__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, long long swap_w, long long swap_v) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, long long swap_w, long long swap_v,
+                                                              long long id_stride, long long id_vbase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
@@ -1266,8 +1267,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode,
       creg = ctl.c()[lane];
       nreg = ctl.next()[lane];
       preg = ctl.prev()[lane];
-      wtreg = ctl.wtab()[lane];
-      vtreg = ctl.vtab()[lane];
+      // id_stride != 0: the slot -> buffer tables are still the ones of creation (no out-of-place update yet): slot k at
+      // (k-1)*stride of the two slot-major allocations -- computed, not loaded (two more cache lines in the entry round
+      // trip cost the one-wavefront step ~1 us at small n)
+      if (id_stride != 0) {
+        wtreg = (long long)(lane - 1) * id_stride;
+        vtreg = id_vbase + (long long)(lane - 1) * id_stride;
+      } else {
+        wtreg = ctl.wtab()[lane];
+        vtreg = ctl.vtab()[lane];
+      }
     }
     if (lane < M) psreg = ctl.plan_slots()[lane];        // (bounded by mvec, not by the count still on its way)
 #pragma unroll
