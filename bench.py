@@ -50,6 +50,11 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  stored vectors per pair).  Both are checked against the compiled
                  src-F08 reference in tests/ (decisions exact, values within the stated
                  tolerance).
+  with_drops (N = 1, headline run only): the same accelerator shape with a SHRUNK subspace -- every input in a 12-dimensional
+                 span, a dependence drop and a device synchronisation per update (--workload drops): updates/s, launch
+                 widths, physical roofline at the actual list length with PMC traffic.
+  out_of_place_entry (N = 1, headline run only): the headline workload through the opt-in nka_hip_accel_update_swap
+                 (two store streams less in PB; bit-identical results).
   config2_n1e7_m10 (N = 1, headline run only): BASELINE configs[1] (n = 1e7, m = 10) measured in the same
                  run on the first 1e7 elements of the resident inputs (updates/s, whole-update fraction).
   config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
@@ -242,13 +247,14 @@ FLAVOR_TEXT = {"c": "src-C rounding f += c*(v-w), compact storage (v slot keeps 
                "f08vec": "src-F08-vector rounding ((-c)*w + c*v) + f, normalise by reciprocal"}
 
 
-def words_moved(flavor: str, L: int, k: int):
+def words_moved(flavor: str, L: int, k: int, out_of_place: bool = False):
     """8-byte words per element each launch of the two-pass schedule really moves
     (confirmed by the PMC passes under profiles/): PA reads w1, f and the L stored
     w; PB reads f and the k pairs (one vector per pair with compact storage, the
-    pending pair always as two) and writes w1', v1', w_new, v_new, f."""
+    pending pair always as two) and writes w1', v1', w_new, v_new, f -- out of place
+    (nka_hip_accel_update_swap) w1', v1', v_new only."""
     pb_reads = (2 + k) if flavor == "c" else (1 + 2 * k)
-    return {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + 5}
+    return {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + (3 if out_of_place else 5)}
 
 
 def pmc_traffic(flavor: str, n_local: int, m: int):
@@ -313,7 +319,8 @@ def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170, extra_ar
         return None
 
 
-def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None, L=None, k=None):
+def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None, L=None, k=None,
+                   out_of_place=False):
     """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
     PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
     PMC counters) / mean launch duration (HIP events on the kernel stream during
@@ -325,13 +332,13 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
     useful work, not a bandwidth (it may exceed the peak and is never `frac`)."""
     L = m if L is None else L          # stored vectors PA reads / pairs PB combines: mvec with the subspace full,
     k = m if k is None else k          # fewer after dependence drops (--workload drops)
-    words = words_moved(flavor, L, k)
+    words = words_moved(flavor, L, k, out_of_place)
     ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}
     if pm_live:
         pm, pm_src = pm_live, ("same run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child process of "
                                "this script after the timed region; FETCH_SIZE x 2 on gfx950")
     else:
-        pm, pm_src = pmc_traffic(flavor, n_local, m) if (L, k) == (m, m) else (None, None)
+        pm, pm_src = pmc_traffic(flavor, n_local, m) if (L, k) == (m, m) and not out_of_place else (None, None)
     pmk = {"PA_k_dots": "k_dots", "PB_k_combine": "k_combine"}
     kernels = {}
     for name, w in words.items():
@@ -626,7 +633,7 @@ def main(argv=None):
 
     ev_stride = 1 if n_local >= 50_000_000 else 4
 
-    def measure(acc, workload="full"):
+    def measure(acc, workload="full", out_of_place=False):
         """W_all untimed calls (priming + warm-up), then EXACTLY K timed updates
         bracketed by barrier + synchronize; returns wall time (max over ranks),
         mean per-phase device times (HIP events on the kernel stream), num_vec.
@@ -634,12 +641,15 @@ def main(argv=None):
         synchronisation per update, inside the timed region, where a solver reads its
         residual norm -- that is what lets the host see the list word (nka_hip_list_bound)."""
         sync_each = workload == "drops"
+        # out of place (nka_hip_accel_update_swap): every input row is HANDED to the accelerator (it becomes w of the new
+        # pair) and never written again -- W_all + K distinct rows; the buffers it returns are not needed here
+        update = (lambda row: acc.accel_update_swap(row, views=False)) if out_of_place else acc.accel_update
         for t in range(min(P, W_all + K)):     # inputs (re)generated outside the timed region
             fill(t, t, workload)
         for t in range(W_all):
             if t >= P:
                 fill(t % P, t, workload)
-            acc.accel_update(pool[t % P])
+            update(pool[t % P])
             if sync_each:
                 torch.cuda.synchronize(dev)
         sync_all()
@@ -655,7 +665,7 @@ def main(argv=None):
             t = W_all + s
             if t >= P:
                 fill(t % P, t, workload)       # only when HBM cannot hold W+K inputs (reported below)
-            acc.accel_update(pool[t % P])
+            update(pool[t % P])
             if sync_each:
                 torch.cuda.synchronize(dev)
         sync_all()
@@ -761,6 +771,23 @@ def main(argv=None):
             a3.delete()
             basis_box[0] = None
 
+    def out_of_place_extra():
+        """The opt-in out-of-place entry on the headline workload: same inputs, same protocol, nka_hip_accel_update_swap in
+        place of nka_hip_accel_update (bit-identical results: tests/test_hip_round4.py).  PB stores w1', v1', v_new only."""
+        if refill_in_timed_region:
+            return {"value": None, "error": "needs W + K distinct resident input rows"}
+        a4 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor])
+        try:
+            e4, mean4, nv4, nv4_end, _, stats4 = measure(a4, "full", out_of_place=True)
+            fl4 = FLAVOR_NAMES[a4.flavor()]
+            return {"entry": "nka_hip_accel_update_swap (include/nka_hip.h): the caller's buffer becomes w_new, f_out is stored "
+                             "once (as v_new) and lent to the caller",
+                    "flavor": FLAVOR_TEXT[fl4], "value": K / e4, "unit": "updates/s", "ms_per_step": 1e3 * e4 / K,
+                    "steady_state": bool(nv4 == m and nv4_end == m),
+                    "roofline": roofline_block(fl4, n_local, m, mean4, None, stats4, None, out_of_place=True)}
+        finally:
+            a4.delete()                 # (before the input rows it holds are released)
+
     drops = None
     headline = world == 1 and (n_global, m) == (10**8, 20) and args.workload == "full" and not args.no_cpu_baseline
     if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
@@ -768,6 +795,12 @@ def main(argv=None):
             drops = with_drops_extra()
         except Exception as exc:           # an extra, never the measured path
             drops = {"value": None, "error": repr(exc)}
+    oop = None
+    if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+        try:
+            oop = out_of_place_extra()
+        except Exception as exc:           # an extra, never the measured path
+            oop = {"value": None, "error": repr(exc)}
 
     # Secondary figure in the same run: the src-F08 rounding (two stored vectors
     # per pair, bit-faithful to F08:397), same workload, same protocol.
@@ -825,6 +858,8 @@ def main(argv=None):
             out["also_f08_rounding"] = also
         if drops is not None:
             out["with_drops"] = drops
+        if oop is not None:
+            out["out_of_place_entry"] = oop
         if headline:
             try:
                 c2 = config2_line()

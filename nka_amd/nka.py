@@ -247,11 +247,13 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_accel_update(h, C.c_void_p(f.data_ptr())), "accel_update", self._L)
         return f
 
-    def accel_update_swap(self, f):
+    def accel_update_swap(self, f, views: bool = True):
         """Out-of-place update (nka_hip_accel_update_swap): `f`, a float64 CUDA tensor holding the correction, is HANDED
         to the accelerator -- it becomes the storage of the new pair's w, so it is kept alive here and must not be
         written again.  Returns (buf, acc): `buf`, a tensor view of a free library buffer for the caller's next input;
-        `acc`, a view of the accelerated correction, to be read only, valid until the next call on this object."""
+        `acc`, a view of the accelerated correction, to be read only, valid until the next call on this object.
+        views=False returns the two raw device addresses instead (wrapping a pointer in a tensor costs ~0.4 ms the
+        first time it is seen)."""
         import torch
         h = self._handle()
         if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float64 and f.is_contiguous()
@@ -268,6 +270,8 @@ class nka:  # noqa: N801  (the reference's type name)
         if not any(t.data_ptr() == f.data_ptr() for t in self._swap_keep):
             self._swap_keep.append(f)                   # the library keeps using this memory
             self.__dict__.setdefault("_views", {}).setdefault(f.data_ptr(), f)
+        if not views:
+            return int(io.value), int(acc.value)
         return self._view(io.value), self._view(acc.value)
 
     def _view(self, ptr):
