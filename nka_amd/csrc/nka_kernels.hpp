@@ -731,7 +731,9 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   double *wnew = vs.w + ctl.pc[PC_NEW_W], *vnew = vs.w + ctl.pc[PC_NEW_V];
   const long long *cw = ctl.comb_w(), *cv = ctl.comb_v();
   const double *cc = ctl.comb_c();
-  const bool store_w = !(flags & kPbNoStoreW), store_f = !(flags & kPbNoStoreF);     // (uniform: out-of-place update)
+  // (uniform: out-of-place update.  The two scalar branches around the stores cost the in-place path nothing measurable:
+  //  interleaved A/B against a build with unconditional stores, profiles/r04/ab_pb_flags.txt)
+  const bool store_w = !(flags & kPbNoStoreW), store_f = !(flags & kPbNoStoreF);
   const bool norm0 = ctl.ic[IC_NORMED] != 0;
   const double s = ctl.dc[DC_S];
   const double rs = 1.0 / s;
