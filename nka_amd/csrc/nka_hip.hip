@@ -201,6 +201,7 @@ struct nka_hip_state {
   double *spare_w = nullptr, *spare_v = nullptr;   // free buffers the host knows of (given away by the next swap update)
   bool swap_pending = false;  // the buffers the last swap update displaced have not been collected yet (record word 3)
   int64_t swap_seq = 0;       // number of that update
+  const double *last_acc = nullptr;   // the accelerated f lent by the last out-of-place update (read only for the caller)
   std::vector<void *> extra_allocs;   // the two spare buffers allocated at the first swap update (freed at destroy)
   // launch geometry
   int num_cu = 256;
@@ -1208,6 +1209,9 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
   if (int rc = collect_spares(a)) return rc;
   double *const in = *f_io, *const give_w = a->spare_w, *const vnew = a->spare_v;
   if (in == give_w || in == vnew) return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the library's own spare");
+  if (in == a->last_acc)
+    return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the accelerated f lent by the previous update (read only: it "
+                                "is the stored v of the pending pair)");
   if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;   // (a failed update is not done: the spares stay)
   a->swapped = true;
   a->swap_pending = true;
@@ -1215,6 +1219,7 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
   a->spare_w = a->spare_v = nullptr;
   *f_io = give_w;
   *f_acc = vnew;
+  a->last_acc = vnew;
   return 0;
 }
 

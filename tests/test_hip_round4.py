@@ -278,3 +278,6 @@ def test_out_of_place_update_argument_checks(torch_cuda):
     assert torch.equal(acc, torch.ones_like(acc))         # the first update returns its input
     buf2, acc2 = a.accel_update_swap(buf)                 # the lent buffer comes back as the next input: the normal protocol
     assert buf2.data_ptr() not in (buf.data_ptr(), acc2.data_ptr()) and a.num_vec() == 1
+    with pytest.raises(nka_amd.NKAError, match="read only"):
+        a.accel_update_swap(acc2)                         # the accelerated f is the stored v of the pending pair: not an input
+    assert a.num_vec() == 1 and a.defined()
