@@ -159,6 +159,20 @@ def test_fortran_array_bench_runs(fortran_build):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,m,flavor", [(100003, 6, 2), (4097, 3, 0), (250000, 20, 1)])
+def test_out_of_place_update_and_list_bound_through_the_fortran_front_end(fortran_build, n, m, flavor):
+    """call accel%accel_update_swap(f_io, f_acc) and accel%list_bound() of the drop-in module nka_type (round 4): against
+    accel_update_dev on the same inputs bit for bit, dependence drops and a repeated input included; with a
+    synchronisation per call the host's bound equals the true list length (nka_amd/fortran/array/nka_swap_driver.F90)."""
+    p = subprocess.run([os.path.join(fortran_build, "nka_swap_driver"), str(n), str(m), str(m + 16), str(flavor)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "OK calls=" in p.stdout
+    below = int(p.stdout.split("calls_with_a_bound_below_the_plain_count=")[1].split()[0])
+    assert below >= 3, p.stdout            # the dependence drops were seen by the host
+
+
+@pytest.mark.gpu
 def test_abstract_vector_bench_mode_runs(fortran_build):
     p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "bench", "4", "100000", "5", "5"],
                        capture_output=True, text=True, timeout=300)
