@@ -151,7 +151,7 @@ def lib_path() -> str:
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j4"]
+    args = ["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j6"]
     if force:
         subprocess.run(args + ["clean"], check=True)
     subprocess.run(args, check=True)
