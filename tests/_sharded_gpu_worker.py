@@ -66,8 +66,14 @@ def main():
             full.accel_update(f_full)
             spread.update(x)
             ft = torch.from_numpy(x[lo:hi].copy()).cuda()
-            acc.accel_update(ft)
-            out = ft.cpu().numpy()
+            if flavor == nka_amd.FLAVOR_C and t % 2 == 1:
+                # every other update of the second pass OUT OF PLACE (nka_hip_accel_update_swap): the same collective in
+                # between, the same bits out, on every rank (an empty slice hands over an empty buffer)
+                _, acc_f = acc.accel_update_swap(ft)
+                out = acc_f.cpu().numpy()
+            else:
+                acc.accel_update(ft)
+                out = ft.cpu().numpy()
             assert acc.num_vec() == full.num_vec(), (rank, flavor, t)
             st = acc.state()
             assert st.list_order() == full.state().list_order(), (rank, flavor, t)
