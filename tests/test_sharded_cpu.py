@@ -92,3 +92,16 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(nka_amd.NKAError):
         nka_amd.nka().init(10, 3)
+
+
+def test_public_headers_compile_as_c_and_cxx(tmp_path):
+    """include/*.h are the boundary a C (or Fortran-through-C) caller builds against: each must compile on its own as
+    C99 and as C++17 (plain pointers and sizes, no HIP or torch types)."""
+    inc = os.path.join(ROOT, "include")
+    for hdr in sorted(f for f in os.listdir(inc) if f.endswith(".h")):
+        for lang, comp, std in (("c", "gcc", "-std=c99"), ("c++", "g++", "-std=c++17")):
+            src = tmp_path / f"use_{hdr.replace('.', '_')}.{'c' if lang == 'c' else 'cpp'}"
+            src.write_text(f'#include "{hdr}"\nint main(void) {{ return 0; }}\n')
+            p = subprocess.run([comp, std, "-Wall", "-Werror", "-Wno-unused-function", "-fsyntax-only", f"-I{inc}", str(src)],
+                               capture_output=True, text=True)
+            assert p.returncode == 0, (hdr, lang, p.stderr[-2000:])
