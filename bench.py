@@ -28,10 +28,15 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  `whole_update` = PA + scalar step + PB the same way; `kernels`
                  per launch.  The
                  contract's B_alg = 8n(11+L+2k) (a three-pass
-                 schedule that moves more bytes than this one) appears only as
-                 `contract_bytes_ratio` / `contract_GBps`, never as a fraction.
+                 schedule that moves more bytes than this one) appears as
+                 `contract_bytes_ratio`; a B_alg-based rate (`contract_GBps`,
+                 `contract_frac_of_peak`) only where B_alg bounds the traffic from below:
+                 under also_f08_rounding, never for the compact flavour.
   cpu_baseline : the compiled reference (oracle/_ref, kind "reference") or the
-                 oracle port timed on this box's host on a bounded sample.
+                 oracle port, serial (1 core), timed on this box's host in this run: at the
+                 benchmark's own n when the host has the memory for it (22 fill calls + 3
+                 timed updates at n = 1e8, m = 20: ~60 s of CPU work), else at n = 2e7 with
+                 the reason in `sample`.
                  `traffic`: HBM bytes of that launch by the PMC counters, measured IN THIS RUN
                  (two rocprofv3 passes, FETCH_SIZE and WRITE_SIZE, over a short child process of
                  this script after the timed region; `traffic_source` says so, or names the
