@@ -1,3 +1,4 @@
+# (libnka_hip_dead0.so = the library built with -DNKA_DEAD_SLOT_TILE0=0; libnka_hip_stamps.so = make -C nka_amd/csrc stamps)
 # round-4 evidence, part A (run through gpurun): tests of the round, dead ring slots A/B, phase stamps incl. PB and the kernel boundaries
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_hip_round4.py tests/test_hip_round2.py -x -q --tb=short > gpurun_out/pytest_r4.log 2>&1 || { tail -40 gpurun_out/pytest_r4.log; exit 1; }

@@ -1,3 +1,4 @@
+# round-4: tests of the list word + its in-process A/B (profiles/r04/ab_list_word.txt); needs libnka_hip_diag.so (built by build())
 set -e
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_hip_round4.py -x -q --tb=short > gpurun_out/pytest_r4.log 2>&1 || { tail -40 gpurun_out/pytest_r4.log; exit 1; }

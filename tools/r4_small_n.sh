@@ -1,3 +1,4 @@
+# round-4: scalar-step phases (stamps build) and the small-n sweep after the address block went in
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_hip_round4.py tests/test_hip_parity.py -x -q --tb=short > gpurun_out/pytest_r4.log 2>&1 || { tail -30 gpurun_out/pytest_r4.log; exit 1; }
 tail -2 gpurun_out/pytest_r4.log

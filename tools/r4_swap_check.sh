@@ -1,3 +1,4 @@
+# round-4: tests of the out-of-place entry + tools/ab_swap.py (profiles/r04/ab_swap_entry.txt)
 set -e
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_hip_round4.py -x -q --tb=short > gpurun_out/pytest_r4.log 2>&1 || { tail -40 gpurun_out/pytest_r4.log; exit 1; }
