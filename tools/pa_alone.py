@@ -24,4 +24,4 @@ for v in [int(x) for x in (sys.argv[2:] or ["0", "201", "202"])]:
     ms = C.c_float()
     for _ in range(2):
         assert L.nka_hip_debug_time_pa(acc._handle(), C.c_void_p(f.data_ptr()), 10, C.byref(ms)) == 0
-    print(f"pa_pipe={v:4d}: PA alone {ms.value:.3f} ms = {8e-9 * n * 22 / ms.value:.0f} GB/s", flush=True)
+    print(f"pa_pipe={v:4d}: PA alone {ms.value:.3f} ms = {8e-6 * n * 22 / ms.value:.0f} GB/s", flush=True)
