@@ -470,7 +470,8 @@ def run_rank_group(nproc, script, script_args, timeout_s, env=None):
             p.wait()
             rc = 124
     finally:
-        kill_group(signal.SIGKILL)            # nothing of the group outlives the attempt (no-op when it has exited)
+        if timed_out or p.poll() is None:     # (never after a normal exit: the group id of a reaped child is not ours any more)
+            kill_group(signal.SIGKILL)        # nothing of a group that was given up on outlives the attempt
         for sg, h in old.items():
             signal.signal(sg, h)
     for t in th:
