@@ -827,7 +827,10 @@ int nka_hip_relax(nka_hip_t a) {
   if (a->pending) {
     a->pending = false;
     a->list_ub = std::max(a->list_ub - 1, 0);
-    a->relaxed_after.push_back(a->seq);
+    if (!a->word_off && a->list_word) a->relaxed_after.push_back(a->seq);   // (only the list word's arithmetic reads these)
+    if (a->relaxed_after.size() > 4096) a->relaxed_after.erase(a->relaxed_after.begin(), a->relaxed_after.begin() + 2048);
+    // (a caller that relaxes thousands of times without ever letting a word through: dropping old entries can only
+    //  LOOSEN the bound, list_bound_now subtracts one per entry)
   }
   return 0;
 }
