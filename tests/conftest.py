@@ -16,8 +16,9 @@ def pytest_sessionstart(session):
     """The built libraries are git-ignored; a fresh checkout builds them once
     (hipcc cross-compiles gfx950 without a GPU; ~15 s)."""
     import nka_amd
-    if not os.path.exists(nka_amd.lib_path()):
-        nka_amd.build()
+    from nka_amd import _lib
+    if not os.path.exists(nka_amd.lib_path()) or not os.path.exists(_lib.diag_lib_path()):
+        nka_amd.build()          # (libnka_hip.so AND libnka_hip_diag.so: the variant tests load the diagnostic build)
 
 
 @pytest.fixture(autouse=True)
