@@ -70,7 +70,7 @@ def test_scenarios_decisions_exact_values_within_tolerance(torch_cuda, oracle, n
     # COMPILED reference's own outputs (held by the fixture) have from it
     exact, err_ref = P.fixture_truth(g, oracle)
     for u in range(len(outs)):
-        truth = (S.rel_err(outs[u], exact[u], inputs[u]), err_ref[u], n)
+        truth = (S.rel_err(outs[u], exact[u], inputs[u]), err_ref[u], n, m)
         P.check(S.rel_err(outs[u], g[key][u], inputs[u]), states[u], f"scenario {name} flavor {flavor} vs own reference",
                 where=u, spread=spreads[u], truth=truth)
         # every flavour -- the front ends' default C/compact one included -- against the

@@ -137,7 +137,7 @@ def survey(nseeds, O, out):
              f"{'seed':>5s} {'n':>6s} {'m':>3s} {'max err_dev':>12s} {'max err_ref':>12s} {'allowance used':>14s}"]
     used = []
     for seed, n, m, ed, er in rows:
-        r = ed / max(P.truth_factor(n) * er, 1e-300) if ed > 1e-12 else 0.0
+        r = ed / max(P.truth_factor(n, m) * er, 1e-300) if ed > 1e-12 else 0.0
         used.append((r, n))
         lines.append(f"{seed:5d} {n:6d} {m:3d} {ed:12.3e} {er:12.3e} {r:14.2f}")
     rs = sorted(r for r, _ in used)
