@@ -639,6 +639,7 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     std::vector<long long> pc((size_t)a->ctl.pc_count(), 0);
     Ctl h = a->ctl;
     h.pc = pc.data();
+    pc[PC_OLD_W] = pc[PC_OLD_V] = kNoBuffer;      // (offset 0 is a real buffer: slot 1 of w)
     for (int k = 1; k <= mvec + 1; k++) {
       h.wtab()[k] = buffer_offset(a, a->vs.w + (size_t)(k - 1) * a->vs.stride);
       h.vtab()[k] = buffer_offset(a, a->vs.v + (size_t)(k - 1) * a->vs.stride);
@@ -1167,19 +1168,20 @@ static int collect_spares(nka_hip_t a) {
              (int64_t)__atomic_load_n(a->list_word + 3, __ATOMIC_ACQUIRE) == a->swap_seq;
     };
     if (!fresh()) HIP_TRY(hipStreamSynchronize(a->stream));
-    double *ow = nullptr, *ov = nullptr;
+    long long ow = kNoBuffer, ov = kNoBuffer;
     if (fresh()) {
-      ow = buffer_at(a, (long long)a->list_word[1]);
-      ov = buffer_at(a, (long long)a->list_word[2]);
+      ow = (long long)a->list_word[1];
+      ov = (long long)a->list_word[2];
     } else {                                   // no record (the word is switched off): read the address block itself
       long long hdr[PC_HEADER] = {};
       HIP_TRY(hipMemcpy(hdr, a->ctl.pc, sizeof hdr, hipMemcpyDeviceToHost));
-      ow = buffer_at(a, hdr[PC_OLD_W]);
-      ov = buffer_at(a, hdr[PC_OLD_V]);
+      ow = hdr[PC_OLD_W];
+      ov = hdr[PC_OLD_V];
     }
-    if (!ow || !ov) return fail(NKA_HIP_ESTATE, "accel_update_swap: the displaced buffers of the previous update are missing");
-    a->spare_w = ow;
-    a->spare_v = ov;
+    if (ow == kNoBuffer || ov == kNoBuffer)
+      return fail(NKA_HIP_ESTATE, "accel_update_swap: the displaced buffers of the previous update are missing");
+    a->spare_w = buffer_at(a, ow);
+    a->spare_v = buffer_at(a, ov);
     a->swap_pending = false;
   }
   if (!a->spare_w || !a->spare_v) {            // first out-of-place update of this handle: two more buffers
