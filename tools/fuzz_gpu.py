@@ -68,6 +68,10 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
             return _pairwise_dot(x, y)
         acc.set_host_dot(dp_a)
         ora.set_dot_prod(dp_o)
+    # every other seed mixes OUT-OF-PLACE updates in (nka_hip_accel_update_swap: the input buffer is handed over, the
+    # result comes back as a view) -- drawn from a generator of its own, so that a seed names the same call sequence as before
+    rng_swap = np.random.default_rng(777_000 + seed)
+    swap_share = 0.0 if (hostdot or seed % 2 == 0) else float(rng_swap.choice([0.3, 0.7, 1.0]))
     for step, op in enumerate(array_ops(rng, n, steps)):
         if op[0] == "update":
             x = op[1]
@@ -76,7 +80,12 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
             if not hostdot:
                 spread.update(x)
             ft = torch.from_numpy(x.copy()).cuda()
-            acc.accel_update(ft)
+            if swap_share > 0.0 and rng_swap.random() < swap_share:
+                _, ft = acc.accel_update_swap(ft)
+                if rng_swap.random() < 0.5:
+                    torch.cuda.synchronize()           # (sometimes the record of the displaced buffers is fresh, sometimes not)
+            else:
+                acc.accel_update(ft)
             if hostdot:
                 assert np.array_equal(ft.cpu().numpy(), f), (key, step, float(np.abs(ft.cpu().numpy() - f).max()))
                 assert calls[0] == calls[1], (key, step, calls)
@@ -253,7 +262,10 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
             ora.accel_update(f)
             spread.update(x)
             ft = torch.from_numpy(x[lo:hi].copy()).cuda()
-            acc.accel_update(ft)
+            if seed % 2 == 1 and step % 3 != 0:       # odd seeds: two of three updates out of place, on every rank alike
+                _, ft = acc.accel_update_swap(ft)
+            else:
+                acc.accel_update(ft)
             out = ft.cpu().numpy()
             nx = np.linalg.norm(x)
             if nx > 0:
