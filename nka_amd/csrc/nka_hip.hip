@@ -1213,8 +1213,8 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
     return fail(NKA_HIP_ESTATE, "accel_update_swap: cannot be captured into a graph (the host chooses buffers per call)");
   if (int rc = collect_spares(a)) return rc;
   double *const in = *f_io, *const give_w = a->spare_w, *const vnew = a->spare_v;
-  if (in == give_w || in == vnew) return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the library's own spare");
-  if (in == a->last_acc)
+  if (in && (in == give_w || in == vnew)) return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the library's own spare");
+  if (in && in == a->last_acc)          // (an empty slice, vlen 0, hands over a null buffer every time)
     return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the accelerated f lent by the previous update (read only: it "
                                 "is the stored v of the pending pair)");
   if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;   // (a failed update is not done: the spares stay)
