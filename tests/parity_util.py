@@ -159,7 +159,10 @@ def truth_factor(n, mvec=None):
     The device's advantage over the reference is its blocked, fused summation -- error ~ eps log n against the
     reference's sequential ~ eps sqrt(n) -- and it grows with n: over the 7 400 soak sequences of round 4
     (profiles/r04/fuzz_soak.txt) the ratio err_dev / err_ref has median 0.05 for n > 2048, 0.14 for 513..2048, 0.28 for
-    129..512, 0.58 for n <= 16, and it NEVER exceeds 2 beyond one tile (0 of 4 145 sequences; largest 1.64).  Within one tile
+    129..512, 0.58 for n <= 16, and of the 4 142 sequences beyond one tile that ran to their end none exceeds 2 (largest
+    1.64).  (One further sequence beyond one tile did not run to its end: sharded soak seed 3319, n = 1660, stopped at its
+    8th operation by the per-call stop with err_dev 1.1e-12 -- a tenth above the base -- against err_ref 5.5e-14 so far.  The
+    thresholds were NOT moved for it; profiles/r04/sharded_seed_3319_replay.txt shows what it is.)  Within one tile
     a sum is exact to a few units in the last place in any order: device and reference are then two equally good draws of
     the same rounding-error distribution (switching on FMA alone, or the blocked order alone, in the reference's own
     arithmetic moves its error by factors between 0.3 and 3.6 there: profiles/r04/error_attribution.txt), and the ratio of
@@ -189,8 +192,15 @@ def tolerance(state, base=1e-12, spread=None, truth=None):
     return base / (piv * piv), piv, "conditioning (no spread supplied)"
 
 
-def check(err, state, key, base=1e-12, where=None, spread=None, truth=None):
+STOPS = []      # (key, where, err_dev, tol) of per-call stops tripped under check(stop=False): the soak tool's record
+
+
+def check(err, state, key, base=1e-12, where=None, spread=None, truth=None, stop=True):
     """Record `err` = ||f_device - f_reference|| / ||f_in|| under `key` and assert the rule above.
+    stop=False (the soak tool only; every test asserts): a tripped per-call stop is RECORDED (STOPS, rec["stops"]) and the
+    sequence goes on, so that it is still judged by THE rule at its end -- the per-call stop measures against the reference's
+    distance SO FAR, and where the errors of both grow 25-fold per update (sharded soak seed 3583: 6e-14, 1.5e-12, 3.9e-11 on
+    three successive updates of the reference) being one update ahead trips it.
     truth = (err_dev, err_ref) against the extended-precision trajectory (Spread.truth / fixture_truth): THE rule,
     err_dev <= max(base, 2 err_ref); `spread` is then only recorded ("K needed", the rounds-2/3 diagnostic).
     Without truth: the old rules (spread, else pivot)."""
@@ -219,6 +229,10 @@ def check(err, state, key, base=1e-12, where=None, spread=None, truth=None):
         rec.update(err=float(err), pivot=float(piv))
     if judged >= rec.get("judged", -1.0):
         rec.update(judged=judged, tol=float(tol), rule=rule)
+    if not stop and truth is not None and judged > tol:
+        rec["stops"] = rec.get("stops", 0) + 1
+        STOPS.append((key, where, judged, float(tol)))
+        return err
     assert judged <= tol, (key, where, judged, float(tol), float(piv), rule, float(err))
     return err
 

@@ -92,7 +92,7 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
                 P.record(0.0, 0.0, key)
             elif np.linalg.norm(x) > 0:
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value,
-                truth=spread.truth(ft.cpu().numpy(), x))
+                truth=spread.truth(ft.cpu().numpy(), x), stop=strict)
             else:
                 assert np.array_equal(ft.cpu().numpy(), f), (key, step)     # a zero input returns a zero
         elif op[0] == "relax":
@@ -202,7 +202,7 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True)
             spread.update(arg)
             if np.linalg.norm(arg) > 0:
                 P.check(S.rel_err(got, f, arg), ora.state(), key, where=step, spread=spread.value,
-                truth=spread.truth(got, arg))
+                truth=spread.truth(got, arg), stop=strict)
             else:
                 assert np.array_equal(got, f), (key, step)
         elif code == 1:
@@ -215,6 +215,16 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True)
     assert all(poss[r] == raws[r].size for r in range(world)), key
     BEYOND.extend(P.finish([key], strict))
     return key
+
+
+def seed_line(key, rec, P):
+    """One record per sequence that ran to its end: "ok", or "stop" where the per-call stop was tripped on the way (recorded,
+    the sequence still judged by THE rule: tests/parity_util.py check(stop=False))."""
+    trips = [(w, f"{j:.2e}", f"{t:.2e}") for k, w, j, t in P.STOPS if k == key]
+    return (f"{'stop' if trips else 'ok  '} {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
+            f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
+            f"{rec.get('err', 0.0):.2e}, spread K {rec.get('k_needed', 0.0):.2f})"
+            + (f" per-call stop tripped at (operation, err_dev, limit): {trips}" if trips else "") + "\n")
 
 
 class _Alias:
@@ -271,7 +281,7 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
             if nx > 0:
                 # this rank's share of the global error (the slices' squares add up to the whole)
                 P.check(float(np.linalg.norm(out - f[lo:hi]) / nx), acc.state(), key, where=step, spread=spread.value,
-                        truth=spread.truth(out, x, sl=slice(lo, hi)))
+                        truth=spread.truth(out, x, sl=slice(lo, hi)), stop=strict)
             else:
                 assert np.array_equal(out, f[lo:hi]), (key, step)
         elif r < 0.87:
@@ -316,9 +326,7 @@ def sharded_worker(args):
         try:
             key = one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, strict=False)
             rec = P.WORST.get(key, {})
-            out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
-                      f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
-                      f"{rec.get('err', 0.0):.2e}, spread K {rec.get('k_needed', 0.0):.2f})\n")
+            out.write(seed_line(key, rec, P))
             out.flush()
         except Exception:                                   # noqa: BLE001
             out.write(f"FAIL seed {seed} rank {rank}\n{traceback.format_exc()}\n")
@@ -330,10 +338,12 @@ def sharded_worker(args):
             print(f"{seed - args.first_seed} seeds, {time.time() - t0:.0f} s", flush=True)
     rmax = max([r.get("truth_ratio", 0.0) for r in P.WORST.values()] + [0.0])
     out.write(f"# rank {rank}: seeds {args.first_seed}..{seed - 1} ok; truth rule: largest share of the allowance used {rmax:.2f}; "
-              f"sequences beyond it (below the hard stop): {len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}\n")
+              f"sequences beyond it: {len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}; per-call stops tripped "
+              f"(recorded, sequence continued): {len(P.STOPS)} {[(k, w) for k, w, _, _ in P.STOPS]}\n")
     out.close()
     if rank == 0:
-        print(f"# seeds {args.first_seed}..{seed - 1} ok on {dist.get_world_size()} ranks; largest K needed (rank 0) {kmax:.2f}")
+        print(f"# seeds {args.first_seed}..{seed - 1} ran to their end on {dist.get_world_size()} ranks; rank 0: largest share of the allowance "
+              f"{rmax:.2f}, beyond it {len(BEYOND)}, per-call stops tripped {len(P.STOPS)}")
     dist.barrier()
     dist.destroy_process_group()
     return 0
@@ -384,9 +394,7 @@ def main():
                 else:
                     key = one_seed(seed, torch, oracle, P, S, nka_amd, hostdot=args.hostdot, strict=False)
                 rec = P.WORST.get(key, {})
-                out.write(f"ok   {key}: dev-exact {rec.get('err_dev_exact') or 0.0:.2e} ref-exact {rec.get('err_ref_exact') or 0.0:.2e} "
-                          f"(tol {rec.get('tol', 0.0):.1e}, allowance used {rec.get('truth_ratio', 0.0):.2f}; dev-ref "
-                          f"{rec.get('err', 0.0):.2e}, spread K {rec.get('k_needed', 0.0):.2f})\n")
+                out.write(seed_line(key, rec, P))
             except Exception:                               # noqa: BLE001 -- record and carry on with the next seed
                 failed.append(seed)
                 out.write(f"FAIL seed {seed}\n{traceback.format_exc()}\n")
@@ -401,8 +409,10 @@ def main():
         summary = (f"# seeds {args.first_seed}..{seed - 1}: {seed - args.first_seed - len(failed)} ok, {len(failed)} failed "
                    f"{failed}; truth rule (max err_dev <= max(base, {P.TRUTH_FACTOR:g} x max err_ref) per sequence): share of the "
                    f"allowance used -- median {rq(0.5):.2f}, 90 % {rq(0.9):.2f}, largest {rq(1.0):.2f}; spread diagnostic: largest K "
-                   f"{kmax:.2f}; well-conditioned worst dev-ref {wmax:.2e}; sequences beyond the allowance (below the hard stop of "
-                   f"{P.TRUTH_HARD:g} x per call): {len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}")
+                   f"{kmax:.2f}; well-conditioned worst dev-ref {wmax:.2e}; sequences beyond the allowance: "
+                   f"{len(BEYOND)} {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in BEYOND]}; per-call stops ({P.TRUTH_HARD:g} x the reference's "
+                   f"distance so far, {P.TRUTH_HARD_TINY:g} x within one tile) tripped -- recorded, sequence continued: {len(P.STOPS)} "
+                   f"{[(k, w) for k, w, _, _ in P.STOPS]}")
         out.write(summary + "\n")
     print(summary)
     return 1 if failed else 0

@@ -13,7 +13,7 @@ import parity_util as P  # noqa: E402
 
 def records(path):
     for ln in open(path):
-        if not ln.startswith("ok"):
+        if not ln.startswith(("ok", "stop")):
             continue
         m = re.search(r"dev-exact ([0-9.e+-]+) ref-exact ([0-9.e+-]+)", ln)
         if not m:
@@ -24,7 +24,7 @@ def records(path):
         else:
             k = re.search(r" (\d+)x(\d+) m=(\d+)", ln)
             n, mv = int(k.group(1)) * int(k.group(2)), int(k.group(3))
-        yield float(m.group(1)), float(m.group(2)), n, mv
+        yield float(m.group(1)), float(m.group(2)), n, mv, ln.startswith("stop")
 
 
 def main():
@@ -39,7 +39,7 @@ def main():
         rec = list(records(f))
         failed = sum(1 for ln in open(f) if ln.startswith("FAIL"))
         used, beyond = [], []
-        for dev, ref, n, mv in rec:
+        for dev, ref, n, mv, _ in rec:
             fac = P.truth_factor(n, mv)
             used.append(dev / (fac * ref) if dev > 1e-12 and ref > 0 else 0.0)
             if dev > max(1e-12, fac * ref):
@@ -49,7 +49,9 @@ def main():
         if not used:
             lines.append(f"## {os.path.basename(f)}: no records")
             continue
-        lines.append(f"## {os.path.basename(f)}: {len(rec)} sequences" + (f" (+ {failed} stopped by the per-call hard stop or an assertion: see the file)" if failed else ""))
+        tripped = sum(1 for r in rec if r[4])
+        lines.append(f"## {os.path.basename(f)}: {len(rec)} sequences" + (f" (+ {failed} ended by the per-call stop or an assertion: see the file)" if failed else "")
+                     + (f"; per-call stop tripped in {tripped} (recorded, the sequence ran on and is judged here)" if tripped else ""))
         lines.append(f"share of the allowance used: median {used[len(used) // 2]:.2f}, 90 % {used[int(.9 * len(used))]:.2f}, largest {used[-1]:.2f}; "
                      f"beyond the allowance: {len(beyond)} {beyond}")
         lines.append("")
