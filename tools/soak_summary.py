@@ -66,6 +66,15 @@ def main():
                          f"{sum(1 for x in rat if x > 2):5d} {sum(1 for x in rat if x > 4):5d}")
         else:
             lines.append(f"{lab:>14s} {len(sel):10d} {0:11d}")
+    lines.append("")
+    lines.append("## both directions: records in which either err_dev or err_ref ends above 1e-12 -- how often is the DEVICE further from the")
+    lines.append("## extended-precision trajectory than the reference by more than 2 x / 4 x, and how often the REFERENCE further than the device")
+    lines.append(f"{'n':>14s} {'records':>8s} {'device > 2 x':>13s} {'device > 4 x':>13s} {'reference > 2 x':>16s} {'reference > 4 x':>16s}")
+    for lo, hi in ((1, 16), (17, 512), (513, 2048), (2049, 10**9)):
+        sel = [r for r in allr if lo <= r[2] <= hi and max(r[0], r[1]) > 1e-12 and min(r[0], r[1]) > 0]
+        lab = f"{lo}..{hi}" if hi < 10**9 else f"> {lo - 1}"
+        lines.append(f"{lab:>14s} {len(sel):8d} {sum(1 for r in sel if r[0] > 2 * r[1]):13d} {sum(1 for r in sel if r[0] > 4 * r[1]):13d} "
+                     f"{sum(1 for r in sel if r[1] > 2 * r[0]):16d} {sum(1 for r in sel if r[1] > 4 * r[0]):16d}")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
