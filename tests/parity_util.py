@@ -22,8 +22,9 @@ is not within 1e-12 of the truth; how far it is, is MEASURED (round 4), not esti
   and err_ref at that event are two draws of the same rounding-error distribution (the device's
   inner products are NOT less accurate: tools/error_attribution.py), and which call a draw
   peaks at differs between them; per call, a hard stop at TRUTH_HARD (8; 32 within one tile) x the reference's distance
-  so far catches a real defect where it happens.  Decisions (num_vec, list order, slots,
-  s == 0) are compared exactly, separately.
+  so far catches a real defect where it happens (every test; the soak tool records a trip and lets the sequence run on:
+  check(stop=False)).  The rule is an empirical bar with a counted exceedance rate, 25 of 18 916 soak records in round 4
+  (truth_factor).  Decisions (num_vec, list order, slots, s == 0) are compared exactly, separately.
 
 The rule of rounds 2-3 -- ||f_device - f_reference|| <= max(base, 4 x spread), spread = the
 largest pairwise difference of the reference's three flavours -- is still COMPUTED and printed
