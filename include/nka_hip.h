@@ -139,7 +139,8 @@ int nka_hip_accel_update(nka_hip_t a, double *f_dev);
  *   out  *f_io  : a free device buffer of the library (>= vlen_local doubles, contents undefined) for the caller's NEXT
  *                 input; it dies with the handle.
  *   out  *f_acc : the accelerated f -- the v of the new pair, stored once -- to be READ only (solution update, next
- *                 residual), valid until the next accel_update* / restart / destroy on this handle.
+ *                 residual), valid until the next accel_update* / restart / destroy on this handle.  Handing it to either
+ *                 update entry as the next f is refused (NKA_HIP_EINVAL): it is the stored v of the pending pair.
  * Same arithmetic, same bits, same state as nka_hip_accel_update on the same inputs; the two entries can be mixed.  The
  * buffers an update displaces are known on the device only; they reach the host with the list word's record (no
  * synchronisation if the caller has synchronised since the previous out-of-place update, else this call waits for the

@@ -1078,6 +1078,9 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   if (!f && a->n > 0) return fail(NKA_HIP_EINVAL, "accel_update: f is NULL");
   HIP_TRY(hipSetDevice(a->device));
   if (int rc = nka_detail::check_device_span(f, a->n, "accel_update: f")) return rc;   // F08:258 size(f) == vlen
+  if (swap_w == kNoBuffer && f && f == a->last_acc)      // in place on the buffer the last out-of-place update lent for READING
+    return fail(NKA_HIP_EINVAL, "accel_update: that buffer is the accelerated f lent by the previous out-of-place update (read only: "
+                                "it is the stored v of the pending pair); copy it, or go on with nka_hip_accel_update_swap");
   if (a->needs_comm)
     return fail(NKA_HIP_ECOMM, "accel_update: this accelerator is a copy of a sharded one and has no all-reduce yet: call "
                                "nka_hip_comm_init_rank or nka_hip_set_allreduce on it first (nka_hip_clone)");
@@ -1142,6 +1145,7 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   if (a->timing_this) a->timing_count++;
   a->list_ub = comb_ub + 1;
   a->pending = true;
+  if (swap_w == kNoBuffer) a->last_acc = nullptr;         // (the loan of the previous out-of-place update has ended)
   return 0;
 }
 

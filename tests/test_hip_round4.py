@@ -280,4 +280,6 @@ def test_out_of_place_update_argument_checks(torch_cuda):
     assert buf2.data_ptr() not in (buf.data_ptr(), acc2.data_ptr()) and a.num_vec() == 1
     with pytest.raises(nka_amd.NKAError, match="read only"):
         a.accel_update_swap(acc2)                         # the accelerated f is the stored v of the pending pair: not an input
+    with pytest.raises(nka_amd.NKAError, match="read only"):
+        a.accel_update(acc2)                              # ... nor the in-place entry's f (it would be overwritten while read)
     assert a.num_vec() == 1 and a.defined()
