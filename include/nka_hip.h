@@ -147,6 +147,23 @@ int nka_hip_accel_update(nka_hip_t a, double *f_dev);
  * stream).  Not with nka_hip_set_host_dot; not capturable into a graph. */
 int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
 
+/* HOW THE INNER PRODUCTS ARE SUMMED.  The reference's sums are sequential (its default dot product: C .c:200-208;
+ * `dot_product` in F08:216-219); the fast passes sum in blocks, fused, and take the Gram row of the normalised
+ * difference from raw sums -- closer to the exact result than the reference from n ~ 1e3 up, but other bits.
+ *   NKA_HIP_SUMS_REFERENCE_ORDER  every sum of an update exactly as the reference forms it -- the norm first, then
+ *       <w1',w_k>, <f,w_k>, <f,w1'> on the ROUNDED w1' = d/s, element after element, one rounding per product and per
+ *       addition -- on one workgroup.  Everything else of an update being bit-exact given its sums, accel_update then
+ *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
+ *       does) at ANY n: a validation mode for callers moving over from the reference (n sequential additions per
+ *       sum: about 4 ms per update at n = 1e6).  Single rank only (a sharded update would need the global norm before
+ *       the Gram row: a second exchange): accel_update returns NKA_HIP_ESTATE with an all-reduce installed.
+ *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
+ *   NKA_HIP_SUMS_AUTO (default)   reference order where it is free -- a single rank and a vector of at most one tile of
+ *       the fast passes (n <= 512), where it is also faster than they are -- blocked otherwise.
+ * A user dot product (nka_hip_set_host_dot) overrides all three.  Can be changed between updates. */
+enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2 };
+int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
+
 /* Host-array compatibility entry (the reference signature takes host memory,
  * F08:252): H2D copy, update, D2H copy, stream synchronised on return. */
 int nka_hip_accel_update_host(nka_hip_t a, double *f_host);
@@ -179,7 +196,8 @@ int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t 
  * red[0] = <d,d>, red[1] = <f,d>, red[2+p] = <d,w_p>, red[2+mvec+p] = <f,w_p>
  * for the p-th older list entry (2+2*mvec doubles).  The solve divides the d
  * rows by s = sqrt(red[0]).  With these a CPU restatement of the scalar step
- * can be checked bit for bit. */
+ * can be checked bit for bit.  With reference-order sums (nka_hip_set_sum_order) red[1] and red[2+p] are the sums on the
+ * NORMALISED difference, <f,w1'> and <w1',w_p>, and the solve takes them as they are. */
 int nka_hip_get_reductions(nka_hip_t a, double *red_out);
 /* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
 int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);

@@ -218,6 +218,7 @@ struct nka_hip_state {
   bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
                                  // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
+  int sum_order = NKA_HIP_SUMS_AUTO;   // nka_hip_set_sum_order: reference-order sums (k_dots_ordered) within one tile / always / never
   bool debug = false;         // NKA_HIP_DEBUG=1: check defined() on entry of every update, like the
                               // reference built without -DNDEBUG (F08:257); synchronises
   // distribution hook
@@ -788,6 +789,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tile = src->pb_tile;
   b->pb_tickets = src->pb_tickets;
   b->serial_solve = src->serial_solve;
+  b->sum_order = src->sum_order;
   b->debug = src->debug;
   if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
     b->allreduce = src->allreduce;
@@ -1067,6 +1069,12 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   return 0;
 }
 
+// Reference-order sums: asked for, or free -- a vector of at most one tile of the blocked kernels on a single rank.
+static bool ordered_sums(const nka_hip_state *a) {
+  if (a->allreduce || a->host_dot) return false;
+  return a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER || (a->sum_order == NKA_HIP_SUMS_AUTO && a->n <= kOrdChunk);
+}
+
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
 
 int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, kNoBuffer, kNoBuffer); }
@@ -1084,6 +1092,10 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   if (a->needs_comm)
     return fail(NKA_HIP_ECOMM, "accel_update: this accelerator is a copy of a sharded one and has no all-reduce yet: call "
                                "nka_hip_comm_init_rank or nka_hip_set_allreduce on it first (nka_hip_clone)");
+  if (a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER && a->allreduce && !a->host_dot)
+    return fail(NKA_HIP_ESTATE, "accel_update: reference-order sums were asked for (nka_hip_set_sum_order) on a sharded "
+                                "accelerator: the Gram row of the normalised difference needs the GLOBAL norm first, a second "
+                                "exchange per update, which this library does not make");
   if (a->debug && nka_hip_defined(a) != 1)                                                // F08:257 ASSERT(defined(this))
     return fail(NKA_HIP_ESTATE, "accel_update: the device state fails the defined() invariants");
   hipStream_t s = a->stream;
@@ -1111,6 +1123,14 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     RoctxRange range("nka:host dot products + scalar step");
     if (int rc = host_dot_update_scalars(a, f, mode)) return rc;
     solved = true;
+  } else if (ordered_sums(a)) {
+    // every sum in the reference's order on one workgroup: the update returns the reference's bits (k_dots_ordered)
+    RoctxRange range("nka:PA dots in the reference's order");
+    if (a->pending || older_ub > 0) {
+      hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), 0, s, a->ctl, a->vs, f, mode & kSolveRcp);
+      HIP_TRY(hipGetLastError());
+    }
+    mode |= kSolvePrenorm;
   } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
     enqueue_pa(a, f, vec, older_ub);
@@ -1510,6 +1530,14 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
   HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
   HIP_TRY(hipEventElapsedTime(&ms[2], e[2], e[3]));
   HIP_TRY(hipEventElapsedTime(&ms[3], e[0], e[3]));
+  return 0;
+}
+
+int nka_hip_set_sum_order(nka_hip_t a, int32_t order) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (order != NKA_HIP_SUMS_AUTO && order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED)
+    return fail(NKA_HIP_EINVAL, "set_sum_order: NKA_HIP_SUMS_AUTO, _REFERENCE_ORDER or _BLOCKED");
+  a->sum_order = order;
   return 0;
 }
 

@@ -518,6 +518,101 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
   if (lane == 0) ctl.red()[dst] = live ? r : 0.0;
 }
 
+// ---- PA in the REFERENCE'S ORDER: every sum of the update as the reference forms it ---------------
+// One workgroup.  The reference's inner products are sequential sums of rounded products (its default dot product:
+// C .c:200-208; `dot_product(x, y)` in F08:216-219, compiled without contraction as oracle/Makefile does), the norm first (F08:267), then -- with w1' = d/s (F08:283; (1/s)*d in the vector flavour,
+// F08V:256) already ROUNDED -- the Gram row <w1',w_k> (F08:286-290) and the projections <f,w_k>, <f,w1'> (F08:371).
+// This kernel forms exactly those: element after element, one rounding per product and per addition (no fma), the
+// normalised w1' staged through LDS in chunks so that every sum sees the same rounded values PB will store.  red[] then
+// holds  [0] sum d^2, [1] <f,w1'>, [2+p] <w1',w_p>, [2+mvec+p] <f,w_p>  -- the scalar step takes [1] and the Gram row as
+// they are (kSolvePrenorm) -- and, the scalar step and PB's statements being bit-exact given their inputs, the update
+// returns THE REFERENCE'S BITS.  Thread 0 sums the norm; thread r owns sum r of the second phase (two each beyond 256).
+// Cost: n sequential additions -- free within one tile of the fast kernels (n <= 512: 5 us, where the blocked PA and its
+// final sums take 13), a validation mode beyond (about 4 ms per update at n = 1e6).  Single rank only: the Gram row
+// needs the GLOBAL norm first, i.e. a second exchange (nka_hip_set_sum_order).
+constexpr int kOrdThreads = 256;
+constexpr int kOrdChunk = 512;
+static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_dots_ordered(Ctl ctl, Vecs vs, const double *__restrict__ f, int rcp) {
+  __shared__ double sh[kOrdChunk];
+  __shared__ double sum_dd;
+  const int t = threadIdx.x;
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const int mvec = ctl.mvec;
+  const int64_t n = vs.n;
+  const double *w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f;
+  const long long *pw = ctl.plan_w();
+  double *red = ctl.red();
+
+  double s = 0.0;
+  if (pending) {                                     // the norm, F08:266-267
+    double acc = 0.0;
+    for (int64_t c0 = 0; c0 < n; c0 += kOrdChunk) {
+      const int len = (int)(n - c0 < kOrdChunk ? n - c0 : kOrdChunk);
+      for (int i = t; i < len; i += kOrdThreads) sh[i] = w1[c0 + i] - f[c0 + i];
+      __syncthreads();
+      if (t == 0)
+        for (int i = 0; i < len; i++) acc = __dadd_rn(acc, __dmul_rn(sh[i], sh[i]));
+      __syncthreads();
+    }
+    if (t == 0) sum_dd = acc;
+    __syncthreads();
+    s = sqrt(sum_dd);
+  }
+  const bool normed = pending && s != 0.0;           // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
+  const double rs = 1.0 / s;
+  // second phase: sum r of  [<f,w1'>,] <w1',w_p> (p < nolder), <f,w_p> (p < nolder)
+  const int first_rows = normed ? 1 + nolder : 0;    // sums that involve w1'
+  const int nsum = first_rows + nolder;
+  double acc[2] = {0.0, 0.0};
+  const double *yv[2] = {f, f};
+  bool x_is_f[2] = {true, true}, y_is_w1[2] = {false, false}, live[2] = {false, false};
+  for (int q = 0; q < 2; q++) {
+    const int r = t + q * kOrdThreads;
+    if (r >= nsum) continue;
+    live[q] = true;
+    if (r < first_rows) {
+      if (r == 0) { x_is_f[q] = true; y_is_w1[q] = true; }                       // <f,w1'>
+      else { x_is_f[q] = false; yv[q] = vs.w + pw[r - 1]; }                      // <w1',w_p>
+    } else {
+      yv[q] = vs.w + pw[r - first_rows];                                         // <f,w_p>
+    }
+  }
+  for (int64_t c0 = 0; c0 < n; c0 += kOrdChunk) {
+    const int len = (int)(n - c0 < kOrdChunk ? n - c0 : kOrdChunk);
+    if (normed) {
+      for (int i = t; i < len; i += kOrdThreads) {
+        const double d = w1[c0 + i] - f[c0 + i];
+        sh[i] = rcp ? __dmul_rn(rs, d) : d / s;      // the value PB stores as w1'
+      }
+    }
+    __syncthreads();
+    for (int q = 0; q < 2; q++) {
+      if (!live[q]) continue;
+      const double *y = yv[q] + c0;
+      double a = acc[q];
+      if (x_is_f[q] && y_is_w1[q])
+        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(f[c0 + i], sh[i]));
+      else if (x_is_f[q])
+        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(f[c0 + i], y[i]));
+      else
+        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(sh[i], y[i]));
+      acc[q] = a;
+    }
+    __syncthreads();
+  }
+  // red[]: zero what this update does not cover (nothing stale reaches a later reader), then the sums
+  for (int i = t; i < 2 + 2 * mvec; i += kOrdThreads) red[i] = 0.0;
+  __syncthreads();
+  if (t == 0 && pending) red[0] = sum_dd;
+  for (int q = 0; q < 2; q++) {
+    if (!live[q]) continue;
+    const int r = t + q * kOrdThreads;
+    if (r < first_rows) red[r == 0 ? 1 : 2 + (r - 1)] = acc[q];
+    else red[2 + mvec + (r - first_rows)] = acc[q];
+  }
+}
+
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------
 // COMB 0: x/s          ; (f - c*w) + c*v       F08:282-283, 397
 // COMB 1: (1/s)*x      ; ((-c)*w + c*v) + f    F08V:255-256 scale(1/s), :374 update3_

@@ -75,6 +75,7 @@ module nka_type
     procedure :: accel_update_dev
     procedure :: accel_update_swap
     procedure :: list_bound
+    procedure :: set_sum_order
     procedure :: relax
     procedure :: restart
     procedure :: defined
@@ -87,6 +88,7 @@ module nka_type
   end type nka
 
   public :: NKA_HIP_FLAVOR_F08, NKA_HIP_FLAVOR_F08_VECTOR, NKA_HIP_FLAVOR_C, NKA_HIP_FLAVOR_DEFAULT
+  public :: NKA_HIP_SUMS_AUTO, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED
 
 contains
 
@@ -243,6 +245,16 @@ contains
     class(nka), intent(in) :: this
     list_bound = nka_hip_list_bound(this%handle)
   end function list_bound
+
+  !! How the inner products are summed (nka_hip_set_sum_order, include/nka_hip.h): NKA_HIP_SUMS_REFERENCE_ORDER = every sum
+  !! as the reference forms it (an update then returns the reference's bits at any n; single rank; slow beyond a few
+  !! thousand elements), NKA_HIP_SUMS_BLOCKED = the fast passes at every n, NKA_HIP_SUMS_AUTO (default) = reference order
+  !! within one tile (n <= 512).
+  subroutine set_sum_order(this, order)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: order
+    call nka_hip_check(nka_hip_set_sum_order(this%handle, int(order, c_int32_t)), 'nka%set_sum_order')
+  end subroutine set_sum_order
 
   subroutine restart(this)                                    ! F08:422-436
     class(nka), intent(inout) :: this

@@ -11,6 +11,7 @@ module nka_hip_c
   integer(c_int), parameter :: NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2
   !! resolved by nka_hip_create: environment NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
   integer(c_int), parameter :: NKA_HIP_FLAVOR_DEFAULT = -1
+  integer(c_int), parameter :: NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2
 
   interface
     integer(c_int) function nka_hip_create(handle, vlen_local, mvec, vtol, flavor, device, stream) bind(C)
@@ -43,6 +44,11 @@ module nka_hip_c
     integer(c_int) function nka_hip_list_bound(handle) bind(C)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle
+    end function
+    integer(c_int) function nka_hip_set_sum_order(handle, order) bind(C)
+      import :: c_int, c_ptr, c_int32_t
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: order      ! NKA_HIP_SUMS_AUTO / _REFERENCE_ORDER / _BLOCKED (include/nka_hip.h)
     end function
     integer(c_int) function nka_hip_accel_update_host(handle, f_host) bind(C)
       import :: c_int, c_ptr, c_double

@@ -17,6 +17,7 @@ from . import _lib
 
 FLAVOR_F08, FLAVOR_F08_VECTOR, FLAVOR_C = 0, 1, 2
 FLAVOR_DEFAULT = -1     # resolved by the library: NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
+SUMS_AUTO, SUMS_REFERENCE_ORDER, SUMS_BLOCKED = 0, 1, 2     # nka_hip_set_sum_order (include/nka_hip.h)
 
 
 class NKAError(RuntimeError):
@@ -292,6 +293,13 @@ class nka:  # noqa: N801  (the reference's type name)
         """True once an accel_update captured into a hipGraph stays valid on replay
         (steady state: see nka_hip_capture_safe in include/nka_hip.h)."""
         return self._L.nka_hip_capture_safe(self._handle()) == 1
+
+    def set_sum_order(self, order: int):
+        """How the inner products are summed (nka_hip_set_sum_order): SUMS_REFERENCE_ORDER = every sum as the reference forms
+        it, so that an update returns the reference's bits at any n (single rank; slow beyond a few thousand elements);
+        SUMS_BLOCKED = the fast passes at every n; SUMS_AUTO (default) = reference order within one tile (n <= 512)."""
+        _check(self._L.nka_hip_set_sum_order(self._handle(), int(order)), "set_sum_order", self._L)
+        return self
 
     def list_bound(self) -> int:
         """The host's upper bound on the list length at the entry of the next update (no synchronisation):

@@ -1,0 +1,190 @@
+"""Reference-order sums (nka_hip_set_sum_order, k_dots_ordered): with every inner product of an update summed exactly as
+the reference sums it -- the norm first, then the Gram row and the projections on the ROUNDED w1' = d/s, element after
+element, one rounding per product and per addition -- the scalar step and PB's statements being bit-exact given their
+inputs, nka_hip_accel_update returns THE REFERENCE'S BITS.  By default (NKA_HIP_SUMS_AUTO) that holds for every vector of
+at most one tile (n <= 512) on a single rank -- every golden scenario of the compiled reference among them --, on request
+(NKA_HIP_SUMS_REFERENCE_ORDER) at any n.  All comparisons here are np.array_equal: no tolerance anywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+FLAVORS = {0: "f_out_f08", 1: "f_out_f08vec", 2: "f_out_c"}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _update(torch, acc, x, swap=False):
+    t = torch.from_numpy(x.copy()).cuda()
+    if swap:
+        _, out = acc.accel_update_swap(t)
+        return out.cpu().numpy()
+    acc.accel_update(t)
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", S.scenario_names())
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+def test_every_golden_scenario_of_the_compiled_reference_bit_for_bit(torch_cuda, name, flavor):
+    """The ten state-machine scenarios (n = 64 and n = 7): outputs of the COMPILED reference flavour the handle runs,
+    held by the fixture, against the default device path -- equal in every bit of every output, and in the factor."""
+    import nka_amd
+    g = S.load(name)
+    key = FLAVORS[flavor]
+    if key not in g.files:
+        pytest.skip("fixture has no output for this flavour")
+    n, m = int(g["n"]), int(g["mvec"])
+    assert n <= 512
+    acc = nka_amd.nka().init(n, m, flavor=flavor)                     # NKA_HIP_SUMS_AUTO
+    states = []
+    outs, trace = S.replay(acc, g, update=lambda a, f: _update(torch_cuda, a, f), after_update=lambda u, a: states.append(a.state()))
+    assert np.array_equal(trace, g["num_vec"])
+    for u in range(len(outs)):
+        assert np.array_equal(outs[u], g[key][u]), (name, flavor, u, float(np.abs(outs[u] - g[key][u]).max()))
+    if "h" in g.files and flavor == 2:                                # the C reference's factor, entry by entry
+        for u, st in enumerate(states):
+            live = st.list_order()[1:]
+            ix = np.ix_([k - 1 for k in live], [k - 1 for k in live])
+            assert np.array_equal(st.h[ix], g["h"][u][ix]), (name, u)
+    assert acc.defined()
+
+
+def _lockstep(torch, oracle, n, m, flavor, order, calls=30, seed=0, swap_every=0):
+    import nka_amd
+    rng = np.random.default_rng(1000 * n + 10 * m + flavor + seed)
+    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    if order is not None:
+        acc.set_sum_order(order)
+    ora = oracle.OracleNKA(n, m, flavor)
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    for t in range(calls):
+        kind = t % 7
+        x = rng.standard_normal(3) @ basis if kind in (3, 5) else prev.copy() if kind == 6 else rng.standard_normal(n)
+        prev = x
+        f = x.copy()
+        ora.accel_update(f)
+        out = _update(torch, acc, x, swap=bool(swap_every) and t % swap_every == 1)
+        assert np.array_equal(out, f), (n, m, flavor, t, float(np.abs(out - f).max()))
+        sa, so = acc.state(), ora.state()
+        assert sa.list_order() == so.list_order() and sa.free_order() == so.free_order()
+        live = so.list_order()[1:]
+        ix = np.ix_([k - 1 for k in live], [k - 1 for k in live])
+        assert np.array_equal(sa.h[ix], so.h[ix]), (n, m, flavor, t)
+        if t == 11:
+            acc.relax(); ora.relax()
+        if t == 19:
+            acc.set_vec_tol(0.3); ora.set_vec_tol(0.3)
+        if t == 24:
+            acc.restart(); ora.restart()
+    assert acc.defined()
+    return acc
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+@pytest.mark.parametrize("n,m", [(1, 2), (2, 5), (7, 8), (64, 6), (255, 20), (512, 9), (512, 40)])
+def test_within_one_tile_the_default_path_returns_the_reference_bits(torch_cuda, oracle, flavor, n, m):
+    """Random call sequences with dependent and repeated inputs, relax, set_vec_tol, restart, lists beyond one launch of
+    the fast passes (m = 40): the oracle's flavour (pinned to its compiled reference bit for bit) and the device agree in
+    every bit of every output and of the factor, in place and out of place."""
+    _lockstep(torch_cuda, oracle, n, m, flavor, None, swap_every=3)
+
+
+@pytest.mark.parametrize("flavor", [0, 1, 2])
+@pytest.mark.parametrize("n,m", [(513, 4), (4099, 10), (20011, 20), (100003, 6)])
+def test_on_request_the_reference_bits_at_any_length(torch_cuda, oracle, flavor, n, m):
+    import nka_amd
+    _lockstep(torch_cuda, oracle, n, m, flavor, nka_amd.SUMS_REFERENCE_ORDER, calls=26, swap_every=4)
+
+
+def test_medium_fixture_of_the_compiled_f08_reference_bit_for_bit(torch_cuda):
+    """n = 1e5, m = 10, 25 calls: the samples, the norm and the probe functional of the compiled src-F08 reference's
+    outputs (tests/golden/medium_n100000_m10.npz) -- equal, not close."""
+    import nka_amd
+    g = np.load(os.path.join(S.GOLD, "medium_n100000_m10.npz"))
+    n, m, calls = int(g["n"]), int(g["mvec"]), int(g["calls"])
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    acc = nka_amd.nka().init(n, m, flavor=nka_amd.FLAVOR_F08).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+    probe = np.cos(np.arange(n) * 0.001)
+    for t in range(calls):
+        f = rng.random(n) * 2.0 - 1.0
+        out = _update(torch_cuda, acc, f)
+        assert acc.num_vec() == g["num_vec"][t]
+        assert np.array_equal(out[g["idx"]], g["out_samples"][t]), t
+        assert float(np.linalg.norm(out)) == float(g["out_norm"][t]) and float(out @ probe) == float(g["out_probe"][t]), t
+
+
+def test_auto_is_blocked_beyond_one_tile_and_for_sharded_accelerators(torch_cuda, oracle):
+    """What NKA_HIP_SUMS_AUTO chooses shows in red[1]: <f,d> (raw, blocked) or <f,w1'> (reference order)."""
+    import nka_amd
+    rng = np.random.default_rng(9)
+
+    def red1_is_raw(acc, n):
+        x0, x1 = rng.standard_normal(n), rng.standard_normal(n)
+        _update(torch_cuda, acc, x0)
+        _update(torch_cuda, acc, x1)
+        red = acc.reductions()
+        d = x0 - x1
+        raw, normed = float(x1 @ d), float(x1 @ d) / np.sqrt(float(d @ d))
+        assert min(abs(red[1] - raw), abs(red[1] - normed)) <= 1e-12 * abs(raw) + 1e-13
+        return abs(red[1] - raw) < abs(red[1] - normed)
+
+    assert not red1_is_raw(nka_amd.nka().init(512, 3), 512)
+    assert red1_is_raw(nka_amd.nka().init(513, 3), 513)
+    assert red1_is_raw(nka_amd.nka().init(512, 3).set_sum_order(nka_amd.SUMS_BLOCKED), 512)
+    assert not red1_is_raw(nka_amd.nka().init(3001, 3).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER), 3001)
+    sharded = nka_amd.nka().init(64, 3)
+    sharded.set_dot_prod(lambda ptr, count, stream: None)          # "a global sum": the accelerator is one slice of many
+    assert red1_is_raw(sharded, 64)
+    sharded.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+    with pytest.raises(nka_amd.NKAError, match="second exchange"):
+        sharded.accel_update(torch_cuda.zeros(64, dtype=torch_cuda.float64, device="cuda"))
+    sharded.set_sum_order(nka_amd.SUMS_AUTO)
+    sharded.accel_update(torch_cuda.ones(64, dtype=torch_cuda.float64, device="cuda"))
+    with pytest.raises(nka_amd.NKAError):
+        sharded.set_sum_order(7)
+
+
+def test_a_copy_keeps_the_sum_order_and_a_captured_update_replays_it(torch_cuda, oracle):
+    import nka_amd
+    torch = torch_cuda
+    n, m = 3001, 4
+    rng = np.random.default_rng(4)
+    a = nka_amd.nka().init(n, m, flavor=0).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+    ora = oracle.OracleNKA(n, m, 0)
+    for t in range(m + 3):
+        x = rng.standard_normal(n)
+        f = x.copy(); ora.accel_update(f)
+        assert np.array_equal(_update(torch, a, x), f)
+    b = a.copy()
+    x = rng.standard_normal(n)
+    f = x.copy(); ora.accel_update(f)
+    assert np.array_equal(_update(torch, b, x), f)                  # the copy sums in the reference's order too
+    # captured into a graph on a side stream (steady state: capture_safe), replayed on fresh inputs
+    torch.cuda.synchronize()
+    assert b.capture_safe()
+    x = rng.standard_normal(n)
+    buf = torch.from_numpy(x.copy()).cuda()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        b.set_stream(s.cuda_stream)
+        with torch.cuda.graph(g, stream=s):
+            b.accel_update(buf)
+    for rep in range(3):
+        x = rng.standard_normal(n)
+        buf.copy_(torch.from_numpy(x))
+        g.replay()
+        torch.cuda.synchronize()
+        f = x.copy(); ora.accel_update(f)
+        assert np.array_equal(buf.cpu().numpy(), f), rep

@@ -51,8 +51,12 @@ def _pairwise_dot(x, y):
 
 def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, strict=True):
     rng, n, m, flavor = array_shape(seed, hostdot)
-    key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}"
-    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    # how the sums are formed (nka_hip_set_sum_order), by seed: the fast blocked passes at every n / the default (reference
+    # order within one tile) / reference order at every n -- where the order is the reference's the outputs must be its BITS
+    sums = (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER)[seed % 3]
+    same_bits = not hostdot and (sums == nka_amd.SUMS_REFERENCE_ORDER or (sums == nka_amd.SUMS_AUTO and n <= 512))
+    key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}" + ("" if hostdot else f" sums {('blocked', 'auto', 'reference')[seed % 3]}")
+    acc = nka_amd.nka().init(n, m, flavor=flavor).set_sum_order(sums)
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)
     calls = [0, 0]
@@ -91,6 +95,8 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
                 assert calls[0] == calls[1], (key, step, calls)
                 P.record(0.0, 0.0, key)
             elif np.linalg.norm(x) > 0:
+                if same_bits:
+                    assert np.array_equal(ft.cpu().numpy(), f), (key, step, float(np.abs(ft.cpu().numpy() - f).max()))
                 P.check(S.rel_err(ft.cpu().numpy(), f, x), acc.state(), key, where=step, spread=spread.value,
                 truth=spread.truth(ft.cpu().numpy(), x), stop=strict)
             else:
