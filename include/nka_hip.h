@@ -154,13 +154,15 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *       <w1',w_k>, <f,w_k>, <f,w1'> on the ROUNDED w1' = d/s, element after element, one rounding per product and per
  *       addition -- on one workgroup.  Everything else of an update being bit-exact given its sums, accel_update then
  *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
- *       does) at ANY n: a validation mode for callers moving over from the reference (n sequential additions per
- *       sum: about 4 ms per update at n = 1e6).  Single rank only (a sharded update would need the global norm before
- *       the Gram row: a second exchange): accel_update returns NKA_HIP_ESTATE with an all-reduce installed.
+ *       does) at ANY n: a validation mode for callers moving over from the reference.  Cost: two chains of n dependent
+ *       additions per update -- on par with the fast passes up to n = 64, +15-20 us at n = 512, 0.4 ms at n = 1e4,
+ *       45 ms at n = 1e6 (profiles/r04/sum_order_cost.txt).  Single rank only (a sharded update would need the global
+ *       norm before the Gram row: a second exchange): accel_update returns NKA_HIP_ESTATE with an all-reduce installed.
  *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
- *   NKA_HIP_SUMS_AUTO (default)   reference order where it is free -- a single rank and a vector of at most one tile of
- *       the fast passes (n <= 512), where it is also faster than they are -- blocked otherwise.
- * A user dot product (nka_hip_set_host_dot) overrides all three.  Can be changed between updates. */
+ *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden
+ *       scenario of the reference among them) -- blocked otherwise.
+ * A user dot product (nka_hip_set_host_dot) overrides all three.  Can be changed between updates.  REFERENCE_ORDER is
+ * offered up to mvec = 250 (NKA_HIP_EINVAL beyond). */
 enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2 };
 int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
 

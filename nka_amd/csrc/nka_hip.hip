@@ -581,6 +581,15 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     }
   }
 
+  {   // the reference-order pass stages whole chunks of every vector in LDS (k_dots_ordered)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dots_ordered), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * (kOrdLdsDoubles + kOrdLdsPad)));
+    if (e != hipSuccess) {
+      delete a;
+      return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(e));
+    }
+  }
+
   // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
   // the slot stride is padded to 256 B so every slot base allows 16-B loads.
   // (A skew of the slots across HBM channels was measured in round 2 and has no
@@ -1069,10 +1078,10 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   return 0;
 }
 
-// Reference-order sums: asked for, or free -- a vector of at most one tile of the blocked kernels on a single rank.
+// Reference-order sums: asked for, or free -- a vector of at most kOrdAutoMax elements on a single rank.
 static bool ordered_sums(const nka_hip_state *a) {
-  if (a->allreduce || a->host_dot) return false;
-  return a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER || (a->sum_order == NKA_HIP_SUMS_AUTO && a->n <= kOrdChunk);
+  if (a->allreduce || a->host_dot || a->mvec > kOrdMaxMvec) return false;
+  return a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER || (a->sum_order == NKA_HIP_SUMS_AUTO && a->n <= kOrdAutoMax);
 }
 
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
@@ -1127,7 +1136,9 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     // every sum in the reference's order on one workgroup: the update returns the reference's bits (k_dots_ordered)
     RoctxRange range("nka:PA dots in the reference's order");
     if (a->pending || older_ub > 0) {
-      hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), 0, s, a->ctl, a->vs, f, mode & kSolveRcp);
+      const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
+      hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
+                         ord_chunk(rows));
       HIP_TRY(hipGetLastError());
     }
     mode |= kSolvePrenorm;
@@ -1537,6 +1548,8 @@ int nka_hip_set_sum_order(nka_hip_t a, int32_t order) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   if (order != NKA_HIP_SUMS_AUTO && order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED)
     return fail(NKA_HIP_EINVAL, "set_sum_order: NKA_HIP_SUMS_AUTO, _REFERENCE_ORDER or _BLOCKED");
+  if (order == NKA_HIP_SUMS_REFERENCE_ORDER && a->mvec > kOrdMaxMvec)
+    return fail(NKA_HIP_EINVAL, "set_sum_order: reference-order sums are offered up to mvec = " + std::to_string(kOrdMaxMvec));
   a->sum_order = order;
   return 0;
 }

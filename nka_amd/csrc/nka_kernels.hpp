@@ -520,97 +520,178 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
 
 // ---- PA in the REFERENCE'S ORDER: every sum of the update as the reference forms it ---------------
 // One workgroup.  The reference's inner products are sequential sums of rounded products (its default dot product:
-// C .c:200-208; `dot_product(x, y)` in F08:216-219, compiled without contraction as oracle/Makefile does), the norm first (F08:267), then -- with w1' = d/s (F08:283; (1/s)*d in the vector flavour,
-// F08V:256) already ROUNDED -- the Gram row <w1',w_k> (F08:286-290) and the projections <f,w_k>, <f,w1'> (F08:371).
-// This kernel forms exactly those: element after element, one rounding per product and per addition (no fma), the
-// normalised w1' staged through LDS in chunks so that every sum sees the same rounded values PB will store.  red[] then
-// holds  [0] sum d^2, [1] <f,w1'>, [2+p] <w1',w_p>, [2+mvec+p] <f,w_p>  -- the scalar step takes [1] and the Gram row as
-// they are (kSolvePrenorm) -- and, the scalar step and PB's statements being bit-exact given their inputs, the update
-// returns THE REFERENCE'S BITS.  Thread 0 sums the norm; thread r owns sum r of the second phase (two each beyond 256).
-// Cost: n sequential additions -- free within one tile of the fast kernels (n <= 512: 5 us, where the blocked PA and its
-// final sums take 13), a validation mode beyond (about 4 ms per update at n = 1e6).  Single rank only: the Gram row
-// needs the GLOBAL norm first, i.e. a second exchange (nka_hip_set_sum_order).
+// C .c:200-208; `dot_product(x, y)` in F08:216-219, compiled without contraction as oracle/Makefile does), the norm first
+// (F08:267), then -- with w1' = d/s (F08:283; (1/s)*d in the vector flavour, F08V:256) already ROUNDED -- the Gram row
+// <w1',w_k> (F08:286-290) and the projections <f,w_k>, <f,w1'> (F08:371).  This kernel forms exactly those: element after
+// element, one rounding per product and per addition (no fma).  A chunk of f, of the normalised w1' and of every older w is
+// staged in LDS by the whole workgroup (coalesced); then thread r walks the chunk for sum r, so that the only serial
+// thing per element is the addition itself.  Rows are `chunk + 1` apart (the lanes of a wavefront read different rows at
+// the same element: an odd stride spreads them over the banks).  red[] then holds  [0] sum d^2, [1] <f,w1'>,
+// [2+p] <w1',w_p>, [2+mvec+p] <f,w_p>  -- the scalar step takes [1] and the Gram row as they are (kSolvePrenorm) -- and,
+// the scalar step and PB's statements being bit-exact given their inputs, the update returns THE REFERENCE'S BITS.
+// Cost: two chains of n dependent additions (the norm, then the sums on w1'), 25-35 ns per element on an otherwise idle
+// MI355X (tools/sum_order_cost.py, profiles/r04/sum_order_cost.txt): on par with the blocked PA and its final sums up to
+// n = 64 (the default there), +15-20 us per update at n = 512, 45 ms per update at n = 1e6.  Single rank only: the Gram row needs the GLOBAL norm
+// first, i.e. a second exchange (nka_hip_set_sum_order).
 constexpr int kOrdThreads = 256;
-constexpr int kOrdChunk = 512;
-static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_dots_ordered(Ctl ctl, Vecs vs, const double *__restrict__ f, int rcp) {
-  __shared__ double sh[kOrdChunk];
+constexpr int kOrdChunkMax = 512;
+constexpr int kOrdMaxMvec = 250;                     // two sums per thread and eight elements per LDS row at least
+constexpr int kOrdAutoMax = 64;                      // NKA_HIP_SUMS_AUTO sums in the reference's order up to this length (where it costs nothing)
+constexpr int kOrdLdsDoubles = 16000;                // 125 KiB of dynamic LDS (one workgroup; 160 KiB per CU on gfx950) ...
+constexpr int kOrdLdsPad = 16;                       // ... plus what ord_sum may read past the last row
+__host__ __device__ inline int ord_chunk(int rows) {
+  int c = kOrdLdsDoubles / (rows < 1 ? 1 : rows) - 1;
+  return c > kOrdChunkMax ? kOrdChunkMax : (c < 8 ? 8 : c);
+}
+__host__ __device__ inline size_t ord_lds_bytes(int rows) {
+  return sizeof(double) * ((size_t)rows * (ord_chunk(rows) + 1) + kOrdLdsPad);
+}
+// a + x[0]*y[0] + x[1]*y[1] + ... in THAT order, one rounding per product and per addition; the LDS reads of the next eight
+// elements are in flight while the eight additions of this batch wait for one another (rows are padded: reading up to
+// seven elements past `len` stays inside the allocation; those products are not added).
+__device__ __forceinline__ double ord_sum(double a, const double *x, const double *y, int len) {
+#pragma clang fp contract(off)      // products and additions stay separate roundings whatever the build's flags
+  double xb[8], yb[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) { xb[u] = x[u]; yb[u] = y[u]; }
+  for (int i0 = 0; i0 < len; i0 += 8) {
+    double xn[8], yn[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { xn[u] = x[i0 + 8 + u]; yn[u] = y[i0 + 8 + u]; }
+    if (i0 + 8 <= len) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) a = a + xb[u] * yb[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u < len) a = a + xb[u] * yb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { xb[u] = xn[u]; yb[u] = yn[u]; }
+  }
+  return a;
+}
+// Chunk [c0, c0+len) of the older w's into LDS rows 2.., sixteen loads in flight per thread.
+__device__ __forceinline__ void ord_load_older(double *sh, int S, const Vecs &vs, const long long *pw, int nolder, int64_t c0, int len) {
+  const int total = nolder * len;
+  for (int k0 = threadIdx.x; k0 < total; k0 += 16 * kOrdThreads) {
+    double v[16];
+    int at[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int k = k0 + u * kOrdThreads;
+      at[u] = -1;
+      if (k < total) {
+        const int p = k / len, i = k - p * len;
+        v[u] = (vs.w + pw[p])[c0 + i];
+        at[u] = (2 + p) * S + i;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (at[u] >= 0) sh[at[u]] = v[u];
+  }
+}
+
+static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_dots_ordered(Ctl ctl, Vecs vs,
+                                                                                              const double *__restrict__ f,
+                                                                                              int rcp, int chunk) {
+  extern __shared__ double ord_sh[];
   __shared__ double sum_dd;
   const int t = threadIdx.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int mvec = ctl.mvec;
   const int64_t n = vs.n;
+  const int S = chunk + 1;                           // row stride in LDS
   const double *w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f;
   const long long *pw = ctl.plan_w();
   double *red = ctl.red();
+  double *row_f = ord_sh, *row_w1 = ord_sh + S;      // rows 2.. : the older w's
+  const bool single = n <= chunk;                    // the whole vectors fit: every global load of the update is issued ONCE
 
-  double s = 0.0;
-  if (pending) {                                     // the norm, F08:266-267
-    double acc = 0.0;
-    for (int64_t c0 = 0; c0 < n; c0 += kOrdChunk) {
-      const int len = (int)(n - c0 < kOrdChunk ? n - c0 : kOrdChunk);
-      for (int i = t; i < len; i += kOrdThreads) sh[i] = w1[c0 + i] - f[c0 + i];
-      __syncthreads();
-      if (t == 0)
-        for (int i = 0; i < len; i++) acc = __dadd_rn(acc, __dmul_rn(sh[i], sh[i]));
-      __syncthreads();
+  // The sums on the ROUNDED w1' wait for the norm, those on f alone do not: they live in DIFFERENT wavefronts, so that the
+  // second kind is summed while thread 0 sums the norm.  Threads 0..127 own the w1' sums  r = t, t + 128  (r = 0: <f,w1'>;
+  // 1 <= r <= nolder: <w1',w_(r-1)>), threads 128..255 the sums on f  p = t - 128, t  (<f,w_p>, p < nolder).
+  double acc[2] = {0.0, 0.0};
+  const double *xr[2] = {row_f, row_f}, *yr[2] = {row_f, row_f};
+  int dst[2] = {-1, -1};                             // where the sum goes in red[]
+  const bool on_w1 = t < kOrdThreads / 2;
+  for (int q = 0; q < 2; q++) {
+    if (on_w1) {
+      const int r = t + q * (kOrdThreads / 2);
+      if (r > nolder) continue;
+      if (r == 0) { xr[q] = row_f; yr[q] = row_w1; dst[q] = 1; }
+      else { xr[q] = row_w1; yr[q] = ord_sh + (size_t)(2 + (r - 1)) * S; dst[q] = 2 + (r - 1); }
+    } else {
+      const int p = (t - kOrdThreads / 2) + q * (kOrdThreads / 2);
+      if (p >= nolder) continue;
+      xr[q] = row_f; yr[q] = ord_sh + (size_t)(2 + p) * S; dst[q] = 2 + mvec + p;
     }
-    if (t == 0) sum_dd = acc;
+  }
+
+  // ---- first pass: the norm (F08:266-267); with everything resident also the sums on f alone, on the other threads ----
+  double s = 0.0;
+  {
+    double dd = 0.0;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+      const int len = (int)(n - c0 < chunk ? n - c0 : chunk);
+      if (!pending && !single) break;
+      for (int i = t; i < len; i += kOrdThreads) {
+        const double fi = f[c0 + i];
+        row_f[i] = fi;
+        row_w1[i] = w1[c0 + i] - fi;                 // d (F08:266; (-1)*f + w1 in F08V:237: same bits)
+      }
+      if (single) ord_load_older(ord_sh, S, vs, pw, nolder, c0, len);
+      __syncthreads();
+      if (t == 0 && pending) dd = ord_sum(dd, row_w1, row_w1, len);
+      if (single && !on_w1)
+        for (int q = 0; q < 2; q++)
+          if (dst[q] >= 0) acc[q] = ord_sum(acc[q], xr[q], yr[q], len);
+      if (!single) __syncthreads();
+    }
+    if (t == 0) sum_dd = dd;
     __syncthreads();
-    s = sqrt(sum_dd);
+    if (pending) s = sqrt(sum_dd);
   }
   const bool normed = pending && s != 0.0;           // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
   const double rs = 1.0 / s;
-  // second phase: sum r of  [<f,w1'>,] <w1',w_p> (p < nolder), <f,w_p> (p < nolder)
-  const int first_rows = normed ? 1 + nolder : 0;    // sums that involve w1'
-  const int nsum = first_rows + nolder;
-  double acc[2] = {0.0, 0.0};
-  const double *yv[2] = {f, f};
-  bool x_is_f[2] = {true, true}, y_is_w1[2] = {false, false}, live[2] = {false, false};
-  for (int q = 0; q < 2; q++) {
-    const int r = t + q * kOrdThreads;
-    if (r >= nsum) continue;
-    live[q] = true;
-    if (r < first_rows) {
-      if (r == 0) { x_is_f[q] = true; y_is_w1[q] = true; }                       // <f,w1'>
-      else { x_is_f[q] = false; yv[q] = vs.w + pw[r - 1]; }                      // <w1',w_p>
-    } else {
-      yv[q] = vs.w + pw[r - first_rows];                                         // <f,w_p>
-    }
-  }
-  for (int64_t c0 = 0; c0 < n; c0 += kOrdChunk) {
-    const int len = (int)(n - c0 < kOrdChunk ? n - c0 : kOrdChunk);
+
+  // ---- second pass: the sums on the ROUNDED w1' (and, if the vectors did not fit, those on f alone) ----
+  if (single) {
     if (normed) {
+      for (int i = t; i < (int)n; i += kOrdThreads) row_w1[i] = rcp ? rs * row_w1[i] : row_w1[i] / s;   // the value PB stores as w1'
+      __syncthreads();
+      if (on_w1)
+        for (int q = 0; q < 2; q++)
+          if (dst[q] >= 0) acc[q] = ord_sum(acc[q], xr[q], yr[q], (int)n);
+    }
+  } else {
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+      const int len = (int)(n - c0 < chunk ? n - c0 : chunk);
       for (int i = t; i < len; i += kOrdThreads) {
-        const double d = w1[c0 + i] - f[c0 + i];
-        sh[i] = rcp ? __dmul_rn(rs, d) : d / s;      // the value PB stores as w1'
+        const double fi = f[c0 + i];
+        row_f[i] = fi;
+        if (normed) {
+          const double d = w1[c0 + i] - fi;
+          row_w1[i] = rcp ? rs * d : d / s;          // the value PB stores as w1'
+        }
       }
+      ord_load_older(ord_sh, S, vs, pw, nolder, c0, len);
+      __syncthreads();
+      if (normed || !on_w1)
+        for (int q = 0; q < 2; q++)
+          if (dst[q] >= 0) acc[q] = ord_sum(acc[q], xr[q], yr[q], len);
+      __syncthreads();
     }
-    __syncthreads();
-    for (int q = 0; q < 2; q++) {
-      if (!live[q]) continue;
-      const double *y = yv[q] + c0;
-      double a = acc[q];
-      if (x_is_f[q] && y_is_w1[q])
-        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(f[c0 + i], sh[i]));
-      else if (x_is_f[q])
-        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(f[c0 + i], y[i]));
-      else
-        for (int i = 0; i < len; i++) a = __dadd_rn(a, __dmul_rn(sh[i], y[i]));
-      acc[q] = a;
-    }
-    __syncthreads();
   }
   // red[]: zero what this update does not cover (nothing stale reaches a later reader), then the sums
+  __syncthreads();
   for (int i = t; i < 2 + 2 * mvec; i += kOrdThreads) red[i] = 0.0;
   __syncthreads();
   if (t == 0 && pending) red[0] = sum_dd;
-  for (int q = 0; q < 2; q++) {
-    if (!live[q]) continue;
-    const int r = t + q * kOrdThreads;
-    if (r < first_rows) red[r == 0 ? 1 : 2 + (r - 1)] = acc[q];
-    else red[2 + mvec + (r - first_rows)] = acc[q];
-  }
+  for (int q = 0; q < 2; q++)
+    if (dst[q] >= 0 && (normed || !on_w1)) red[dst[q]] = acc[q];
 }
 
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------

@@ -249,7 +249,7 @@ contains
   !! How the inner products are summed (nka_hip_set_sum_order, include/nka_hip.h): NKA_HIP_SUMS_REFERENCE_ORDER = every sum
   !! as the reference forms it (an update then returns the reference's bits at any n; single rank; slow beyond a few
   !! thousand elements), NKA_HIP_SUMS_BLOCKED = the fast passes at every n, NKA_HIP_SUMS_AUTO (default) = reference order
-  !! within one tile (n <= 512).
+  !! where it costs nothing (n <= 64).
   subroutine set_sum_order(this, order)
     class(nka), intent(inout) :: this
     integer, intent(in) :: order

@@ -297,7 +297,7 @@ class nka:  # noqa: N801  (the reference's type name)
     def set_sum_order(self, order: int):
         """How the inner products are summed (nka_hip_set_sum_order): SUMS_REFERENCE_ORDER = every sum as the reference forms
         it, so that an update returns the reference's bits at any n (single rank; slow beyond a few thousand elements);
-        SUMS_BLOCKED = the fast passes at every n; SUMS_AUTO (default) = reference order within one tile (n <= 512)."""
+        SUMS_BLOCKED = the fast passes at every n; SUMS_AUTO (default) = reference order where it costs nothing (n <= 64)."""
         _check(self._L.nka_hip_set_sum_order(self._handle(), int(order)), "set_sum_order", self._L)
         return self
 

@@ -39,9 +39,9 @@ def torch_cuda():
 
 
 def make_acc(n, m, flavor=0, sums=None):
-    """This file holds the FAST passes to their bars at every n (blocked, fused sums; raw-sum Gram row), also within one
-    tile, where a single-rank accelerator would sum in the reference's order by itself (nka_hip_set_sum_order; a sharded
-    one keeps the fast passes there).  Reference-order sums have their own file: tests/test_hip_reference_order.py."""
+    """This file holds the FAST passes to their bars at every n (blocked, fused sums; raw-sum Gram row), also up to 64
+    elements, where a single-rank accelerator would sum in the reference's order by itself (nka_hip_set_sum_order; a
+    sharded one keeps the fast passes there).  Reference-order sums have their own file: tests/test_hip_reference_order.py."""
     import nka_amd
     return nka_amd.nka().init(n, m, flavor=flavor).set_sum_order(nka_amd.SUMS_BLOCKED if sums is None else sums)
 

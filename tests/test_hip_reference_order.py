@@ -1,9 +1,9 @@
 """Reference-order sums (nka_hip_set_sum_order, k_dots_ordered): with every inner product of an update summed exactly as
 the reference sums it -- the norm first, then the Gram row and the projections on the ROUNDED w1' = d/s, element after
 element, one rounding per product and per addition -- the scalar step and PB's statements being bit-exact given their
-inputs, nka_hip_accel_update returns THE REFERENCE'S BITS.  By default (NKA_HIP_SUMS_AUTO) that holds for every vector of
-at most one tile (n <= 512) on a single rank -- every golden scenario of the compiled reference among them --, on request
-(NKA_HIP_SUMS_REFERENCE_ORDER) at any n.  All comparisons here are np.array_equal: no tolerance anywhere."""
+inputs, nka_hip_accel_update returns THE REFERENCE'S BITS.  By default (NKA_HIP_SUMS_AUTO) that holds where it costs nothing:
+for every vector of at most 64 elements on a single rank -- every golden scenario of the compiled reference among them --,
+on request (NKA_HIP_SUMS_REFERENCE_ORDER) at any n.  All comparisons here are np.array_equal: no tolerance anywhere."""
 import os
 
 import numpy as np
@@ -44,7 +44,7 @@ def test_every_golden_scenario_of_the_compiled_reference_bit_for_bit(torch_cuda,
     if key not in g.files:
         pytest.skip("fixture has no output for this flavour")
     n, m = int(g["n"]), int(g["mvec"])
-    assert n <= 512
+    assert n <= 64
     acc = nka_amd.nka().init(n, m, flavor=flavor)                     # NKA_HIP_SUMS_AUTO
     states = []
     outs, trace = S.replay(acc, g, update=lambda a, f: _update(torch_cuda, a, f), after_update=lambda u, a: states.append(a.state()))
@@ -92,8 +92,8 @@ def _lockstep(torch, oracle, n, m, flavor, order, calls=30, seed=0, swap_every=0
 
 
 @pytest.mark.parametrize("flavor", [0, 1, 2])
-@pytest.mark.parametrize("n,m", [(1, 2), (2, 5), (7, 8), (64, 6), (255, 20), (512, 9), (512, 40)])
-def test_within_one_tile_the_default_path_returns_the_reference_bits(torch_cuda, oracle, flavor, n, m):
+@pytest.mark.parametrize("n,m", [(1, 2), (2, 5), (7, 8), (33, 40), (64, 6), (64, 20)])
+def test_up_to_64_elements_the_default_path_returns_the_reference_bits(torch_cuda, oracle, flavor, n, m):
     """Random call sequences with dependent and repeated inputs, relax, set_vec_tol, restart, lists beyond one launch of
     the fast passes (m = 40): the oracle's flavour (pinned to its compiled reference bit for bit) and the device agree in
     every bit of every output and of the factor, in place and out of place."""
@@ -101,30 +101,29 @@ def test_within_one_tile_the_default_path_returns_the_reference_bits(torch_cuda,
 
 
 @pytest.mark.parametrize("flavor", [0, 1, 2])
-@pytest.mark.parametrize("n,m", [(513, 4), (4099, 10), (20011, 20), (100003, 6)])
+@pytest.mark.parametrize("n,m", [(65, 3), (255, 20), (512, 9), (512, 40), (513, 4), (4099, 10), (20011, 20), (100003, 6), (3001, 140)])
 def test_on_request_the_reference_bits_at_any_length(torch_cuda, oracle, flavor, n, m):
     import nka_amd
     _lockstep(torch_cuda, oracle, n, m, flavor, nka_amd.SUMS_REFERENCE_ORDER, calls=26, swap_every=4)
 
 
 def test_medium_fixture_of_the_compiled_f08_reference_bit_for_bit(torch_cuda):
-    """n = 1e5, m = 10, 25 calls: the samples, the norm and the probe functional of the compiled src-F08 reference's
-    outputs (tests/golden/medium_n100000_m10.npz) -- equal, not close."""
+    """n = 1e5, m = 10, 25 calls: the sampled entries of the compiled src-F08 reference's outputs
+    (tests/golden/medium_n100000_m10.npz) -- equal, not close.  (The fixture's norm and probe functional were formed by
+    the generating script's BLAS: sums again, in yet another order; they are held to the stated tolerance elsewhere.)"""
     import nka_amd
     g = np.load(os.path.join(S.GOLD, "medium_n100000_m10.npz"))
     n, m, calls = int(g["n"]), int(g["mvec"]), int(g["calls"])
     rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
     acc = nka_amd.nka().init(n, m, flavor=nka_amd.FLAVOR_F08).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
-    probe = np.cos(np.arange(n) * 0.001)
     for t in range(calls):
         f = rng.random(n) * 2.0 - 1.0
         out = _update(torch_cuda, acc, f)
         assert acc.num_vec() == g["num_vec"][t]
         assert np.array_equal(out[g["idx"]], g["out_samples"][t]), t
-        assert float(np.linalg.norm(out)) == float(g["out_norm"][t]) and float(out @ probe) == float(g["out_probe"][t]), t
 
 
-def test_auto_is_blocked_beyond_one_tile_and_for_sharded_accelerators(torch_cuda, oracle):
+def test_auto_is_blocked_beyond_64_elements_and_for_sharded_accelerators(torch_cuda, oracle):
     """What NKA_HIP_SUMS_AUTO chooses shows in red[1]: <f,d> (raw, blocked) or <f,w1'> (reference order)."""
     import nka_amd
     rng = np.random.default_rng(9)
@@ -139,9 +138,9 @@ def test_auto_is_blocked_beyond_one_tile_and_for_sharded_accelerators(torch_cuda
         assert min(abs(red[1] - raw), abs(red[1] - normed)) <= 1e-12 * abs(raw) + 1e-13
         return abs(red[1] - raw) < abs(red[1] - normed)
 
-    assert not red1_is_raw(nka_amd.nka().init(512, 3), 512)
-    assert red1_is_raw(nka_amd.nka().init(513, 3), 513)
-    assert red1_is_raw(nka_amd.nka().init(512, 3).set_sum_order(nka_amd.SUMS_BLOCKED), 512)
+    assert not red1_is_raw(nka_amd.nka().init(64, 3), 64)
+    assert red1_is_raw(nka_amd.nka().init(65, 3), 65)
+    assert red1_is_raw(nka_amd.nka().init(64, 3).set_sum_order(nka_amd.SUMS_BLOCKED), 64)
     assert not red1_is_raw(nka_amd.nka().init(3001, 3).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER), 3001)
     sharded = nka_amd.nka().init(64, 3)
     sharded.set_dot_prod(lambda ptr, count, stream: None)          # "a global sum": the accelerator is one slice of many

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""What reference-order sums cost (nka_hip_set_sum_order): microseconds per update, blocked passes against
+k_dots_ordered, full subspace, wall clock over a run of back-to-back updates with one synchronisation at the end.
+  tools/sum_order_cost.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import nka_amd  # noqa: E402
+from nka_amd import synth  # noqa: E402
+
+
+def us_per_update(n, m, order, reps):
+    acc = nka_amd.nka().init(n, m).set_sum_order(order)
+    fs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(8)]
+    for j, f in enumerate(fs):
+        synth.fill_torch(f, 4321, j, 0, n)
+    for t in range(m + 4):
+        acc.accel_update(fs[t % 8].clone())
+    work = [f.clone() for f in fs]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        acc.accel_update(work[r % 8])
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / reps
+
+
+print(f"{'n':>9s} {'mvec':>5s} {'blocked us':>11s} {'reference-order us':>19s}")
+for n, m, reps in ((64, 5, 2000), (64, 20, 2000), (512, 5, 2000), (512, 20, 2000), (512, 40, 1000), (4096, 20, 500), (10**4, 20, 300),
+                   (10**5, 20, 100), (10**6, 20, 20)):
+    b = us_per_update(n, m, nka_amd.SUMS_BLOCKED, reps)
+    r = us_per_update(n, m, nka_amd.SUMS_REFERENCE_ORDER, max(5, reps // (1 if n <= 4096 else 4)))
+    print(f"{n:9d} {m:5d} {b:11.1f} {r:19.1f}", flush=True)
