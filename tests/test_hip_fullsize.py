@@ -143,7 +143,8 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
     """n = 2e7, m = 20, independent uniform(-1,1) inputs from the bench's generator
     (every element different) with a dependent vector every 9th call: the HIP
     path in its F08 rounding AND in the bench's headline C/compact rounding
-    against the reference's own src-F08 module on the same inputs."""
+    against the reference's own src-F08 module on the same inputs -- within the stated tolerance with the fast passes,
+    and EQUAL IN EVERY BIT with the sums formed in the reference's order."""
     import nka_amd
     from nka_amd import synth
     torch = torch_cuda
@@ -152,6 +153,9 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
     exact = oracle.OracleExact(n, m)             # the same calls in extended precision: the truth (13 GB of host memory)
     err_ref = 0.0
     accs = {0: nka_amd.nka().init(n, m, flavor=0), 2: nka_amd.nka().init(n, m, flavor=2)}
+    # ... and a third accelerator that forms its sums in the reference's order (nka_hip_set_sum_order: ~1 s per update at
+    # this length): its output must be the compiled reference's, BIT FOR BIT, on every one of the 27 calls
+    same = nka_amd.nka().init(n, m, flavor=0).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
     basis = [synth.fill_numpy(77, j, 0, n, n) for j in range(3)]
     dev = torch.empty(n, dtype=torch.float64, device="cuda")
     worst = {0: 0.0, 2: 0.0}
@@ -179,11 +183,15 @@ def test_non_periodic_full_size_against_the_compiled_fortran_reference(torch_cud
             P.check(err, acc.state(), f"non-periodic n=2e7 m=20 flavor {flavor} vs compiled src-F08", base=TOL_FULL, where=t,
                     spread=0.0, truth=(float(torch.linalg.vector_norm(dev - fex)) / nx, err_ref))
             worst[flavor] = max(worst[flavor], err)
+        dev.copy_(xin)
+        same.accel_update(dev)
+        assert torch.equal(dev, fref), ("reference-order sums", t, float((dev - fref).abs().max()))
         del xin, fref, fex
     assert ref.num_vec() == m
-    for acc in accs.values():
+    for acc in list(accs.values()) + [same]:
         assert acc.defined()
-    print(f"non-periodic n={n} m={m}: worst rel err vs compiled src-F08 reference: F08 rounding {worst[0]:.2e}, "
+    print(f"non-periodic n={n} m={m}: reference-order sums bit-identical to the compiled src-F08 reference on all {calls} calls; "
+          f"worst rel err vs compiled src-F08 reference: F08 rounding {worst[0]:.2e}, "
           f"C/compact rounding {worst[2]:.2e}")
 
 
