@@ -42,6 +42,7 @@ module nka_type
   public :: nka_init, nka_delete, nka_set_vec_tol, nka_defined
   public :: nka_vec_len, nka_num_vec, nka_max_vec, nka_vec_tol, nka_real_kind
   public :: nka_accel_update, nka_accel_update_dev, nka_relax, nka_restart, nka_set_allreduce
+  public :: nka_set_sum_order, NKA_HIP_SUMS_AUTO, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED
 
 contains
 
@@ -64,6 +65,14 @@ contains
     type(nka), intent(inout) :: this
     real(r8), intent(in) :: vtol
     call nka_hip_check(nka_hip_set_vec_tol(this%handle, vtol), 'nka_set_vec_tol')
+  end subroutine
+
+  !! Beside the reference's API: how the inner products are summed (nka_hip_set_sum_order, include/nka_hip.h).
+  !! NKA_HIP_SUMS_REFERENCE_ORDER: every sum as the reference forms it -- an update then returns the reference's bits at any n.
+  subroutine nka_set_sum_order(this, order)
+    type(nka), intent(inout) :: this
+    integer, intent(in) :: order
+    call nka_hip_check(nka_hip_set_sum_order(this%handle, int(order, c_int32_t)), 'nka_set_sum_order')
   end subroutine
 
   subroutine nka_set_allreduce(this, fn, ctx)
