@@ -30,8 +30,11 @@ def us_per_update(n, m, order, reps):
 
 
 print(f"{'n':>9s} {'mvec':>5s} {'blocked us':>11s} {'reference-order us':>19s}")
-for n, m, reps in ((64, 5, 2000), (64, 20, 2000), (512, 5, 2000), (512, 20, 2000), (512, 40, 1000), (4096, 20, 500), (10**4, 20, 300),
-                   (10**5, 20, 100), (10**6, 20, 20)):
+CASES = ((64, 5, 2000), (64, 20, 2000), (512, 5, 2000), (512, 20, 2000), (512, 40, 1000), (4096, 20, 500), (10**4, 20, 300),
+         (10**5, 20, 100), (10**6, 20, 20))
+if len(sys.argv) > 1:                      # tools/sum_order_cost.py N MVEC REPS   (one case, e.g. under rocprofv3)
+    CASES = ((int(float(sys.argv[1])), int(sys.argv[2]), int(sys.argv[3])),)
+for n, m, reps in CASES:
     b = us_per_update(n, m, nka_amd.SUMS_BLOCKED, reps)
     r = us_per_update(n, m, nka_amd.SUMS_REFERENCE_ORDER, max(5, reps // (1 if n <= 4096 else 4)))
     print(f"{n:9d} {m:5d} {b:11.1f} {r:19.1f}", flush=True)
