@@ -1,3 +1,5 @@
+# round-4: two trees timed alternately on one box.  Needs the other tree beside this one, built:
+#   git worktree add _r03 f3841c3 && make -C _r03/nka_amd/csrc -j6   (and `git worktree remove --force _r03` afterwards)
 mkdir -p gpurun_out
 for rep in 1 2 3; do
   for tree in . _r03; do
