@@ -155,8 +155,8 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *       addition -- on one workgroup.  Everything else of an update being bit-exact given its sums, accel_update then
  *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
  *       does) at ANY n: a validation mode for callers moving over from the reference.  Cost: two chains of n dependent
- *       additions per update -- on par with the fast passes up to n = 64, +15-20 us at n = 512, 0.4 ms at n = 1e4,
- *       45 ms at n = 1e6 (profiles/r04/sum_order_cost.txt).  Single rank only (a sharded update would need the global
+ *       additions per update -- on par with the fast passes up to n = 64, +12-18 us at n = 512, 0.4 ms at n = 1e4,
+ *       40 ms at n = 1e6 (profiles/r04/sum_order_cost.txt).  Single rank only (a sharded update would need the global
  *       norm before the Gram row: a second exchange): accel_update returns NKA_HIP_ESTATE with an all-reduce installed.
  *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
  *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden

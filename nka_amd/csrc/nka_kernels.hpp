@@ -529,9 +529,9 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
 // the same element: an odd stride spreads them over the banks).  red[] then holds  [0] sum d^2, [1] <f,w1'>,
 // [2+p] <w1',w_p>, [2+mvec+p] <f,w_p>  -- the scalar step takes [1] and the Gram row as they are (kSolvePrenorm) -- and,
 // the scalar step and PB's statements being bit-exact given their inputs, the update returns THE REFERENCE'S BITS.
-// Cost: two chains of n dependent additions (the norm, then the sums on w1'), 25-35 ns per element on an otherwise idle
+// Cost: two chains of n dependent additions (the norm, then the sums on w1'), 20-30 ns per element on an otherwise idle
 // MI355X (tools/sum_order_cost.py, profiles/r04/sum_order_cost.txt): on par with the blocked PA and its final sums up to
-// n = 64 (the default there), +15-20 us per update at n = 512, 45 ms per update at n = 1e6.  Single rank only: the Gram row needs the GLOBAL norm
+// n = 64 (the default there), +12-18 us per update at n = 512, 40 ms per update at n = 1e6.  Single rank only: the Gram row needs the GLOBAL norm
 // first, i.e. a second exchange (nka_hip_set_sum_order).
 constexpr int kOrdThreads = 256;
 constexpr int kOrdChunkMax = 512;
@@ -571,25 +571,27 @@ __device__ __forceinline__ double ord_sum(double a, const double *x, const doubl
   }
   return a;
 }
-// Chunk [c0, c0+len) of the older w's into LDS rows 2.., sixteen loads in flight per thread.
+// Chunk [c0, c0+len) of the older w's into LDS rows 2..: eight rows at a time, two elements of each row per thread (a chunk
+// has at most 512 elements): sixteen loads in flight per thread, the row addresses uniform (scalar loads of the plan).
 __device__ __forceinline__ void ord_load_older(double *sh, int S, const Vecs &vs, const long long *pw, int nolder, int64_t c0, int len) {
-  const int total = nolder * len;
-  for (int k0 = threadIdx.x; k0 < total; k0 += 16 * kOrdThreads) {
-    double v[16];
-    int at[16];
+  const int i0 = threadIdx.x, i1 = threadIdx.x + kOrdThreads;
+  static_assert(kOrdChunkMax <= 2 * kOrdThreads, "two elements of a row per thread cover a chunk");
+  for (int p0 = 0; p0 < nolder; p0 += 8) {
+    double v0[8], v1[8];
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int k = k0 + u * kOrdThreads;
-      at[u] = -1;
-      if (k < total) {
-        const int p = k / len, i = k - p * len;
-        v[u] = (vs.w + pw[p])[c0 + i];
-        at[u] = (2 + p) * S + i;
-      }
+    for (int u = 0; u < 8; u++) {
+      const int p = p0 + u < nolder ? p0 + u : nolder - 1;      // (the last group repeats a row: the loads stay unconditional)
+      const double *wp = vs.w + pw[p] + c0;
+      v0[u] = i0 < len ? wp[i0] : 0.0;
+      v1[u] = i1 < len ? wp[i1] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (at[u] >= 0) sh[at[u]] = v[u];
+    for (int u = 0; u < 8; u++) {
+      if (p0 + u >= nolder) continue;
+      double *dst = sh + (size_t)(2 + p0 + u) * S;
+      if (i0 < len) dst[i0] = v0[u];
+      if (i1 < len) dst[i1] = v1[u];
+    }
   }
 }
 
