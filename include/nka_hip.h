@@ -430,6 +430,18 @@ int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, c
  * nka_hip_vec_allreduce_now runs the installed hooks once on `count` host values
  * (count <= 50), so that a launcher can prove the communicator before the first update. */
 typedef int (*nka_hip_host_allreduce_fn)(void *ctx, double *host_vals, int32_t count);
+/* Sums of the vector hooks in the REFERENCE'S ORDER (the abstract-vector counterpart of nka_hip_set_sum_order).  With
+ * NKA_HIP_SUMS_REFERENCE_ORDER nka_hip_vec_dot -- and nka_hip_vec_norm2, which is its square root -- sums element after
+ * element, one rounding per product and per addition, as `sum(x*y)` over the elements does
+ * (/root/reference/src-F08-vector/grid_vector_type.F90:170-197); the batched and stage reductions of this library sum in
+ * blocks and return NKA_HIP_ESTATE then: a vector type that honours the switch (hip_block_vector, hip_grid_vector) runs
+ * the default bodies of the batched / stage hooks, i.e. the reference's own sequence of deferred hook calls
+ * (vector_class.F90), and the vector flavour of the accelerator returns the bits of the reference on the same vector
+ * type.  Works with the parallel-aware reductions too (ordered partial sums per rank, summed by the hook -- the
+ * reference's own parallel contract).  n sequential additions per dot product: a validation mode.
+ * NKA_HIP_SUMS_BLOCKED (= _AUTO, the default): the fast reductions. */
+int nka_hip_vec_set_sum_order(nka_hip_vec_ws_t ws, int32_t order);
+int nka_hip_vec_get_sum_order(nka_hip_vec_ws_t ws);      /* NKA_HIP_SUMS_REFERENCE_ORDER or NKA_HIP_SUMS_BLOCKED; <0 on error */
 int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx);
 int nka_hip_vec_set_host_allreduce(nka_hip_vec_ws_t ws, nka_hip_host_allreduce_fn fn, void *ctx);
 int nka_hip_vec_comm_init_rank(nka_hip_vec_ws_t ws, const void *id128, int32_t nranks, int32_t rank);

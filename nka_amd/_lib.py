@@ -90,6 +90,8 @@ SIGNATURES = {
                                                     C.c_double, C.c_int32, C.c_double, C.c_int32]),
     "nka_hip_vec_axpy_many_keep_pend": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, _dp, C.POINTER(C.c_void_p), C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double]),
+    "nka_hip_vec_set_sum_order": (C.c_int, [C.c_void_p, C.c_int32]),
+    "nka_hip_vec_get_sum_order": (C.c_int, [C.c_void_p]),
     "nka_hip_vec_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "nka_hip_vec_set_host_allreduce": (C.c_int, [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]),
     "nka_hip_vec_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),

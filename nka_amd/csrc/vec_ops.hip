@@ -54,6 +54,7 @@ struct nka_hip_vec_ws {
   void *host_allreduce_ctx = nullptr;
   ncclComm_t comm = nullptr;
   double *red_dev = nullptr;      // 2*kManyMax+2 doubles: the sums of one reduction in canonical layout
+  int sum_order = 0;              // nka_hip_vec_set_sum_order: 1 = dot() sums element after element, unfused (k_dot_ordered)
 };
 
 namespace {
@@ -124,6 +125,29 @@ __global__ __launch_bounds__(kBlock) void k_dot(int64_t n, const double *__restr
   if (blockIdx.x == G - 1)
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < n; i += kBlock) acc[0] = fma(x[i], y[i], acc[0]);
   block_reduce_store<1>(acc, partials, G);
+}
+
+// <x,y> in the REFERENCE'S ORDER (nka_hip_vec_set_sum_order): element after element, one rounding per product and per
+// addition -- what `sum(x*y)` / a plain loop over the elements gives (grid_vector_type.F90:170-183; the oracle's default
+// dot product).  One workgroup: chunks of x and y are staged in LDS by all threads, thread 0 walks them (nka::ord_sum: the
+// reads of the next eight elements are in flight while the additions of this batch wait for one another).  The sum lands in
+// partials[0]; the final-sum kernel then adds nothing to it.
+constexpr int kDotOrdChunk = 1024;
+static __global__ __launch_bounds__(kBlock) void k_dot_ordered(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                               double *__restrict__ partials) {
+  __shared__ double sx[kDotOrdChunk + 16], sy[kDotOrdChunk + 16];
+  double acc = 0.0;
+  for (int64_t c0 = 0; c0 < n; c0 += kDotOrdChunk) {
+    const int len = (int)(n - c0 < kDotOrdChunk ? n - c0 : kDotOrdChunk);
+    for (int i = threadIdx.x; i < len; i += kBlock) {
+      sx[i] = x[c0 + i];
+      sy[i] = y[c0 + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) acc = ord_sum(acc, sx, sy, len);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[0] = acc;
 }
 
 // ---- batched hooks: one pass for many dots / many axpys -----------
@@ -1034,8 +1058,10 @@ static int nka_hip_vec_dot_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x
     if (int rc = nka_detail::check_device_span(x, n, "vec_dot: x")) return rc;
     if (int rc = nka_detail::check_device_span(y, n, "vec_dot: y")) return rc;
     const bool v2 = al16(x) && al16(y);
-    g = grid_for(ws, n, v2 ? 2 : 1);
-    if (v2)
+    g = ws->sum_order == 1 ? 1 : grid_for(ws, n, v2 ? 2 : 1);
+    if (ws->sum_order == 1)
+      hipLaunchKernelGGL(k_dot_ordered, dim3(1), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
+    else if (v2)
       hipLaunchKernelGGL((k_dot<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
     else
       hipLaunchKernelGGL((k_dot<1>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
@@ -1058,6 +1084,9 @@ int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *h
 // vals[j] = <x, ys[j]>, j < count: x is read once per group of kManyMax vectors.
 static int nka_hip_vec_dot_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys, int32_t count,
                          double *host_vals) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (!ws || n < 0 || count < 0 || (count > 0 && (!ys || !host_vals))) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   for (int j = 0; j < count; j++) host_vals[j] = 0.0;
   if (count == 0 || (n == 0 && !ws_parallel(ws))) return 0;
@@ -1103,6 +1132,9 @@ int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const 
 static int nka_hip_vec_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
                               const double *const *ys, int32_t count, double *host_vals0, double *host_vals1,
                               double *host_cross) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (!ws || n < 0 || count < 0 || !host_cross || (count > 0 && (!ys || !host_vals0 || !host_vals1)))
     return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_cross = 0.0;
@@ -1231,6 +1263,9 @@ int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const doubl
 // caller applies the update in the next stage, nka_hip_vec_scale_dot_pair_many with pre).
 static int nka_hip_vec_update_norm2_entry(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, int32_t store,
                              double *host_norm) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (!ws || !host_norm || n < 0) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   *host_norm = 0.0;
   if (n == 0 && !ws_parallel(ws)) return 0;
@@ -1273,6 +1308,9 @@ static int scale_dot_pair_many_impl(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 static int nka_hip_vec_scale_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
                                     int32_t pre, double pre_a, const double *f, const double *const *ys, int32_t count,
                                     double *host_vals_w, double *host_vals_f, double *host_cross) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   return scale_dot_pair_many_impl(ws, n, w, v, a, subtract, pre, pre_a, f, ys, count, host_vals_w, host_vals_f, host_cross, 1);
 }
 int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a, int32_t subtract,
@@ -1287,6 +1325,9 @@ int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, d
 static int nka_hip_vec_dot_pair_many_scaled_entry(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
                                      const double *f, const double *const *ys, int32_t count, double *host_vals_w,
                                      double *host_vals_f, double *host_cross) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_dot_pair_many_scaled: more than 24 vectors");
   return scale_dot_pair_many_impl(ws, n, const_cast<double *>(w), const_cast<double *>(w), a, 0, pre, pre_a, f, ys, count,
                                   host_vals_w, host_vals_f, host_cross, 0);
@@ -1305,6 +1346,9 @@ int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const doubl
 static int nka_hip_vec_diff_norm_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
                                         const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
                                         double *host_vals_x, double *host_cross) {
+  if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
+    return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
+                                 "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (!host_dd) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
   if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_diff_norm_dot_pair_many: more than 24 vectors");
   *host_dd = 0.0;
@@ -1455,6 +1499,18 @@ int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, c
 }
 
 // ---- parallel-aware reductions: hooks on the workspace (include/nka_hip.h) ------------------
+int nka_hip_vec_set_sum_order(nka_hip_vec_ws_t ws, int32_t order) {
+  if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
+  if (order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED && order != NKA_HIP_SUMS_AUTO)
+    return nka_detail::set_error(NKA_HIP_EINVAL, "vec_set_sum_order: NKA_HIP_SUMS_REFERENCE_ORDER, _BLOCKED (or _AUTO = blocked)");
+  ws->sum_order = order == NKA_HIP_SUMS_REFERENCE_ORDER ? 1 : 0;
+  return 0;
+}
+int nka_hip_vec_get_sum_order(nka_hip_vec_ws_t ws) {
+  if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
+  return ws->sum_order == 1 ? NKA_HIP_SUMS_REFERENCE_ORDER : NKA_HIP_SUMS_BLOCKED;
+}
+
 int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx) {
   if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
   ws->allreduce = fn;

@@ -45,6 +45,15 @@ module nka_hip_c
       import :: c_int, c_ptr
       type(c_ptr), value :: handle
     end function
+    integer(c_int) function nka_hip_vec_set_sum_order(ws, order) bind(C)
+      import :: c_int, c_ptr, c_int32_t
+      type(c_ptr), value :: ws
+      integer(c_int32_t), value :: order
+    end function
+    integer(c_int) function nka_hip_vec_get_sum_order(ws) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ws
+    end function
     integer(c_int) function nka_hip_set_sum_order(handle, order) bind(C)
       import :: c_int, c_ptr, c_int32_t
       type(c_ptr), value :: handle

@@ -84,6 +84,7 @@ module hip_block_vector_type
   public :: hip_block_vector_workspace
   public :: hip_block_vector_use_rccl, hip_block_vector_set_allreduce, hip_block_vector_set_host_allreduce
   public :: hip_block_vector_allreduce_now
+  public :: hip_block_vector_set_sum_order, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED
 
 contains
 
@@ -309,6 +310,10 @@ contains
     type(c_ptr) :: ptrs(size(idx))
     integer :: j
     if (size(idx) == 0) return
+    if (reference_order(this)) then            ! the reference's own loop of dot() calls, each summed in its order
+      call vector_default_dot_many(this, ys, idx, vals)
+      return
+    end if
     select type (ys)
     class is (hip_block_vector)
       do j = 1, size(idx)
@@ -329,6 +334,10 @@ contains
     real(r8), intent(out) :: vals_this(:), vals_other(:), cross
     type(c_ptr) :: ptrs(max(size(idx),1))
     integer :: j
+    if (reference_order(this)) then
+      call vector_default_dot_pair_many(this, other, ys, idx, vals_this, vals_other, cross)
+      return
+    end if
     select type (other)
     class is (hip_block_vector)
       select type (ys)
@@ -405,6 +414,10 @@ contains
     real(r8) :: s
     s = 0.0_r8
     stored = .false.
+    if (reference_order(this)) then            ! update, then norm2: F08V:237-238 as the reference issues them
+      s = vector_default_update_norm2(this, a, x, stored)
+      return
+    end if
     select type (x)
     class is (hip_block_vector)
       call nka_hip_check(nka_hip_vec_update_norm2(this%ws, this%nred, this%base, a, x%base, 0_c_int32_t, s), &
@@ -432,7 +445,7 @@ contains
     vals_this = 0.0_r8
     vals_x = 0.0_r8
     cross = 0.0_r8
-    fused = size(idx) <= 24 .and. defer_scale_enabled() .and. fuse_norm_enabled()
+    fused = size(idx) <= 24 .and. defer_scale_enabled() .and. fuse_norm_enabled() .and. .not. reference_order(this)
     if (.not. fused) then
       s = update_norm2_fused(this, a, x, stored)
       return
@@ -478,6 +491,10 @@ contains
     if (present(pre_a)) then
       pre = 1
       pa = pre_a
+    end if
+    if (reference_order(this)) then            ! scale v, scale w, the Gram row by dot(): F08V:255-264 as the reference issues them
+      call vector_default_scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled, f_row)
+      return
     end if
     if (present(f_row)) f_row = .true.          ! both inner-product rows come out of the one pass
     select type (v)
@@ -638,6 +655,22 @@ contains
       end select
     end select
     error stop 'incompatible arguments to VECTOR%AXPY_MANY_KEEP'
+  end subroutine
+
+  !! The workspace sums in the reference's order (hip_block_vector_set_sum_order): the reduction-bearing batched / stage
+  !! hooks then run their DEFAULT bodies -- the reference's own sequence of deferred hook calls (vector_class.F90) -- and
+  !! dot() / norm2() sum element after element, so that the accelerator returns the reference's bits.
+  logical function reference_order(this)
+    class(hip_block_vector), intent(in) :: this
+    reference_order = nka_hip_vec_get_sum_order(this%ws) == NKA_HIP_SUMS_REFERENCE_ORDER
+  end function
+
+  !! call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER | NKA_HIP_SUMS_BLOCKED): nka_hip_vec_set_sum_order
+  !! for every vector that shares the workspace (include/nka_hip.h).
+  subroutine hip_block_vector_set_sum_order(ws, order)
+    type(c_ptr), intent(in) :: ws
+    integer, intent(in) :: order
+    call nka_hip_check(nka_hip_vec_set_sum_order(ws, int(order, c_int32_t)), 'vec_set_sum_order')
   end subroutine
 
   !! NKA_HIP_VEC_FUSE_NORM=0: the norm stage stays a pass of its own (test / A/B aid; read once)

@@ -29,6 +29,11 @@ module vector_class
   use, intrinsic :: iso_fortran_env, only: r8 => real64
   implicit none
   private
+  !! The DEFAULT bodies of the reduction-bearing batched / stage hooks under names of their own: a type that overrides
+  !! them can still run the reference's sequence of deferred hook calls on request (hip_block_vector does, when its
+  !! workspace sums in the reference's order) -- Fortran has no way to invoke an overridden binding of an ABSTRACT parent.
+  public :: vector_default_dot_many, vector_default_dot_pair_many, vector_default_update_norm2, &
+            vector_default_scale_dot_pair_many
 
   type, abstract, public :: vector
   contains
@@ -373,6 +378,45 @@ contains
     call ws(keep_in)%copy(this)
     call this%axpy_many(a, xs, idx)
     call xs(keep_out)%copy(this)
+  end subroutine
+
+
+  subroutine vector_default_dot_many(this, ys, idx, vals)
+    class(vector), intent(in) :: this
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals(:)
+    call dot_many(this, ys, idx, vals)
+  end subroutine
+
+  subroutine vector_default_dot_pair_many(this, other, ys, idx, vals_this, vals_other, cross)
+    class(vector), intent(in) :: this, other
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_other(:), cross
+    call dot_pair_many(this, other, ys, idx, vals_this, vals_other, cross)
+  end subroutine
+
+  function vector_default_update_norm2(this, a, x, stored) result(s)
+    class(vector), intent(inout) :: this
+    real(r8), intent(in) :: a
+    class(vector), intent(in) :: x
+    logical, intent(out) :: stored
+    real(r8) :: s
+    s = update_norm2(this, a, x, stored)
+  end function
+
+  subroutine vector_default_scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled, f_row)
+    class(vector), intent(inout) :: this, v
+    real(r8), intent(in) :: a
+    logical, intent(in) :: subtract
+    class(vector), intent(in) :: f
+    class(vector), intent(in) :: ys(:)
+    integer, intent(in) :: idx(:)
+    real(r8), intent(out) :: vals_this(:), vals_f(:), cross
+    real(r8), intent(in), optional :: pre_a
+    logical, intent(out), optional :: scaled, f_row
+    call scale_dot_pair_many(this, v, a, subtract, f, ys, idx, vals_this, vals_f, cross, pre_a, scaled, f_row)
   end subroutine
 
 end module vector_class

@@ -151,6 +151,52 @@ def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45), (2, 4099, 30, 50)])
+def test_abstract_vector_flavour_with_reference_order_sums_returns_the_reference_bits(fortran_build, oracle, tmp_path, nfield,
+                                                                                      nper, mvec, ncalls):
+    """hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER) (driver: compact argument + 10): dot() sums element
+    after element, the reduction-bearing batched / stage hooks run their default bodies -- the reference's own sequence of
+    deferred hook calls -- and the vector flavour of the accelerator returns the oracle's F08-vector outputs BIT FOR BIT."""
+    out = tmp_path / "vecref.bin"
+    p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "check", str(nfield), str(nper),
+                        str(mvec), str(ncalls), str(out), "10"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    n = nfield * nper
+    raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * n + 1)
+    ora = oracle.OracleNKA(n, mvec, oracle.F08_VECTOR)
+    for t in range(ncalls):
+        x, nv, got = raw[t, :n], int(raw[t, n]), raw[t, n + 1:]
+        f = x.copy()
+        ora.accel_update(f)
+        assert nv == ora.num_vec(), (t, nv, ora.num_vec())
+        assert np.array_equal(got, f), (t, float(np.abs(got - f).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,mvec,ncalls", [(7, 5, 3, 14), (50, 50, 6, 24), (33, 17, 20, 45), (1, 1, 2, 6)])
+def test_grid_vector_with_reference_order_sums_equals_the_compiled_reference_on_its_own_grid_vector(fortran_build, oracle, tmp_path,
+                                                                                                    nx, ny, mvec, ncalls):
+    """The same on hip_grid_vector, against the COMPILED reference running its own grid_vector
+    (oracle/_ref/libnka_ref_f08vec.so): the whole (nx+2) x (ny+2) array of every output, ghost ring included, equal in
+    every bit."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnka_ref_f08vec.so")):
+        pytest.skip("the compiled reference is not built (oracle/_ref)")
+    out = tmp_path / "gridref.bin"
+    p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), "checkgrid", str(nx), str(ny),
+                        str(mvec), str(ncalls), str(out), "10"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    ntot = (nx + 2) * (ny + 2)
+    raw = np.fromfile(out, dtype=np.float64).reshape(ncalls, 2 * ntot + 1)
+    ref = oracle.RefF08Vector(nx, ny, mvec)
+    for t in range(ncalls):
+        x, nv, got = raw[t, :ntot], int(raw[t, ntot]), raw[t, ntot + 1:]
+        full = x.copy()
+        ref.accel_update(full)
+        assert nv == ref.num_vec(), (t, nv, ref.num_vec())
+        assert np.array_equal(got, full), (t, float(np.abs(got - full).max()))
+
+
+@pytest.mark.gpu
 def test_fortran_array_bench_runs(fortran_build):
     p = subprocess.run([os.path.join(fortran_build, "nka_bench"), "2000000", "6", "5", "0"],
                        capture_output=True, text=True, timeout=300)
