@@ -166,7 +166,7 @@ def truth_factor(n, mvec=None):
     there: profiles/r04/error_attribution.txt), and the ratio of two draws has a tail -- hence 4.  Beyond the allowance: 25 of
     the 18 916 records; 22 with n <= 9, and the three rank records of ONE sequence beyond one tile (sharded soak seed 3319,
     n = 1660: err_dev 1.05 .. 1.14e-12 against the base of 1e-12; profiles/r04/sharded_seed_3319_replay.txt shows what it
-    is); the later soak of the final tree added one more beyond one tile (abstract-vector flavour, 4 x 257 elements: 3.5 x)
+    is); the later soak of the final tree added two more beyond one tile (abstract-vector flavour, 1 028 and 771 elements: 3.5 x, 3.4 x)
     and, sharded over three ranks, 13 records with at most 5 elements.  The thresholds were not moved for any of them."""
     return TRUTH_FACTOR_TINY if (n is not None and n <= TINY_N) else TRUTH_FACTOR
 
