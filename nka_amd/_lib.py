@@ -147,6 +147,25 @@ def load_diag() -> C.CDLL:
     return _DIAG
 
 
+_EXTRA = {}
+
+
+def load_diag_at(path: str) -> C.CDLL:
+    """Another build of the diagnostic ABI (e.g. libnka_hip_diag_ft.so, `make -C nka_amd/csrc ftemporal`) as one more
+    independent copy of the library in the process: tools/ab_libs.py alternates two builds on the same inputs."""
+    path = os.path.abspath(path)
+    if path not in _EXTRA:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found")
+        L = C.CDLL(path)
+        for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _EXTRA[path] = L
+    return _EXTRA[path]
+
+
 def lib_path() -> str:
     # NKA_HIP_LIB: load another build of the same ABI (kernel tuning experiments)
     return os.environ.get("NKA_HIP_LIB") or os.path.join(HERE, "libnka_hip.so")

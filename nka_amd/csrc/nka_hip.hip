@@ -27,6 +27,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -203,6 +204,15 @@ struct nka_hip_state {
   int64_t swap_seq = 0;       // number of that update
   const double *last_acc = nullptr;   // the accelerated f lent by the last out-of-place update (read only for the caller)
   std::vector<void *> extra_allocs;   // the two spare buffers allocated at the first swap update (freed at destroy)
+  // Who holds which buffer, as far as the HOST can know it: `taken` = every buffer outside the two slot-major
+  // allocations that a table entry may name (callers' buffers handed in, the two extra allocations); `lent` = the free
+  // buffers handed to the caller for its NEXT input (they may lie anywhere, the slot-major allocations included).  A
+  // buffer may enter an update only if the library does not hold it: it is lent, or it is foreign to both.
+  std::set<const double *> taken, lent;
+  bool captured = false;      // the handle's stream was seen capturing: replays re-issue the scalar step with the ARGUMENTS of
+                              // the capture, so from then on it loads the slot -> buffer tables instead of computing them
+  bool poisoned = false;      // a HIP call failed AFTER the scalar step of an update was enqueued: the lists on the device
+                              // are ahead of the vectors; every later call but destroy returns NKA_HIP_ESTATE
   // launch geometry
   int num_cu = 256;
   int bpc[2] = {0, 0};        // blocks per CU of PA, PB; 0 = automatic (see grid_for)
@@ -215,6 +225,7 @@ struct nka_hip_state {
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
+  int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
   bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
                                  // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
@@ -819,6 +830,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
 
 int nka_hip_restart(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (a->poisoned) return fail(NKA_HIP_ESTATE, "restart: an earlier update failed after its scalar step had been enqueued: destroy the handle");
   HIP_TRY(hipSetDevice(a->device));
   hipLaunchKernelGGL(k_restart, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), a->stream,
                      a->ctl, a->state_in_global ? 1 : 0);
@@ -832,6 +844,7 @@ int nka_hip_restart(nka_hip_t a) {
 
 int nka_hip_relax(nka_hip_t a) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (a->poisoned) return fail(NKA_HIP_ESTATE, "relax: an earlier update failed after its scalar step had been enqueued: destroy the handle");
   HIP_TRY(hipSetDevice(a->device));
   hipLaunchKernelGGL(k_relax, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), a->stream,
                      a->ctl, a->state_in_global ? 1 : 0);
@@ -863,7 +876,9 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int nl = a->mvec + 1;
-    const long long id_stride = a->swapped ? 0 : (long long)a->vs.stride, id_vbase = buffer_offset(a, a->vs.v);
+    // (identity tables are COMPUTED from the stride only while no table entry can have changed AND no graph holds this
+    //  launch: a replay re-issues it with the arguments frozen at capture, a later out-of-place update would be invisible)
+    const long long id_stride = (a->swapped || a->captured) ? 0 : (long long)a->vs.stride, id_vbase = buffer_offset(a, a->vs.v);
 #define ROWS(NL) \
   hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v, id_stride, id_vbase)
     if (nl <= 6) ROWS(6);
@@ -1084,6 +1099,19 @@ static bool ordered_sums(const nka_hip_state *a) {
   return a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER || (a->sum_order == NKA_HIP_SUMS_AUTO && a->n <= kOrdAutoMax);
 }
 
+// Does [p, p + n) touch memory the library holds -- the slot-major allocations or a buffer it has taken over -- that it
+// has NOT lent to the caller?  (A handful of buffers: linear scans.)
+static bool held_by_library(const nka_hip_state *a, const double *p) {
+  if (a->lent.count(p)) return false;
+  const int64_t n = std::max<int64_t>(a->n, 1);
+  auto overlaps = [&](const double *q, int64_t len) { return p < q + len && q < p + n; };
+  const int64_t block = a->vs.stride * (int64_t)(a->mvec + 1);
+  if (overlaps(a->vs.w, block) || overlaps(a->vs.v, block)) return true;
+  // every taken buffer holds n doubles: one of them overlaps [p, p + n) iff its base lies in (p - n, p + n)
+  auto it = a->taken.upper_bound(p - n);
+  return it != a->taken.end() && *it < p + n;
+}
+
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
 
 int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, kNoBuffer, kNoBuffer); }
@@ -1098,6 +1126,12 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   if (swap_w == kNoBuffer && f && f == a->last_acc)      // in place on the buffer the last out-of-place update lent for READING
     return fail(NKA_HIP_EINVAL, "accel_update: that buffer is the accelerated f lent by the previous out-of-place update (read only: "
                                 "it is the stored v of the pending pair); copy it, or go on with nka_hip_accel_update_swap");
+  if (a->poisoned)
+    return fail(NKA_HIP_ESTATE, "accel_update: an earlier update of this handle failed after its scalar step had been enqueued "
+                                "(a HIP error): the lists on the device are ahead of the stored vectors.  Destroy the handle");
+  if (a->swapped && f && held_by_library(a, f))
+    return fail(NKA_HIP_EINVAL, "accel_update: that buffer is held by the library (a stored vector, or a buffer handed over to "
+                                "nka_hip_accel_update_swap earlier)");
   if (a->needs_comm)
     return fail(NKA_HIP_ECOMM, "accel_update: this accelerator is a copy of a sharded one and has no all-reduce yet: call "
                                "nka_hip_comm_init_rank or nka_hip_set_allreduce on it first (nka_hip_clone)");
@@ -1112,12 +1146,13 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   const int vec = aligned ? 2 : 1;
   int mode = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? kSolveRcp : 0;
   if (int rc = record(a, 0)) return rc;
-  if (!a->word_off) {
-    // a captured update is replayed with the widths and the update number of the capture: the word can neither
-    // describe the replays nor tighten them (capture_safe() asks for the full width anyway)
+  if (!a->captured) {
+    // a captured update is replayed with the widths, the update number and the kernel ARGUMENTS of the capture: the list
+    // word can neither describe the replays nor tighten them (capture_safe() asks for the full width anyway), and the
+    // scalar step must find the slot -> buffer tables in memory (enqueue_solve)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
-    else if (cs != hipStreamCaptureStatusNone) a->word_off = true;
+    else if (cs != hipStreamCaptureStatusNone) a->captured = a->word_off = true;
   }
   a->list_ub = list_bound_now(a);
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
@@ -1156,6 +1191,13 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   RoctxRange range_tail("nka:solve + PB combine");
   if (!solved)
     if (int rc = enqueue_solve(a, mode, swap_w, swap_v)) return rc;
+  // From here on the scalar step is in the stream: the lists, the factor and (out of place) the tables move on whatever
+  // happens next.  What can still fail is a HIP call (an event record, a launch); the handle is then beyond repair.
+  struct Poison {
+    nka_hip_state *a;
+    bool armed = true;
+    ~Poison() { if (armed) a->poisoned = true; }
+  } poison{a};
   if (int rc = record(a, 2)) return rc;
 
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
@@ -1164,7 +1206,7 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     Ctl &c = a->ctl;
     unsigned long long *const hw = c.hw;
     if (a->word_off) c.hw = nullptr;
-    a->pb_flags = swap_w != kNoBuffer ? (kPbNoStoreW | kPbNoStoreF) : 0;
+    a->pb_flags = (swap_w != kNoBuffer ? (kPbNoStoreW | kPbNoStoreF) : 0) | (a->pb_reverse ? kPbReverse : 0);
     const int rc = enqueue_pb(a, f, vec, comb_ub);
     a->pb_flags = 0;
     c.hw = hw;
@@ -1177,6 +1219,7 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   a->list_ub = comb_ub + 1;
   a->pending = true;
   if (swap_w == kNoBuffer) a->last_acc = nullptr;         // (the loan of the previous out-of-place update has ended)
+  poison.armed = false;
   return 0;
 }
 
@@ -1230,6 +1273,7 @@ static int collect_spares(nka_hip_t a) {
         return fail(NKA_HIP_ENOMEM, std::string("accel_update_swap: hipMalloc of a spare buffer: ") + hipGetErrorString(e));
       }
       a->extra_allocs.push_back(q);
+      a->taken.insert(static_cast<const double *>(q));
       *p = static_cast<double *>(q);
     }
   }
@@ -1252,8 +1296,21 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
   if (in && in == a->last_acc)          // (an empty slice, vlen 0, hands over a null buffer every time)
     return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is the accelerated f lent by the previous update (read only: it "
                                 "is the stored v of the pending pair)");
-  if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;   // (a failed update is not done: the spares stay)
+  if (in && held_by_library(a, in))
+    return fail(NKA_HIP_EINVAL, "accel_update_swap: that buffer is already held by the library (a stored vector, or a buffer "
+                                "handed over earlier): two slots would share it");
+  // (set BEFORE the update: it only makes the scalar step load the tables instead of computing them -- right from the
+  //  moment its launch may have rewritten them, whatever fails behind it.  An update that fails before its scalar step
+  //  is not done and the spares stay; one that fails behind it poisons the handle, update_impl)
   a->swapped = true;
+  if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;
+  if (in) {
+    a->lent.erase(in);
+    const int64_t block = a->vs.stride * (int64_t)(a->mvec + 1);
+    const bool inside = (in >= a->vs.w && in < a->vs.w + block) || (in >= a->vs.v && in < a->vs.v + block);
+    if (!inside) a->taken.insert(in);
+  }
+  if (give_w) a->lent.insert(give_w);
   a->swap_pending = true;
   a->swap_seq = a->seq;
   a->spare_w = a->spare_v = nullptr;
@@ -1616,6 +1673,8 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
     a->pb_tickets = value;
+  } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)
+    a->pb_reverse = value != 0;
   } else if (k == "serial_solve") {
     a->serial_solve = value != 0;
   } else if (k == "list_word") {       // 0: the host's own bound only (the behaviour before round 4), for A/B runs

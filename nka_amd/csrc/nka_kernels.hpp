@@ -43,6 +43,14 @@
 #ifndef NKA_NT_LOADS
 #define NKA_NT_LOADS 1      // streaming reads: non-temporal (nt) loads
 #endif
+#ifndef NKA_F_TEMPORAL
+// != 0 (bit 0: in PA, bit 1: in PB) = the vectors BOTH passes of an update read (f and the raw w of the pending pair: PA reads them, PB reads them again
+// a fraction of a millisecond later) are loaded with the default cache policy instead of nt, in the hope that the 256 MiB
+// Infinity Cache still holds them for PB at shard sizes (n_local <= 1.25e7: 200 MB).  Measured in round 5 (in-process A/B
+// of two builds, tools/ab_libs.py; profiles/r05/ab_mall_reuse.txt) together with PB walking its tiles in the reverse of
+// PA's order (kPbReverse); 0 = every streaming load nt, the product.
+#define NKA_F_TEMPORAL 0
+#endif
 #ifndef NKA_DEAD_SLOT_TILE0
 // A launch wider than the list (the host's bound is one too high in the update that takes a dependence drop, and too high
 // by more for a caller that never synchronises) has DEAD ring slots.  In PB they re-read f: 1 = always its first tile (4 KiB
@@ -286,6 +294,11 @@ template <> __device__ __forceinline__ d2 ld<2>(const double *p) {
   return *reinterpret_cast<const d2 *>(p);
 #endif
 }
+// loads of the vectors that PA and PB both read (see NKA_F_TEMPORAL: bit 0 = in PA, bit 1 = in PB)
+template <int VEC, int PASS_BIT> __device__ __forceinline__ typename VecT<VEC>::type ld_keep(const double *p) {
+  if constexpr ((NKA_F_TEMPORAL & PASS_BIT) != 0) return *reinterpret_cast<const typename VecT<VEC>::type *>(p);
+  else return ld<VEC>(p);
+}
 __device__ __forceinline__ void st(double *p, double x) {
 #if NKA_STORE_POLICY == 1
   __builtin_nontemporal_store(x, p);
@@ -424,8 +437,8 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   int64_t t = blockIdx.x;
   if (t < ntile) {
     const int64_t e = t * (kBlock * VEC) + threadIdx.x * VEC;
-    fv = ld<VEC>(f + e);
-    w1v = ld<VEC>(w1 + e);
+    fv = ld_keep<VEC, 1>(f + e);
+    w1v = ld_keep<VEC, 1>(w1 + e);
 #pragma unroll
     for (int j = 0; j < W; j++) ring[j] = ld<VEC>(wk[j] + (DEAD_OFF(j < nolder, e)));
   }
@@ -443,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
       acc[1] = fma(fq[q], dq[q], acc[1]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    fv = ld<VEC>(f + en);
-    w1v = ld<VEC>(w1 + en);
+    fv = ld_keep<VEC, 1>(f + en);
+    w1v = ld_keep<VEC, 1>(w1 + en);
 #pragma unroll
     for (int j = 0; j < MAXL; j++) {
       const V x = ring[j % W];
@@ -718,7 +731,9 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
 // pending slot, still holding the raw previous f and update -- as
 // w1' = (w1-f)/s, v1' = v1/s formed in registers and stored back.  The last pass
 // stores v_new = f_out.
-enum { kPbNoStoreW = 1, kPbNoStoreF = 2 };   // `flags` of PB in an out-of-place update (nka_hip_accel_update_swap)
+enum { kPbNoStoreW = 1, kPbNoStoreF = 2,     // `flags` of PB in an out-of-place update (nka_hip_accel_update_swap)
+       kPbReverse = 4 };                      // rolling-window PB: walk the tiles from the END of the vectors, i.e. in the
+                                              // reverse of PA's order (diagnostic builds only, see NKA_F_TEMPORAL)
 
 template <int COMB>
 __device__ __forceinline__ double comb1(double x, double c, double w, double v) {
@@ -941,19 +956,25 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 #define DEAD_OFF(live, off) (off)
 #endif
   V finv[T], w0v[T], rw[COMPACT ? 1 : W][T], rv[W][T];
+  // logical tile t -> the elements it covers (kPbReverse: counted from the end; elementwise pass, same bits either way)
+  const bool rev = (flags & kPbReverse) != 0;
+  const int64_t tlast = ntile - 1;
+#define TILE_ELEM(t) (((rev) ? tlast - (t) : (t)) * TILE + lane_off)
+  // pair 0 is the pending pair, whose raw w PA has just read (NKA_F_TEMPORAL): the other ring loads stream
+#define LD_W(j, p) ((j) == 0 ? ld_keep<VEC, 2>(p) : ld<VEC>(p))
   int64_t t = tail_block ? ntile : (int64_t)blockIdx.x;
   if (t < ntile) {
-    const int64_t e = t * TILE + lane_off;
+    const int64_t e = TILE_ELEM(t);
 #pragma unroll
     for (int q = 0; q < T; q++) {
-      finv[q] = ld<VEC>(f + e + q * (kBlock * VEC));
-      if (COMPACT) w0v[q] = ld<VEC>(w0src + e + q * (kBlock * VEC));
+      finv[q] = ld_keep<VEC, 2>(f + e + q * (kBlock * VEC));
+      if (COMPACT) w0v[q] = ld_keep<VEC, 2>(w0src + e + q * (kBlock * VEC));
     }
 #pragma unroll
     for (int j = 0; j < W; j++)
 #pragma unroll
       for (int q = 0; q < T; q++) {
-        if (!COMPACT) rw[j][q] = ld<VEC>(wk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
+        if (!COMPACT) rw[j][q] = LD_W(j, wk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
         rv[j][q] = ld<VEC>(vk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
       }
   }
@@ -965,12 +986,12 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   int64_t tnext = t + G;
   unsigned par = 0;
   while (t < ntile) {
-    const int64_t e = t * TILE + lane_off;
+    const int64_t e = TILE_ELEM(t);
     const bool more = tnext < ntile;
     unsigned claimed = kNoTicket;
     if (tickets && more && threadIdx.x == 0) claimed = ticket_request(my_ticket, ticket_base, (unsigned)ng, grp);
     const int64_t tn = more ? tnext : t;                 // the last iteration prefetches its own tile again
-    const int64_t en = tn * TILE + lane_off;
+    const int64_t en = TILE_ELEM(tn);
     V fin[T], w0[T], x[T];
 #pragma unroll
     for (int q = 0; q < T; q++) {
@@ -982,8 +1003,8 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < T; q++) {
-      finv[q] = ld<VEC>(f + en + q * (kBlock * VEC));
-      if (COMPACT) w0v[q] = ld<VEC>(w0src + en + q * (kBlock * VEC));
+      finv[q] = ld_keep<VEC, 2>(f + en + q * (kBlock * VEC));
+      if (COMPACT) w0v[q] = ld_keep<VEC, 2>(w0src + en + q * (kBlock * VEC));
     }
 #pragma unroll
     for (int j = 0; j < MAXK; j++) {
@@ -997,10 +1018,10 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
 #pragma unroll
       for (int q = 0; q < T; q++) {
         if (j + W < MAXK) {
-          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W] + DEAD_OFF(j + W < ncomb, e) + q * (kBlock * VEC));
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = LD_W(j + W, wk[j + W] + DEAD_OFF(j + W < ncomb, e) + q * (kBlock * VEC));
           rv[j % W][q] = ld<VEC>(vk[j + W] + DEAD_OFF(j + W < ncomb, e) + q * (kBlock * VEC));
         } else {
-          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = ld<VEC>(wk[j + W - MAXK] + DEAD_OFF(j + W - MAXK < ncomb, en) + q * (kBlock * VEC));
+          if (!COMPACT) rw[COMPACT ? 0 : j % W][q] = LD_W(j + W - MAXK, wk[j + W - MAXK] + DEAD_OFF(j + W - MAXK < ncomb, en) + q * (kBlock * VEC));
           rv[j % W][q] = ld<VEC>(vk[j + W - MAXK] + DEAD_OFF(j + W - MAXK < ncomb, en) + q * (kBlock * VEC));
         }
       }
@@ -1069,6 +1090,8 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     }
   }
 #undef DEAD_OFF
+#undef TILE_ELEM
+#undef LD_W
 }
 
 // ---- scalar kernels: list surgery + Cholesky + substitutions on one wavefront ----

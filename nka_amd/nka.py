@@ -56,13 +56,18 @@ class State:
 class nka:  # noqa: N801  (the reference's type name)
     """MI355X accelerator object; see module docstring."""
 
-    def __init__(self, diagnostic: bool = False):
+    def __init__(self, diagnostic: bool = False, lib: str | None = None):
         """diagnostic=True: an object of the diagnostic build (libnka_hip_diag.so: the product plus set_tuning /
         set_grid, include/nka_hip_diag.h) -- for the tests that hold every kernel variant to the same bits and for
         the A/B tools."""
         self._h = None
         self._diag = bool(diagnostic)
-        self._L = _lib.load_diag() if diagnostic else _lib.load()      # raises if the HIP library is missing: no CPU path
+        self._libpath = lib
+        if lib is not None:            # another build of the diagnostic ABI (A/B of compile-time variants, tools/ab_libs.py)
+            self._diag = True
+            self._L = _lib.load_diag_at(lib)
+        else:
+            self._L = _lib.load_diag() if diagnostic else _lib.load()  # raises if the HIP library is missing: no CPU path
         self._cb = None
         self._hd = None
 
@@ -98,7 +103,7 @@ class nka:  # noqa: N801  (the reference's type name)
         factor and tolerance; the two then evolve separately.  Python-level hooks
         (set_dot_prod, set_host_dot) are carried over; the built-in RCCL communicator
         is not (nka_hip_clone)."""
-        other = nka(diagnostic=self._diag)
+        other = nka(diagnostic=self._diag, lib=self._libpath)
         h = C.c_void_p()
         _check(self._L.nka_hip_clone(self._handle(), C.byref(h)), "nka_hip_clone", self._L)
         other._h, other._device, other._vlen, other._mvec = h, self._device, self._vlen, self._mvec

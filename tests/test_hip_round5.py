@@ -1,0 +1,122 @@
+"""GPU tests of round 5: the advisor's findings on the out-of-place entry (a graph captured before the first
+out-of-place update, buffers the library already holds), and the sharded runs of round 5 live in
+tests/test_sharded_ngpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.mark.parametrize("flavor", [0, 2])
+def test_a_graph_captured_before_the_first_out_of_place_update_replays_correctly_after_it(torch_cuda, flavor):
+    """while no out-of-place update has happened, the scalar step COMPUTES the slot -> buffer tables from a
+    kernel argument (the slot stride) instead of loading them.  A capture used to freeze that argument; an eager
+    nka_hip_accel_update_swap afterwards rewrites the tables on the device, and a replay then resolved the stored
+    vectors through stale identity tables -- wrong buffers, NKA_HIP_OK.  Now a launch that is being captured always
+    loads the tables.  capture -> replay -> out-of-place update -> replay, against a twin driven eagerly in place:
+    every output bit and the replicated state."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 100003, 5
+    rng = np.random.default_rng(5 + flavor)
+    X = [rng.standard_normal(n) for _ in range(m + 14)]
+    ref = nka_amd.nka().init(n, m, flavor=flavor)
+    acc = nka_amd.nka().init(n, m, flavor=flavor)
+    side = torch.cuda.Stream()
+    static = torch.empty(n, dtype=torch.float64, device="cuda")
+    it = iter(X)
+
+    def eager_ref(x):
+        t = torch.from_numpy(x.copy()).cuda()
+        ref.accel_update(t)
+        return t
+
+    with torch.cuda.stream(side):
+        for _ in range(m + 3):                            # fill: both in place
+            x = next(it)
+            static.copy_(torch.from_numpy(x))
+            acc.accel_update(static)
+            assert torch.equal(static, eager_ref(x))
+    torch.cuda.synchronize()
+    assert acc.capture_safe()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):                # captured BEFORE any out-of-place update
+        acc.accel_update(static)
+
+    def replay(x):
+        static.copy_(torch.from_numpy(x))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static, eager_ref(x))
+        assert acc.state_digest() == ref.state_digest()
+
+    for _ in range(3):
+        replay(next(it))
+    with torch.cuda.stream(side):                         # an eager OUT-OF-PLACE update: the tables change on the device
+        for _ in range(2):
+            x = next(it)
+            mine = torch.from_numpy(x.copy()).cuda()
+            _, out = acc.accel_update_swap(mine)
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager_ref(x))
+    for _ in range(5):                                    # the replays must resolve every vector through the NEW tables
+        replay(next(it))
+    assert acc.num_vec() == ref.num_vec() == m and acc.defined()
+
+
+def test_out_of_place_entry_refuses_buffers_the_library_holds(torch_cuda):
+    """the out-of-place entry used to check its input only against the two spares and the last lent result.
+    A buffer handed over earlier (now the stored w of a live slot) or an OLDER accelerated f (still the stored v of a
+    live slot) was accepted, and two slots then shared one buffer.  The host now keeps the set of buffers it has taken
+    over and the set it has lent: both entries refuse a held buffer; a lent one is the normal protocol."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 2048, 4
+    a = nka_amd.nka().init(n, m)
+    rng = np.random.default_rng(2)
+    x0 = torch.from_numpy(rng.standard_normal(n)).cuda()
+    x1 = torch.from_numpy(rng.standard_normal(n)).cuda()
+    buf0, acc0 = a.accel_update_swap(x0)                   # x0 is now the stored w of a slot
+    buf1, acc1 = a.accel_update_swap(x1)
+    with pytest.raises(nka_amd.NKAError, match="held by the library"):
+        a.accel_update_swap(x0)                            # handed over earlier
+    with pytest.raises(nka_amd.NKAError, match="held by the library"):
+        a.accel_update_swap(acc0)                          # an older accelerated f: the stored v of a live slot
+    with pytest.raises(nka_amd.NKAError, match="held by the library"):
+        a.accel_update(x0)                                 # the in-place entry would overwrite a stored vector
+    with pytest.raises(nka_amd.NKAError, match="held by the library"):
+        a.accel_update(acc0)                               # ... or one that is being read as a stored v
+    assert a.num_vec() == 1 and a.defined()
+    # the lent buffers are welcome at either entry, in any order, and the arithmetic goes on undisturbed
+    twin = nka_amd.nka().init(n, m)
+    for x in (x0, x1):
+        twin.accel_update(x.clone())
+    for t in range(6):
+        x = torch.from_numpy(rng.standard_normal(n)).cuda()
+        want = x.clone()
+        twin.accel_update(want)
+        lent = buf0 if t % 2 == 0 else buf1
+        lent.copy_(x)
+        if t == 3:
+            a.accel_update(lent)                           # in place on a lent buffer: it stays the caller's
+            got = lent
+        else:
+            nb, got = a.accel_update_swap(lent)
+            if t % 2 == 0:
+                buf0 = nb
+            else:
+                buf1 = nb
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), t
+    assert a.state_digest() == twin.state_digest() and a.defined()
