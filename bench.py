@@ -216,7 +216,7 @@ def config5_abstract_vector(steps: int = 20):
     return out
 
 
-def probe_ceilings(n: int = 10**8, timeout: int = 240):
+def probe_ceilings(n: int = 10**8, timeout: int = 240, device: int | None = None):
     """The repo's own streaming probe (tools/hbm_probe mode `cr`: no arithmetic, random
     data, one block per CU) run as a CHILD process after the timed region, on the same
     box in the same run: what this memory system gives a pure read of 22 streams (PA's
@@ -228,8 +228,12 @@ def probe_ceilings(n: int = 10**8, timeout: int = 240):
     exe = os.path.join(ROOT, "tools", "hbm_probe")
     if not os.path.exists(exe):
         return {"error": "tools/hbm_probe not built"}
+    env = dict(os.environ)
+    if device is not None:        # the child sees only this rank's GPU (N > 1 lines)
+        vis = env.get("HIP_VISIBLE_DEVICES")
+        env["HIP_VISIBLE_DEVICES"] = str(device) if not vis else vis.split(",")[device]
     try:
-        p = subprocess.run([exe, str(n), "0", "cr"], capture_output=True, text=True, timeout=timeout)
+        p = subprocess.run([exe, str(n), "0", "cr"], capture_output=True, text=True, timeout=timeout, env=env)
     except Exception as exc:      # an extra, never the measured path
         return {"error": repr(exc)}
     if p.returncode != 0:
@@ -377,18 +381,51 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
                          "what": "PA + scalar step + PB, first kernel start .. last kernel end"},
         "kernels": kernels,
         "bytes_moved_per_update": moved,
-        "contract_bytes_per_update": b_alg,
-        "contract_bytes_ratio": b_alg / moved,
         "probe_ceiling": probe,
         "device_time_stats_ms": stats,
+        # the same figures once more as FLAT scalars: a record that keeps only the scalar entries of this object (the
+        # driver's `parsed`) still shows both passes, the whole update and the same-run ceiling of the dominant mix
+        "whole_update_frac": (moved / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
+        "whole_update_ms": mean[3],
+        "PA_k_dots_frac": kernels["PA_k_dots"]["frac"], "PA_k_dots_ms": ms["PA_k_dots"],
+        "PB_k_combine_frac": kernels["PB_k_combine"]["frac"], "PB_k_combine_ms": ms["PB_k_combine"],
+        "k_solve_ms": mean[1],
     }
+    if probe and not probe.get("error"):
+        key = "mix_22R_5W_GBps" if flavor == "c" else "mix_42R_5W_GBps"
+        out["probe_ceiling_dominant_mix_GBps"] = probe.get(key)
+        out["probe_ceiling_pure_read_GBps"] = probe.get("pure_read_22_streams_GBps")
     if flavor != "c":
         # SURVEY 8(d)'s B_alg is a lower bound on the traffic only for the flavours that stream BOTH stored vectors of
         # a pair (ratio 1.04): there B_alg / time is the BASELINE.md-style fraction.  Compact storage moves FEWER bytes
-        # than B_alg (ratio 1.45), so no contract rate is printed for it: it would read as > 100 % of the peak.
+        # than B_alg (ratio 1.45): NO contract figure of any kind is printed for it (B_alg / time would read as > 100 % of
+        # the peak); the contract-comparable number of a compact line is roofline.reference_rounding, measured in the same run.
+        out["contract_bytes_per_update"] = b_alg
+        out["contract_bytes_ratio"] = b_alg / moved
         out["contract_GBps"] = (b_alg / upd_s / 1e9) if upd_s > 0 else None
         out["contract_frac_of_peak"] = (b_alg / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None
     return out
+
+
+def reference_rounding_entry(also):
+    """The src-F08-rounding measurement of the same run as the entry `roofline.reference_rounding` (+ flat scalars) of a
+    compact-flavour line: the only figures of the line that can be held against SURVEY.md 8(d)'s B_alg and BASELINE.md."""
+    r = also["roofline"]
+    nested = {"what": "the same workload and protocol in the same run with the src-F08 statement bit for bit (flavor F08: two "
+                      "stored vectors per pair): B_alg = 8n(11+L+2k) bounds ITS traffic from below (ratio 1.04), so "
+                      "contract_frac_of_peak = B_alg / wall time per update / 8 TB/s is the BASELINE.md-comparable fraction",
+              "value": also["value"], "unit": "updates/s", "ms_per_step": also["ms_per_step"],
+              "steady_state": also["steady_state"],
+              "contract_GBps": r.get("contract_GBps"), "contract_frac_of_peak": r.get("contract_frac_of_peak"),
+              "physical_frac": r["whole_update"]["frac"],
+              "kernel_fracs": {k: v.get("frac") for k, v in r["kernels"].items() if "frac" in v},
+              "bytes_moved_per_update": r["bytes_moved_per_update"], "contract_bytes_per_update": r.get("contract_bytes_per_update")}
+    flat = {"reference_rounding_updates_per_s": also["value"], "reference_rounding_ms_per_step": also["ms_per_step"],
+            "reference_rounding_contract_frac_of_peak": r.get("contract_frac_of_peak"),
+            "reference_rounding_physical_frac": r["whole_update"]["frac"],
+            "reference_rounding_PA_frac": r["kernels"]["PA_k_dots"]["frac"],
+            "reference_rounding_PB_frac": r["kernels"]["PB_k_combine"]["frac"]}
+    return nested, flat
 
 
 NO_RETRY_MARK = "NKA_BENCH_NO_RETRY"      # a rank prints this on stderr when a second attempt could not help
@@ -487,9 +524,20 @@ def launch_ranks(args, argv, script=None):
     `launch.first_attempt`.  Prints the ONE JSON line and returns the exit code."""
     script = script or os.path.abspath(__file__)
     t0 = time.perf_counter()
+    # ONE deadline for both attempts (ADVICE r4): launch_timeout for the first, and what is left of launch_timeout + 150 s for
+    # the second -- a driver that allows ~7 minutes for a bench line is never outlasted.
+    deadline = t0 + args.launch_timeout + 150
     rc, line, err, timed_out = run_rank_group(args.gpus, script, argv, args.launch_timeout)
     note = None
-    if line is None and not args.no_fallback and args.allreduce != "staged" and NO_RETRY_MARK not in err:
+    # A second attempt can only help where the COMMUNICATION path is what failed: the first attempt hung (watchdog: a
+    # collective that never returned) or its stderr names RCCL / NCCL / the communicator / the self-test all-reduce.  An
+    # out-of-memory rank, a Python exception elsewhere or a build failure would only fail the same way again, slowly.
+    comm_words = ("rccl", "nccl", "communicator", "all-reduce", "allreduce", "hipipc", "watchdog", "timed out", "timeout",
+                  "rendezvous", "sigalrm", "collective")
+    comm_failure = timed_out or any(w in err.lower() for w in comm_words)
+    if line is None and not comm_failure and not args.no_fallback and args.allreduce != "staged":
+        sys.stderr.write("[bench] the first attempt failed without a sign of the communication path: no second attempt\n")
+    if line is None and comm_failure and not args.no_fallback and args.allreduce != "staged" and NO_RETRY_MARK not in err:
         why = "watchdog expired" if timed_out else f"exit code {rc}"
         lines = err.splitlines()                   # the ranks' own last words, not torchrun's failure report behind them
         cut = max([i for i, ln in enumerate(lines) if "_run_module_as_main" in ln] or [len(lines) + 1]) - 1
@@ -498,7 +546,7 @@ def launch_ranks(args, argv, script=None):
         note = {"first_attempt": f"{why} with --allreduce {args.allreduce}", "last_stderr_line": last[0][-300:],
                 "first_attempt_s": round(time.perf_counter() - t0, 1)}
         sys.stderr.write(f"[bench] first attempt failed ({why}); second attempt with the host-staged all-reduce over gloo\n")
-        left = max(60, min(args.launch_timeout, 200))
+        left = int(max(45, min(args.launch_timeout, deadline - time.perf_counter())))
         rc, line, err, timed_out = run_rank_group(args.gpus, script, list(argv) + ["--backend", "gloo", "--allreduce", "staged"],
                                                   left)
     if line is not None:
@@ -756,6 +804,36 @@ def main(argv=None):
         finally:
             a2.delete()
 
+    def host_array_extra(steps=6):
+        """What an UNCHANGED caller of the reference gets: accel_update(f) on a HOST array (the reference's signature takes
+        host memory, F08:252), i.e. nka_hip_accel_update_host -- H2D copy of f, the update, D2H copy, synchronised -- at
+        BASELINE configs[1]'s size (n = 1e7, m = 10), pageable and pinned host memory.  PCIe-inclusive: never `value`."""
+        import numpy as np
+        n2, m2 = 10**7, 10
+        a5 = nka_amd.nka().init(n2, m2, flavor=FLAVORS[args.flavor])
+        try:
+            dbuf = torch.empty(n2, dtype=torch.float64, device=dev)
+            for t in range(m2 + 2):                       # fill the subspace through the device entry
+                synth.fill_torch(dbuf, SEED, 2000 + t, 0, n2)
+                a5.accel_update(dbuf)
+            torch.cuda.synchronize(dev)
+            res = {"entry": "nka_hip_accel_update_host (include/nka_hip.h): H2D copy of f, update, D2H copy, stream synchronised",
+                   "workload": "n=1e7, mvec=10, fp64, subspace full; 2 x 80 MB cross PCIe per update", "unit": "updates/s"}
+            for name, arr in (("pageable", np.empty(n2)), ("pinned", torch.empty(n2, dtype=torch.float64).pin_memory().numpy())):
+                dt = []
+                for t in range(steps):
+                    synth.fill_torch(dbuf, SEED, 3000 + t, 0, n2)
+                    arr[:] = dbuf.cpu().numpy()
+                    t0 = time.perf_counter()
+                    a5.accel_update(arr)
+                    dt.append(time.perf_counter() - t0)
+                med = float(np.median(dt[1:]))
+                res[name] = {"value": 1.0 / med, "ms_per_update": 1e3 * med, "pcie_GBps": 2 * 8.0 * n2 / med / 1e9}
+            res["steady_state"] = bool(a5.num_vec() == m2)
+            return res
+        finally:
+            a5.delete()
+
     def with_drops_extra():
         """The same accelerator shape with a SHRUNK subspace (VERDICT r3 task 2): every input in a drop-dim dimensional
         span, so every update takes a dependence drop (F08:326-345) and the subspace holds k = drop-dim < mvec vectors;
@@ -864,6 +942,9 @@ def main(argv=None):
             out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:
             out["also_f08_rounding"] = also
+            nested, flat = reference_rounding_entry(also)
+            out["roofline"]["reference_rounding"] = nested
+            out["roofline"].update(flat)
         if drops is not None:
             out["with_drops"] = drops
         if oop is not None:
@@ -876,6 +957,21 @@ def main(argv=None):
             except Exception as exc:       # an extra, never the measured path
                 out["config2_n1e7_m10"] = {"error": repr(exc)}
         lean = args.no_cpu_baseline or world > 1            # lean runs skip the CPU leg and the child-process extras
+        host_arr = None
+        if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+            try:
+                host_arr = host_array_extra()
+            except Exception as exc:       # an extra, never the measured path
+                host_arr = {"error": repr(exc)}
+        if world > 1 and not args.no_cpu_baseline and os.environ.get("NKA_BENCH_PROBE", "1") != "0":
+            # N > 1: rank 0 adds the same-run streaming ceilings at ITS shard size (a child process on rank 0's GPU after
+            # the timed region, while the other ranks wait in the final barrier: ~10 s), so that a scaling record carries
+            # what this memory system gives the shard's mixes next to the event-time fractions
+            probe = probe_ceilings(min(n_local, 10**8), timeout=90, device=local_rank)
+            out["roofline"]["probe_ceiling"] = probe
+            if probe and not probe.get("error"):
+                out["roofline"]["probe_ceiling_dominant_mix_GBps"] = probe.get("mix_22R_5W_GBps" if flavor == "c" else "mix_42R_5W_GBps")
+                out["roofline"]["probe_ceiling_pure_read_GBps"] = probe.get("pure_read_22_streams_GBps")
         if not lean:
             # release HBM (the child processes below need it) before the minute of CPU work
             del pool, pool_store
@@ -917,6 +1013,14 @@ def main(argv=None):
             out["roofline"] = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live, L=Lk, k=Lk)
             if also is not None:
                 also["roofline"]["probe_ceiling"] = probe
+                nested, flat = reference_rounding_entry(also)
+                out["roofline"]["reference_rounding"] = nested
+                out["roofline"].update(flat)
+            if host_arr is not None:
+                out["host_array_entry"] = host_arr
+                for kind in ("pageable", "pinned"):
+                    if isinstance(host_arr.get(kind), dict):      # flat, so that a scalars-only record keeps it
+                        out["roofline"][f"host_array_entry_n1e7_m10_{kind}_updates_per_s"] = host_arr[kind]["value"]
             if drops is not None and drops.get("roofline") and headline:
                 pm_d = pmc_same_run(flavor, n_local, m, extra_args=("--workload", "drops", "--drop-dim", str(args.drop_dim)))
                 if pm_d:

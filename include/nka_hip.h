@@ -156,8 +156,12 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
  *       does) at ANY n: a validation mode for callers moving over from the reference.  Cost: two chains of n dependent
  *       additions per update -- on par with the fast passes up to n = 64, +12-18 us at n = 512, 0.4 ms at n = 1e4,
- *       40 ms at n = 1e6 (profiles/r04/sum_order_cost.txt).  Single rank only (a sharded update would need the global
- *       norm before the Gram row: a second exchange): accel_update returns NKA_HIP_ESTATE with an all-reduce installed.
+ *       40 ms at n = 1e6 (profiles/r04/sum_order_cost.txt).  SHARDED (an all-reduce installed): the reference's sum over
+ *       the global vector is one chain of additions through the slices in rank order, so the ranks take turns -- rank r
+ *       continues the running sums of ranks 0..r-1, the others contribute zeros, and the installed hook (any hook that
+ *       sums) hands the prefix on: N rounds for the norm (w1' = d/s needs the GLOBAL s before it can be rounded), N for the
+ *       rows, 2N small exchanges per update.  An N-rank run then returns the bits of the SINGLE-rank compiled reference.
+ *       The handle must know where its slice lies: nka_hip_set_shard (nka_hip_comm_init_rank does it), else NKA_HIP_ESTATE.
  *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
  *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden
  *       scenario of the reference among them) -- blocked otherwise.
@@ -165,6 +169,10 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  * offered up to mvec = 250 (NKA_HIP_EINVAL beyond). */
 enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2 };
 int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
+/* Position of this rank's slice in the global vector: slice `rank` of `nranks`, slices laid out in rank order (the
+ * reference's parallel contract leaves the layout to the caller, F08:58-64; contiguous slices in rank order are what
+ * nka_amd/dist.py and every front end of this build use).  Only the sharded reference-order sums read it. */
+int nka_hip_set_shard(nka_hip_t a, int32_t rank, int32_t nranks);
 
 /* Host-array compatibility entry (the reference signature takes host memory,
  * F08:252): H2D copy, update, D2H copy, stream synchronised on return. */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "nka_hip_get_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "nka_hip_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int32]),
     "nka_hip_set_sum_order": (C.c_int, [C.c_void_p, C.c_int32]),
+    "nka_hip_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "nka_hip_last_error": (C.c_char_p, []),
     "nka_hip_invalidate_pointer_cache": (None, []),
     "nka_hip_device_info": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),

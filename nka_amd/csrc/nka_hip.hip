@@ -236,6 +236,15 @@ struct nka_hip_state {
   nka_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_ctx = nullptr;
   ncclComm_t comm = nullptr;
+  // peer-to-peer exchange (nka_hip_p2p_export / _attach; nka_kernels.hpp: struct P2P)
+  P2P p2p{};                          // base == nullptr: none
+  void *p2p_mail = nullptr;           // this rank's mailbox (fine-grained device memory, exported through hipIpc)
+  std::vector<void *> p2p_opened;     // the peers' mailboxes as mapped here (hipIpcCloseMemHandle at detach)
+  void *p2p_dev = nullptr;            // offsets table, exchange counter, status word
+  int p2p_ranks = 0;                  // ranks the mailbox was sized for
+  bool p2p_fused = false;             // the PA being enqueued sends its sums itself (update_impl)
+  int shard_rank = -1, shard_n = 0;   // position of this rank's slice in the global vector (nka_hip_set_shard; set by
+                                      // nka_hip_comm_init_rank too): only the sharded reference-order sums need it
   bool needs_comm = false;    // a deep copy of an accelerator that reduced through the built-in RCCL communicator: the
                               // communicator belongs to the original, and rank-local sums would be silently wrong
   nka_hip_host_dot_fn host_dot = nullptr;   // user dot product on host copies (compatibility path)
@@ -291,6 +300,19 @@ int rccl_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
   return 0;
 }
 
+// The peer-to-peer exchange as a plain all-reduce hook: one small kernel that sends and gathers (k_p2p_allreduce).  An update in
+// the fast passes does not come here: its final-sums kernel sends and its scalar step gathers (update_impl).
+int p2p_allreduce(void *ctx, double *buf, int32_t count, void *stream) {
+  auto *a = static_cast<nka_hip_state *>(ctx);
+  if (!a->p2p.base) return fail(NKA_HIP_ECOMM, "peer-to-peer exchange: not attached");
+  if (count < 0 || count > a->p2p.cap) return fail(NKA_HIP_EINVAL, "peer-to-peer exchange: more values than a mailbox row holds");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(128), 0, (hipStream_t)stream, a->p2p, buf, (int)count);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NKA_HIP_ECOMM, std::string("peer-to-peer exchange: ") + hipGetErrorString(e));
+  return 0;
+}
+
 // ---- kernel dispatch by unroll width ------------------------------------------
 template <int MAXL, int VEC>
 int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) {
@@ -298,7 +320,7 @@ int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) 
   const int g = grid_for(a, 0, VEC, occ, MAXL + 2);
   hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, g, pass, npass * MAXL);
+                     a->partials, g, pass, npass * MAXL, a->p2p_fused ? a->p2p : P2P{});
   return g;
 }
 
@@ -313,7 +335,7 @@ int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
   // (Round 3 measured forming these sums -- and the scalar step -- in the tail of the PA launch, by the block that
   //  finishes last: 2-4 us SLOWER per update than the launches it saves, profiles/r03/ab_small_pa_tail_not_kept.txt.)
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, (int)g, 0, MAXL);
+                     a->partials, (int)g, 0, MAXL, a->p2p_fused ? a->p2p : P2P{});
   return (int)g;
 }
 
@@ -686,7 +708,7 @@ int nka_hip_capture_safe(nka_hip_t a) {
   // (the debug mode reads the state back after every update, a user dot product runs on the host, and a caller's all-reduce
   //  hook is a host callback that a replay would not call again: none of them can be captured; the built-in RCCL hook only
   //  enqueues on the stream)
-  const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce;
+  const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce && a->allreduce != p2p_allreduce;
   return (a->pending && list_bound_now(a) >= a->mvec + 1 && !a->debug && !a->host_dot && !user_hook) ? 1 : 0;
 }
 
@@ -716,6 +738,7 @@ int nka_hip_destroy(nka_hip_t a) {
   hipSetDevice(a->device);
   hipStreamSynchronize(a->stream);
   if (a->comm) rccl().CommDestroy(a->comm);
+  nka_hip_p2p_detach(a);
   hipFree(a->vs.v);
   hipFree(a->vs.w);
   hipFree(a->ctl.ic);
@@ -810,8 +833,10 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tickets = src->pb_tickets;
   b->serial_solve = src->serial_solve;
   b->sum_order = src->sum_order;
+  b->shard_rank = src->shard_rank;
+  b->shard_n = src->shard_n;
   b->debug = src->debug;
-  if (src->allreduce != rccl_allreduce) {      // a user hook travels with the object, the RCCL communicator does not
+  if (src->allreduce != rccl_allreduce && src->allreduce != p2p_allreduce) {      // a user hook travels with the object, the RCCL communicator (or the peers' mailboxes) does not
     b->allreduce = src->allreduce;
     b->allreduce_ctx = src->allreduce_ctx;
     b->needs_comm = src->needs_comm;
@@ -871,8 +896,9 @@ int nka_hip_set_vec_tol(nka_hip_t a, double vtol) {
 }
 
 // ---- the three stages of an update, enqueued on the handle's stream -------------
-static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, long long swap_v = kNoBuffer) {
+static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, long long swap_v = kNoBuffer, bool gather = false) {
   hipStream_t s = a->stream;
+  const P2P x = gather ? a->p2p : P2P{};      // the scalar step starts by gathering the sums of all ranks (peer-to-peer exchange)
   if (a->mvec + 1 <= kSolveWaveMax && !a->serial_solve) {
     const size_t sm = solve_wave_smem_bytes(a->mvec);
     const int nl = a->mvec + 1;
@@ -880,7 +906,7 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
     //  launch: a replay re-issues it with the arguments frozen at capture, a later out-of-place update would be invisible)
     const long long id_stride = (a->swapped || a->captured) ? 0 : (long long)a->vs.stride, id_vbase = buffer_offset(a, a->vs.v);
 #define ROWS(NL) \
-  hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v, id_stride, id_vbase)
+  hipLaunchKernelGGL((k_solve_rows<NL>), dim3(1), dim3(kSolveThreads), sm, s, a->ctl, mode, swap_w, swap_v, id_stride, id_vbase, x)
     if (nl <= 6) ROWS(6);
     else if (nl <= 11) ROWS(11);
     else if (nl <= 21) ROWS(21);
@@ -889,7 +915,7 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
 #undef ROWS
   } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
-                       a->state_in_global ? 1 : 0, 0, swap_w, swap_v);
+                       a->state_in_global ? 1 : 0, 0, swap_w, swap_v, x);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1039,7 +1065,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   // ---- device: norm, s == 0 -> relax, Gram row, Cholesky with drops (the reference's loops on one lane)
   const size_t smem = a->state_in_global ? 0 : lst_smem_bytes(a->mvec);
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 1, kNoBuffer, kNoBuffer);
+                     a->state_in_global ? 1 : 0, 1, kNoBuffer, kNoBuffer, P2P{});
   HIP_TRY(hipGetLastError());
   // Phase 1 has changed the lists, the free list, h and the flags on the device.  Whatever fails between here and
   // phase 2 (a copy, a corrupt list, the user's dp) must not leave a half-applied update behind: the control blocks
@@ -1086,7 +1112,7 @@ static int host_dot_update_scalars(nka_hip_t a, const double *f, int mode) {
   HIP_TRY_UNDO(hipMemcpyAsync(a->ctl.c(), c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice, a->stream));
   // ---- device: new slot, substitutions, plans, prepend
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), smem, a->stream, a->ctl, mode | kSolvePrenorm,
-                     a->state_in_global ? 1 : 0, 2, kNoBuffer, kNoBuffer);
+                     a->state_in_global ? 1 : 0, 2, kNoBuffer, kNoBuffer, P2P{});
   HIP_TRY_UNDO(hipGetLastError());
   HIP_TRY_UNDO(hipStreamSynchronize(a->stream));     // (c[] and red[] above are read by the stream until here)
 #undef HIP_TRY_UNDO
@@ -1112,6 +1138,41 @@ static bool held_by_library(const nka_hip_state *a, const double *p) {
   return it != a->taken.end() && *it < p + n;
 }
 
+// Reference-order sums of a SHARDED accelerator (validation mode).  The reference's sum over the global
+// vector is ONE chain of additions through the slices in rank order (its dp is a global dot product, F08:209-219; summed
+// sequentially over the whole vector that is what a single-rank run of the reference computes).  So the ranks take turns:
+// in round r rank r continues the running sums from the prefix over ranks 0..r-1 (k_dots_ordered, carry) while every other
+// rank contributes zeros, and the installed all-reduce hands the new prefix to everybody -- x + 0 + ... + 0 is exact in any
+// order, so ANY hook that sums serves as the chain's transport.  N rounds for the norm (the Gram row needs the GLOBAL s
+// before w1' = d/s can be rounded), N rounds for the rows: 2N small exchanges and the serial walk of the whole global
+// vector per update -- validation speed, bits of the single-rank compiled reference.
+static int ordered_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
+  hipStream_t s = a->stream;
+  const int N = a->shard_n, me = a->shard_rank;
+  const int rows = 2 + older_ub, count = a->ctl.red_count();
+  double *red = a->ctl.red();
+  auto exchange = [&](double *buf, int cnt) -> int {
+    if (int rc = a->allreduce(a->allreduce_ctx, buf, cnt, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+    return 0;
+  };
+  auto round = [&](int r, int phase, double *buf, int cnt) -> int {
+    if (r == me) {
+      hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
+                         ord_chunk(rows), phase, r > 0 ? 1 : 0);
+      HIP_TRY(hipGetLastError());
+    } else {
+      HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)cnt, s));
+    }
+    return exchange(buf, cnt);
+  };
+  if (a->pending)
+    for (int r = 0; r < N; r++)
+      if (int rc = round(r, kOrdNorm, red, 1)) return rc;
+  for (int r = 0; r < N; r++)
+    if (int rc = round(r, kOrdRows, red + 1, count - 1)) return rc;
+  return 0;
+}
+
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
 
 int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, kNoBuffer, kNoBuffer); }
@@ -1135,10 +1196,13 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   if (a->needs_comm)
     return fail(NKA_HIP_ECOMM, "accel_update: this accelerator is a copy of a sharded one and has no all-reduce yet: call "
                                "nka_hip_comm_init_rank or nka_hip_set_allreduce on it first (nka_hip_clone)");
-  if (a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER && a->allreduce && !a->host_dot)
-    return fail(NKA_HIP_ESTATE, "accel_update: reference-order sums were asked for (nka_hip_set_sum_order) on a sharded "
-                                "accelerator: the Gram row of the normalised difference needs the GLOBAL norm first, a second "
-                                "exchange per update, which this library does not make");
+  const bool chain = a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER && a->allreduce && !a->host_dot;
+  if (chain && (a->shard_n < 1 || a->shard_rank < 0))
+    return fail(NKA_HIP_ESTATE, "accel_update: reference-order sums on a sharded accelerator continue the running sums from rank "
+                                "to rank: tell the handle where its slice lies in the global vector first (nka_hip_set_shard; "
+                                "nka_hip_comm_init_rank does it for the built-in communicator)");
+  if (chain && a->mvec > kOrdMaxMvec)
+    return fail(NKA_HIP_EINVAL, "accel_update: reference-order sums are offered up to mvec = " + std::to_string(kOrdMaxMvec));
   if (a->debug && nka_hip_defined(a) != 1)                                                // F08:257 ASSERT(defined(this))
     return fail(NKA_HIP_ESTATE, "accel_update: the device state fails the defined() invariants");
   hipStream_t s = a->stream;
@@ -1162,27 +1226,38 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   // A failure up to and including the all-reduce leaves the update NOT done: only
   // scratch (partials, red[]) has been written; f, the stored vectors, the lists and
   // the host-side bookkeeping are untouched, so the same call may be repeated.
-  bool solved = false;
+  bool solved = false, gather = false;
   if (a->host_dot) {
     RoctxRange range("nka:host dot products + scalar step");
     if (int rc = host_dot_update_scalars(a, f, mode)) return rc;
     solved = true;
+  } else if (chain) {
+    // ... the same sums with the slices of the global vector walked rank after rank (ordered_chain): 2N exchanges
+    RoctxRange range("nka:PA dots in the reference's order, rank after rank");
+    if (a->pending || older_ub > 0)
+      if (int rc = ordered_chain(a, f, mode, older_ub)) return rc;
+    mode |= kSolvePrenorm;
   } else if (ordered_sums(a)) {
     // every sum in the reference's order on one workgroup: the update returns the reference's bits (k_dots_ordered)
     RoctxRange range("nka:PA dots in the reference's order");
     if (a->pending || older_ub > 0) {
       const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
       hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
-                         ord_chunk(rows));
+                         ord_chunk(rows), (int)kOrdAll, 0);
       HIP_TRY(hipGetLastError());
     }
     mode |= kSolvePrenorm;
   } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
+    // peer-to-peer exchange: the final sums go straight into every rank's mailbox and the scalar step gathers them -- no
+    // kernel in between (nka_kernels.hpp: struct P2P)
+    gather = a->allreduce == p2p_allreduce && a->p2p.base != nullptr;
+    a->p2p_fused = gather;
     enqueue_pa(a, f, vec, older_ub);
+    a->p2p_fused = false;
     HIP_TRY(hipGetLastError());
     // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
-    if (a->allreduce)
+    if (a->allreduce && !gather)
       if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), a->ctl.red_count(), s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
   }
   if (int rc = record(a, 1)) return rc;
@@ -1190,7 +1265,7 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
   RoctxRange range_tail("nka:solve + PB combine");
   if (!solved)
-    if (int rc = enqueue_solve(a, mode, swap_w, swap_v)) return rc;
+    if (int rc = enqueue_solve(a, mode, swap_w, swap_v, gather)) return rc;
   // From here on the scalar step is in the stream: the lists, the factor and (out of place) the tables move on whatever
   // happens next.  What can still fail is a HIP call (an event record, a launch); the handle is then beyond repair.
   struct Poison {
@@ -1329,6 +1404,12 @@ static int fetch_state(nka_hip_t a, std::vector<int32_t> &ic, std::vector<double
   HIP_TRY(hipMemcpyAsync(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipMemcpyAsync(dc.data(), a->ctl.dc, sizeof(double) * dc.size(), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
+  if (a->p2p.base) {           // a gather of the peer-to-peer exchange that gave up stored NaNs and raised the status word
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, a->p2p.status, sizeof st, hipMemcpyDeviceToHost));
+    if (st != 0) return fail(NKA_HIP_ECOMM, "peer-to-peer exchange: a rank's sums did not arrive in time (nka_hip_p2p_attach); "
+                                           "the state of this handle is not usable any more");
+  }
   return 0;
 }
 
@@ -1460,6 +1541,115 @@ int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx) {
   return 0;
 }
 
+// ---- peer-to-peer exchange: set-up (collective, like the RCCL communicator) -----------------------------------------
+int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  if (!a || !handle64) return fail(NKA_HIP_EINVAL, "null argument");
+  if (nranks < 1 || nranks > 64) return fail(NKA_HIP_EINVAL, "p2p_export: 1..64 ranks (one node)");
+  HIP_TRY(hipSetDevice(a->device));
+  if (int rc = nka_hip_p2p_detach(a)) return rc;
+  const int cap = std::max(a->ctl.red_count(), 64);
+  const size_t bytes = p2p_mailbox_bytes(nranks, cap);
+  void *m = nullptr;
+  // fine-grained device memory: peers' stores land coherently (RCCL allocates its own flags the same way)
+  hipError_t e = hipExtMallocWithFlags(&m, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(NKA_HIP_ECOMM, std::string("p2p_export: fine-grained allocation: ") + hipGetErrorString(e));
+  }
+  hipIpcMemHandle_t h;
+  if ((e = hipMemset(m, 0, bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+      (e = hipIpcGetMemHandle(&h, m)) != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(m);
+    return fail(NKA_HIP_ECOMM, std::string("p2p_export: hipIpcGetMemHandle: ") + hipGetErrorString(e) +
+                               " (this pool needs HSA_ENABLE_IPC_MODE_LEGACY=0)");
+  }
+  a->p2p_mail = m;
+  a->p2p_ranks = nranks;
+  memcpy(handle64, &h, sizeof h);
+  return 0;
+}
+
+int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank) {
+  if (!a || !handles) return fail(NKA_HIP_EINVAL, "null argument");
+  if (!a->p2p_mail || nranks != a->p2p_ranks) return fail(NKA_HIP_ESTATE, "p2p_attach: call nka_hip_p2p_export(nranks) first");
+  if (rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "p2p_attach: bad rank");
+  HIP_TRY(hipSetDevice(a->device));
+  const int cap = std::max(a->ctl.red_count(), 64);
+  std::vector<long long> off((size_t)nranks, 0);
+  for (int q = 0; q < nranks; q++) {
+    if (q == rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char *>(handles) + (size_t)q * sizeof h, sizeof h);
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (void *o : a->p2p_opened) hipIpcCloseMemHandle(o);
+      a->p2p_opened.clear();
+      return fail(NKA_HIP_ECOMM, std::string("p2p_attach: hipIpcOpenMemHandle(rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+    }
+    a->p2p_opened.push_back(p);
+    off[(size_t)q] = (long long)(reinterpret_cast<intptr_t>(p) - reinterpret_cast<intptr_t>(a->p2p_mail));
+  }
+  // offsets table | exchange counter | status word
+  const size_t tbytes = sizeof(long long) * (size_t)nranks;
+  hipError_t e = hipMalloc(&a->p2p_dev, tbytes + 16);
+  unsigned long long one = 1;
+  int zero = 0;
+  if (e == hipSuccess) e = hipMemcpy(a->p2p_dev, off.data(), tbytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(static_cast<char *>(a->p2p_dev) + tbytes, &one, sizeof one, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(static_cast<char *>(a->p2p_dev) + tbytes + 8, &zero, sizeof zero, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    nka_hip_p2p_detach(a);
+    return fail(NKA_HIP_EHIP, std::string("p2p_attach: ") + hipGetErrorString(e));
+  }
+  a->p2p.base = static_cast<char *>(a->p2p_mail);
+  a->p2p.off = static_cast<const long long *>(a->p2p_dev);
+  a->p2p.xseq = reinterpret_cast<unsigned long long *>(static_cast<char *>(a->p2p_dev) + tbytes);
+  a->p2p.status = reinterpret_cast<int *>(static_cast<char *>(a->p2p_dev) + tbytes + 8);
+  a->p2p.n = nranks;
+  a->p2p.me = rank;
+  a->p2p.cap = cap;
+  a->p2p.timeout_ticks = (long long)env_int("NKA_HIP_P2P_TIMEOUT_MS", 5000) * 100000ll;      // wall_clock64: 100 MHz
+  a->allreduce = p2p_allreduce;
+  a->allreduce_ctx = a;
+  a->needs_comm = false;
+  a->shard_rank = rank;
+  a->shard_n = nranks;
+  return 0;
+}
+
+int nka_hip_p2p_detach(nka_hip_t a) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (!a->p2p_mail && !a->p2p_dev && a->p2p_opened.empty()) return 0;
+  hipSetDevice(a->device);
+  hipStreamSynchronize(a->stream);
+  for (void *o : a->p2p_opened) hipIpcCloseMemHandle(o);
+  a->p2p_opened.clear();
+  hipFree(a->p2p_dev);
+  hipFree(a->p2p_mail);
+  a->p2p_dev = a->p2p_mail = nullptr;
+  a->p2p = P2P{};
+  a->p2p_ranks = 0;
+  if (a->allreduce == p2p_allreduce) {
+    a->allreduce = nullptr;
+    a->allreduce_ctx = nullptr;
+  }
+  (void)hipGetLastError();
+  return 0;
+}
+
+int nka_hip_set_shard(nka_hip_t a, int32_t rank, int32_t nranks) {
+  if (!a) return fail(NKA_HIP_EINVAL, "null handle");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "set_shard: bad rank / nranks");
+  a->shard_rank = rank;
+  a->shard_n = nranks;
+  return 0;
+}
+
 int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
   a->host_dot = fn;
@@ -1498,6 +1688,8 @@ int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32
   a->allreduce = rccl_allreduce;
   a->allreduce_ctx = a;
   a->needs_comm = false;
+  a->shard_rank = rank;        // slices in rank order (nka_amd/dist.py: slice_bounds), as every sharded caller lays them out
+  a->shard_n = nranks;
   return 0;
 }
 

@@ -180,6 +180,93 @@ struct Vecs {
   int64_t n;           // local vector length
 };
 
+// ---- PEER-TO-PEER EXCHANGE of the 2 + 2 mvec sums (round 5, opt-in: nka_hip_p2p_attach) -----------------------------------
+// The one exchange of a sharded update is an all-reduce of 336 bytes: latency, not bandwidth.  Through RCCL it is a kernel of
+// its own between the final sums and the scalar step.  Here every rank owns a MAILBOX in fine-grained device memory that its
+// peers map through hipIpc: the final-sums kernel of rank p writes each sum it forms straight into row p of EVERY rank's
+// mailbox (value, then -- released at system scope -- the number of the exchange as that entry's flag), and the scalar step of
+// rank q starts by waiting, entry by entry, for the N flags and adding the N rows IN RANK ORDER: the same additions in the same
+// order on every rank, hence the same bits -- no communication kernel, two kernel boundaries fewer.
+//   mailbox of one rank: val[2][N][cap] doubles, then flag[2][N][cap] 64-bit words; slot = exchange number & 1.  Two slots
+//   suffice: a rank can start exchange x+2 only after its scalar step of x+1 has seen EVERY peer's row of x+1, and a peer sends
+//   x+1 only after its own scalar step has consumed x (stream order).
+//   `xseq` (device memory of this rank): number of the NEXT exchange, advanced by whoever gathers; device-resident so that a
+//   captured update replays correctly.  Peers' mailboxes are reached as BYTE OFFSETS from this rank's own (`off[q]`): a pointer
+//   read from memory has no address space and would be accessed with FLAT instructions (see Ctl::pc).
+//   A wait is bounded (`timeout_ticks` of the 100 MHz wall clock): a peer that never sends makes the gather store NaNs, raise
+//   `status` and go on, so that the grid always drains; the host reports NKA_HIP_ECOMM at its next synchronising call.
+struct P2P {
+  char *base;                    // this rank's mailbox (nullptr: no peer-to-peer exchange)
+  const long long *off;          // [n] byte offset of rank q's mailbox from `base` (device memory)
+  unsigned long long *xseq;      // number of the next exchange (device memory, starts at 1)
+  int *status;                   // != 0: a wait timed out
+  int n, me, cap;
+  long long timeout_ticks;
+  __device__ double *val(int q, int slot, int src, int e) const {
+    return reinterpret_cast<double *>(base + off[q]) + ((size_t)slot * n + src) * cap + e;
+  }
+  __device__ unsigned long long *flag(int q, int slot, int src, int e) const {
+    return reinterpret_cast<unsigned long long *>(base + off[q]) + (size_t)2 * n * cap + ((size_t)slot * n + src) * cap + e;
+  }
+};
+__host__ __device__ inline size_t p2p_mailbox_bytes(int n, int cap) { return (size_t)2 * n * cap * 16; }
+
+// One lane sends entry e of exchange `seq` to rank q: the value, then the flag released at system scope.
+__device__ __forceinline__ void p2p_send_one(const P2P &x, int q, unsigned long long seq, int e, double v) {
+  const int slot = (int)(seq & 1ull);
+  __hip_atomic_store(x.val(q, slot, x.me, e), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(x.flag(q, slot, x.me, e), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// A whole wavefront sends entry e (lanes q = lane, lane + 64, ... < n each serve one peer); v is uniform.
+__device__ __forceinline__ void p2p_send_wave(const P2P &x, unsigned long long seq, int e, double v) {
+  for (int q = threadIdx.x & 63; q < x.n; q += 64) p2p_send_one(x, q, seq, e, v);
+}
+// Entry e of exchange `seq`, summed over the ranks in rank order (one lane).  Bounded wait.
+__device__ __forceinline__ double p2p_gather_one(const P2P &x, unsigned long long seq, int e) {
+  const int slot = (int)(seq & 1ull);
+  double acc = 0.0;
+  bool late = false;
+  const long long t0 = wall_clock64();
+  for (int r = 0; r < x.n; r++) {
+    unsigned long long *fl = x.flag(x.me, slot, r, e);
+    while (!late && __hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > x.timeout_ticks) late = true;
+    }
+    const double v = __hip_atomic_load(x.val(x.me, slot, r, e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    acc = (r == 0) ? v : acc + v;
+  }
+  if (late) {
+    *x.status = 1;
+    acc = __builtin_nan("");
+  }
+  return acc;
+}
+// The gather at the head of the scalar step: red[e] <- sum over ranks, e < count, by the threads of ONE workgroup; then the
+// exchange number moves on.  (Each thread reads back only entries it wrote itself or after the barrier.)
+__device__ __forceinline__ void p2p_gather_block(const P2P &x, double *red, int count) {
+  const unsigned long long seq = *x.xseq;
+  for (int e = threadIdx.x; e < count; e += blockDim.x) red[e] = p2p_gather_one(x, seq, e);
+  __syncthreads();
+  if (threadIdx.x == 0) *x.xseq = seq + 1;
+}
+// The generic form (the hook behind nka_hip_allreduce_now, the self-test and the reference-order chain): one workgroup sends
+// its `count` values to every rank, then gathers.
+static __global__ __launch_bounds__(128) __attribute__((unused)) void k_p2p_allreduce(P2P x, double *buf, int count) {
+  const unsigned long long seq = *x.xseq;
+  for (int i = threadIdx.x; i < count * x.n; i += blockDim.x) p2p_send_one(x, i % x.n, seq, i / x.n, buf[i / x.n]);
+  __syncthreads();
+  p2p_gather_block(x, buf, count);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane_uniform);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane_uniform);
+  return u.d;
+}
+
 // ---- reductions ---------------------------------------------------------------
 // Sum over the wavefront, valid in LANE 0: the butterfly x += x[lane + off], off = 32, 16, 8, 4, 2, 1 -- the tree
 // __shfl_down builds, hence the same bits -- but through REGISTERS: gfx950's v_permlane32_swap / v_permlane16_swap
@@ -498,11 +585,15 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
 constexpr int kFinThreads = 64;
 // `ncover` = entries of each row that the passes of this update write (npass*MAXL):
 // pass 0 zeroes the rest, so red[] never carries stale sums into the all-reduce.
+// `x.base` != nullptr: the sums do not stay here -- each one goes to row `me` of every rank's mailbox (P2P above) and the
+// scalar step gathers them; red[] is then written by that gather.
 template <int MAXL>
 __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const double *__restrict__ partials, int G,
-                                                               int pass, int ncover) {
+                                                               int pass, int ncover, P2P x) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
+  const bool p2p = x.base != nullptr;
+  const unsigned long long xs = p2p ? *x.xseq : 0ull;
   // the column's partial sums are requested BEFORE the plan is known (whether the column is live only decides
   // if its sum or a zero is stored): the two memory round trips overlap instead of following one another
   double r = 0.0;
@@ -513,8 +604,15 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
   const int base = pass * MAXL;
   if (pass == 0 && c == 0)
     for (int p = ncover + lane; p < ctl.mvec; p += kFinThreads) {
-      ctl.red()[2 + p] = 0.0;
-      ctl.red()[2 + ctl.mvec + p] = 0.0;
+      if (p2p) {
+        for (int q = 0; q < x.n; q++) {
+          p2p_send_one(x, q, xs, 2 + p, 0.0);
+          p2p_send_one(x, q, xs, 2 + ctl.mvec + p, 0.0);
+        }
+      } else {
+        ctl.red()[2 + p] = 0.0;
+        ctl.red()[2 + ctl.mvec + p] = 0.0;
+      }
     }
   int dst = -1;
   bool live = false;
@@ -528,6 +626,10 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
     if (p < ctl.mvec) { dst = 2 + ctl.mvec + p; live = p < nolder; }
   }
   if (dst < 0) return;
+  if (p2p) {
+    p2p_send_wave(x, xs, dst, live ? readlane_f64(r, 0) : 0.0);
+    return;
+  }
   if (lane == 0) ctl.red()[dst] = live ? r : 0.0;
 }
 
@@ -608,9 +710,16 @@ __device__ __forceinline__ void ord_load_older(double *sh, int S, const Vecs &vs
   }
 }
 
+// SHARDED (round 5): the reference's sum over the GLOBAL vector is one chain of additions through the slices in rank
+// order, so rank r CONTINUES the running sums of rank r-1: `carry` != 0 starts every accumulator from the value red[]
+// holds (the prefix over the ranks before this one) instead of 0, and the update is made in two kinds of rounds (nka_hip.hip,
+// ordered_chain): phase 1 = the norm only (red[0]); phase 2 = with s from the GLOBAL red[0], the sums on the rounded w1'
+// and on f (red[1..]).  phase 0 = both in one launch, the single-rank form described above.
+enum { kOrdAll = 0, kOrdNorm = 1, kOrdRows = 2 };
 static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_dots_ordered(Ctl ctl, Vecs vs,
                                                                                               const double *__restrict__ f,
-                                                                                              int rcp, int chunk) {
+                                                                                              int rcp, int chunk, int phase,
+                                                                                              int carry) {
   extern __shared__ double ord_sh[];
   __shared__ double sum_dd;
   const int t = threadIdx.x;
@@ -623,7 +732,7 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
   const long long *pw = ctl.plan_w();
   double *red = ctl.red();
   double *row_f = ord_sh, *row_w1 = ord_sh + S;      // rows 2.. : the older w's
-  const bool single = n <= chunk;                    // the whole vectors fit: every global load of the update is issued ONCE
+  const bool single = n <= chunk && phase == kOrdAll;   // the whole vectors fit: every global load of the update is issued ONCE
 
   // The sums on the ROUNDED w1' wait for the norm, those on f alone do not: they live in DIFFERENT wavefronts, so that the
   // second kind is summed while thread 0 sums the norm.  Threads 0..127 own the w1' sums  r = t, t + 128  (r = 0: <f,w1'>;
@@ -645,10 +754,17 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
     }
   }
 
+  if (carry)
+    for (int q = 0; q < 2; q++)
+      if (dst[q] >= 0) acc[q] = red[dst[q]];           // the running sums of the ranks before this one
   // ---- first pass: the norm (F08:266-267); with everything resident also the sums on f alone, on the other threads ----
   double s = 0.0;
-  {
-    double dd = 0.0;
+  if (phase == kOrdRows) {
+    if (pending) s = sqrt(red[0]);                     // the GLOBAL sum d^2 of the norm rounds
+    if (t == 0) sum_dd = red[0];
+    __syncthreads();
+  } else {
+    double dd = (carry && t == 0) ? red[0] : 0.0;
     for (int64_t c0 = 0; c0 < n; c0 += chunk) {
       const int len = (int)(n - c0 < chunk ? n - c0 : chunk);
       if (!pending && !single) break;
@@ -668,6 +784,10 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
     if (t == 0) sum_dd = dd;
     __syncthreads();
     if (pending) s = sqrt(sum_dd);
+    if (phase == kOrdNorm) {                           // a norm round of a sharded update: red[0] and nothing else
+      if (t == 0 && pending) red[0] = sum_dd;
+      return;
+    }
   }
   const bool normed = pending && s != 0.0;           // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
   const double rs = 1.0 / s;
@@ -702,9 +822,11 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
   }
   // red[]: zero what this update does not cover (nothing stale reaches a later reader), then the sums
   __syncthreads();
-  for (int i = t; i < 2 + 2 * mvec; i += kOrdThreads) red[i] = 0.0;
+  if (!carry) {                                        // (a continuing rank keeps the prefix of the sums it does not own: zeros)
+    for (int i = t + (phase == kOrdRows ? 1 : 0); i < 2 + 2 * mvec; i += kOrdThreads) red[i] = 0.0;
+  }
   __syncthreads();
-  if (t == 0 && pending) red[0] = sum_dd;
+  if (t == 0 && pending && phase == kOrdAll) red[0] = sum_dd;
   for (int q = 0; q < 2; q++)
     if (dst[q] >= 0 && (normed || !on_w1)) red[dst[q]] = acc[q];
 }
@@ -1312,8 +1434,9 @@ __device__ __forceinline__ double solve_nrm(double x, double s, double rs, int m
 // substitutions on the right-hand side the host has put into c[] BY SLOT, combine plan, prepend.
 static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void k_solve(Ctl ctl, int mode, int in_global,
                                                                                        int phase, long long swap_w,
-                                                                                       long long swap_v) {
+                                                                                       long long swap_v, P2P x) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (x.base != nullptr) p2p_gather_block(x, ctl.red(), ctl.red_count());      // the sums of all ranks, in rank order
   Lst L;
   lst_load(L, ctl, smem, in_global);
   if (threadIdx.x == 0) {
@@ -1416,23 +1539,18 @@ __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   return b;
 }
 
-__device__ __forceinline__ double readlane_f64(double x, int src_lane_uniform) {
-  union { double d; int i[2]; } u;
-  u.d = x;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane_uniform);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane_uniform);
-  return u.d;
-}
-
 // NLMAX >= list length is a template parameter: both loops of the factorisation are fully unrolled so
 // that the row a[] stays in registers (62 VGPRs at NLMAX = 21, 116 at 48; no scratch).  Column i:
 // l_p = a_p[i] / L_ii on every lane, then for q = i+1 .. (uniform loop) a_p[q] -= l_p * l_q with
 // l_q = readlane(l, q) -- lanes p <= q update entries nobody reads.
 template <int NLMAX>
 __global__ __launch_bounds__(kSolveThreads) void k_solve_rows(Ctl ctl, int mode, long long swap_w, long long swap_v,
-                                                              long long id_stride, long long id_vbase) {
+                                                              long long id_stride, long long id_vbase, P2P x) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
+  // peer-to-peer exchange: wait for the rows of all ranks and add them in rank order (P2P above); red[] then holds the
+  // global sums like after an all-reduce (lane e reads back below what it has just written itself)
+  if (x.base != nullptr) p2p_gather_block(x, ctl.red(), ctl.red_count());
   const int m1 = ctl.m1(), NL = m1, LDA = NL + 1, M = ctl.mvec, nh = (m1 + 1) * (m1 + 1);
   Lst L;
   L.m1 = m1;

@@ -121,6 +121,8 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
         raise ValueError(f"unknown all-reduce hook {prefer!r}")
     steps = steps[steps.index(prefer):]
     dev = acc._device
+    if hasattr(acc, "set_shard"):
+        acc.set_shard(rank, world_size)      # slices in rank order (slice_bounds): the sharded reference-order sums walk them so
 
     def say(msg):
         if rank == 0:

@@ -76,6 +76,7 @@ module nka_type
     procedure :: accel_update_swap
     procedure :: list_bound
     procedure :: set_sum_order
+    procedure :: set_shard
     procedure :: relax
     procedure :: restart
     procedure :: defined
@@ -255,6 +256,15 @@ contains
     integer, intent(in) :: order
     call nka_hip_check(nka_hip_set_sum_order(this%handle, int(order, c_int32_t)), 'nka%set_sum_order')
   end subroutine set_sum_order
+
+  !! Sharded runs with reference-order sums: slice `rank` (0-based) of `nranks`, slices in rank order (nka_hip_set_shard;
+  !! use_rccl tells the handle by itself).  The ranks then continue one another's running sums and the N-rank run returns
+  !! the bits of the single-rank reference.
+  subroutine set_shard(this, rank, nranks)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: rank, nranks
+    call nka_hip_check(nka_hip_set_shard(this%handle, int(rank, c_int32_t), int(nranks, c_int32_t)), 'nka%set_shard')
+  end subroutine set_shard
 
   subroutine restart(this)                                    ! F08:422-436
     class(nka), intent(inout) :: this

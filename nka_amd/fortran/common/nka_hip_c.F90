@@ -59,6 +59,11 @@ module nka_hip_c
       type(c_ptr), value :: handle
       integer(c_int32_t), value :: order      ! NKA_HIP_SUMS_AUTO / _REFERENCE_ORDER / _BLOCKED (include/nka_hip.h)
     end function
+    integer(c_int) function nka_hip_set_shard(handle, rank, nranks) bind(C)
+      import :: c_int, c_ptr, c_int32_t
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: rank, nranks   ! slice `rank` (0-based) of `nranks`, slices in rank order
+    end function
     integer(c_int) function nka_hip_accel_update_host(handle, f_host) bind(C)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: handle

@@ -306,6 +306,12 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_set_sum_order(self._handle(), int(order)), "set_sum_order", self._L)
         return self
 
+    def set_shard(self, rank: int, nranks: int):
+        """Where this object's slice lies in the global vector (slice `rank` of `nranks`, in rank order): needed by the
+        sharded reference-order sums only (nka_hip_set_shard); use_rccl sets it by itself."""
+        _check(self._L.nka_hip_set_shard(self._handle(), int(rank), int(nranks)), "set_shard", self._L)
+        return self
+
     def list_bound(self) -> int:
         """The host's upper bound on the list length at the entry of the next update (no synchronisation):
         its own count tightened by the device's list word (nka_hip_list_bound)."""

@@ -2,7 +2,8 @@
 torch.distributed.run like the real thing, no GPU, no torch import.  --mode ok: rank 0 prints a JSON line; hang: every
 rank sleeps (the parent's watchdog must kill the whole group; each rank leaves its pid in --pidfile.<rank>);
 fail-unless-staged: exit 7 unless `--allreduce staged` was appended by the parent's second attempt; noretry: fail and
-say that a retry is pointless."""
+say that a retry is pointless; fail-other-unless-staged: a failure that does not name the communication path (the parent
+must NOT make its second attempt)."""
 import argparse
 import json
 import os
@@ -26,6 +27,9 @@ if a.mode == "hang" or (a.mode == "hang-unless-staged" and a.allreduce != "stage
 if a.mode == "fail-unless-staged" and a.allreduce != "staged":
     print(f"rank {rank}: ncclCommInitRank: unhandled system error (pretend)", file=sys.stderr)
     sys.exit(7)
+if a.mode == "fail-other-unless-staged" and a.allreduce != "staged":
+    print(f"rank {rank}: MemoryError: the host could not hold the inputs (pretend)", file=sys.stderr)
+    sys.exit(9)
 if a.mode == "noretry":
     print(f"rank {rank}: only 1 GPU(s) visible (NKA_BENCH_NO_RETRY)", file=sys.stderr)
     sys.exit(5)

@@ -44,20 +44,45 @@ def test_roofline_block_is_physical(bench, flavor, pa_ms, pb_ms):
     moved = 8.0 * n * sum(w.values())
     assert r["whole_update"]["bytes_moved"] == moved
     assert r["whole_update"]["frac"] == pytest.approx(moved / (mean[3] * 1e-3) / 1e9 / 8000.0)
-    # the contract's B_alg never enters a fraction: it is a ratio and a work rate
-    assert r["contract_bytes_per_update"] == 8.0 * n * (11 + 3 * m)
-    assert r["contract_bytes_ratio"] == pytest.approx(8.0 * n * (11 + 3 * m) / moved)
     assert r["bytes_moved_per_update"] == moved
+    # the same figures as flat scalars (what a scalars-only record of the line keeps)
+    assert r["whole_update_frac"] == pytest.approx(r["whole_update"]["frac"])
+    assert r["PA_k_dots_frac"] == pytest.approx(r["kernels"]["PA_k_dots"]["frac"])
+    assert r["PB_k_combine_frac"] == pytest.approx(r["kernels"]["PB_k_combine"]["frac"])
+    assert r["probe_ceiling_pure_read_GBps"] == 7100.0
     if flavor == "c":
-        # compact storage moves FEWER bytes than B_alg: no rate that could be read as > 100 % of the peak is printed
-        assert "contract_GBps" not in r and "contract_frac_of_peak" not in r and r["contract_bytes_ratio"] > 1.4
+        # compact storage moves FEWER bytes than B_alg: NO contract figure of any kind on its line --
+        # nothing a reader could divide by the time and read as > 100 % of the peak
+        assert not [k for k in r if k.startswith("contract")]
     else:
+        # the contract's B_alg never enters a fraction: it is a ratio and a work rate
+        assert r["contract_bytes_per_update"] == 8.0 * n * (11 + 3 * m)
+        assert r["contract_bytes_ratio"] == pytest.approx(8.0 * n * (11 + 3 * m) / moved)
         assert r["contract_GBps"] == pytest.approx(r["whole_update"]["achieved"] * r["contract_bytes_ratio"])
         assert r["contract_frac_of_peak"] == pytest.approx(r["contract_GBps"] / 8000.0) and r["contract_bytes_ratio"] < 1.05
     if pb_ms > 2.0:                          # realistic timings: below the peak
         assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["whole_update"]["frac"] <= 1.0
         for k in ("PA_k_dots", "PB_k_combine"):
             assert 0.0 < r["kernels"][k]["frac"] <= 1.0
+
+
+def test_reference_rounding_entry_carries_the_contract_comparable_figures(bench):
+    """the src-F08-rounding measurement of the same run sits INSIDE `roofline` of the compact line -- as
+    a nested object and as flat scalars -- so that a record which keeps only scalars still shows the BASELINE.md-comparable
+    fraction next to the compact flavour's physical one."""
+    n, m = 10**8, 20
+    mean = [2.55, 0.017, 6.16, 8.71]
+    also = {"value": 1e3 / 8.708, "unit": "updates/s", "ms_per_step": 8.708, "steady_state": True,
+            "roofline": bench.roofline_block("f08", n, m, mean)}
+    nested, flat = bench.reference_rounding_entry(also)
+    b_alg = 8.0 * n * (11 + 3 * m)
+    assert nested["contract_frac_of_peak"] == pytest.approx(b_alg / 8.71e-3 / 1e9 / 8000.0)
+    assert nested["physical_frac"] == pytest.approx(8.0 * n * 68 / 8.71e-3 / 1e9 / 8000.0)
+    assert set(nested["kernel_fracs"]) == {"PA_k_dots", "PB_k_combine"} and nested["value"] == also["value"]
+    assert flat["reference_rounding_contract_frac_of_peak"] == nested["contract_frac_of_peak"]
+    assert flat["reference_rounding_updates_per_s"] == also["value"]
+    assert all(isinstance(v, float) for v in flat.values())                 # scalars only
+    assert 0.7 < flat["reference_rounding_contract_frac_of_peak"] < 0.9 and flat["reference_rounding_PB_frac"] < 1.0
 
 
 def test_committed_pmc_traffic_agrees_with_the_byte_model(bench):
@@ -105,6 +130,10 @@ def test_plain_form_second_attempt_names_the_fallback_hook(bench, capsys):
     assert rc != 0 and lines == []
     # a failure a retry cannot cure (too few GPUs) is not retried
     rc, lines = _launch(bench, capsys, ["--mode", "noretry"])
+    assert rc != 0 and lines == []
+    # ... nor one that shows no sign of the communication path (an out-of-memory rank, an exception elsewhere, a
+    # build failure would only fail again, slowly): the staged second attempt WOULD have succeeded here, and is not made
+    rc, lines = _launch(bench, capsys, ["--mode", "fail-other-unless-staged"])
     assert rc != 0 and lines == []
 
 

@@ -146,8 +146,11 @@ def test_auto_is_blocked_beyond_64_elements_and_for_sharded_accelerators(torch_c
     sharded.set_dot_prod(lambda ptr, count, stream: None)          # "a global sum": the accelerator is one slice of many
     assert red1_is_raw(sharded, 64)
     sharded.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
-    with pytest.raises(nka_amd.NKAError, match="second exchange"):
+    with pytest.raises(nka_amd.NKAError, match="nka_hip_set_shard"):      # the chain over the ranks needs the slice's position
         sharded.accel_update(torch_cuda.zeros(64, dtype=torch_cuda.float64, device="cuda"))
+    sharded.set_shard(0, 1)
+    assert not red1_is_raw(sharded, 64)                              # one "rank": the chain is the single-rank order
+    sharded.restart()
     sharded.set_sum_order(nka_amd.SUMS_AUTO)
     sharded.accel_update(torch_cuda.ones(64, dtype=torch_cuda.float64, device="cuda"))
     with pytest.raises(nka_amd.NKAError):
