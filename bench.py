@@ -103,7 +103,10 @@ def parse(argv=None):
     ap.add_argument("--flavor", choices=["default", "c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "default"),
                     help="'default' = what `call a%%init(vlen, mvec)` of the drop-in Fortran module runs (compact storage "
                          "unless NKA_HIP_FLAVOR says otherwise); or name the reference rounding mirrored")
-    ap.add_argument("--allreduce", choices=["rccl", "torch", "staged"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"))
+    ap.add_argument("--allreduce", choices=["p2p", "rccl", "torch", "staged"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"),
+                    help="the one exchange of a sharded update.  rccl (default): the library's RCCL communicator on the kernel "
+                         "stream; p2p: the opt-in peer-to-peer exchange (mailboxes mapped through hipIpc, no communication "
+                         "kernel; falls through to rccl where IPC is refused); torch / staged: fallbacks")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NKA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend.  gloo (+ --allreduce staged, NKA_BENCH_SHARE_GPU=1) is a REHEARSAL of the "
                          "multi-rank logic with all ranks on one GPU (RCCL refuses that); its numbers mean nothing")
@@ -586,8 +589,8 @@ def main(argv=None):
     share_gpu = os.environ.get("NKA_BENCH_SHARE_GPU") == "1"      # rehearsal: every rank on cuda:0
     if share_gpu:
         local_rank = 0
-    if args.backend == "gloo" and args.allreduce != "staged":
-        raise SystemExit(f"--backend gloo needs --allreduce staged ({NO_RETRY_MARK})")
+    if args.backend == "gloo" and args.allreduce not in ("staged", "p2p"):
+        raise SystemExit(f"--backend gloo needs --allreduce staged or p2p ({NO_RETRY_MARK})")
     ndev = torch.cuda.device_count()
     if local_rank >= ndev:
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible ({NO_RETRY_MARK})")
@@ -632,7 +635,9 @@ def main(argv=None):
             # collective decision over the control plane (all ranks end up with the same hook) + a proven test
             # all-reduce; ladder rccl -> torch (nccl group) -> staged (host, gloo), entered at --allreduce
             prefer = args.allreduce if hook_box[0] == "none" else hook_box[0]
-            ladder = ("staged",) if args.backend == "gloo" else ("rccl", "torch", "staged")
+            ladder = ("staged",) if args.backend == "gloo" and args.allreduce != "p2p" else \
+                ("p2p", "staged") if args.backend == "gloo" else ("p2p", "rccl", "torch", "staged")
+            # ("p2p" is entered only when asked for: attach_allreduce starts the ladder at `prefer`)
             hook_box[0] = nd.attach_allreduce(acc, rank, world, prefer=prefer, data_group=nccl_data_group, ladder=ladder)
             if hook_box[0] != args.allreduce and rank == 0:
                 print(f"[bench] all-reduce hook: asked for '{args.allreduce}', running '{hook_box[0]}'", file=sys.stderr, flush=True)

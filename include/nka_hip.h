@@ -247,6 +247,29 @@ int nka_hip_comm_library(char *path, int32_t len);
  * how many ranks RCCL really connected. */
 int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
 
+/* PEER-TO-PEER EXCHANGE (opt-in, one node): the sums of an update without a communication kernel.  Every rank owns a
+ * mailbox in fine-grained device memory which its peers map through hipIpc; the final-sums kernel of an update writes
+ * each sum straight into every rank's mailbox (value, then the exchange number released at system scope) and the scalar
+ * step starts by waiting for the N rows and adding them IN RANK ORDER -- the same additions in the same order on every
+ * rank, hence the same bits; two kernel boundaries fewer than with an all-reduce kernel in between.  Set-up, collective:
+ *   nka_hip_p2p_export(a, nranks, handle64)   allocate this rank's mailbox, fill 64 bytes (a hipIpcMemHandle_t);
+ *   the caller gathers the nranks handles in rank order by any means (as it broadcasts the RCCL unique id);
+ *   nka_hip_p2p_attach(a, handles, nranks, rank)   map the peers' mailboxes, install the exchange as the reduction
+ *                                                   (it also serves nka_hip_allreduce_now and the reference-order chain,
+ *                                                   as one small send-and-gather kernel).
+ * One process per GPU (hipIpc does not map a handle into the process that exported it).  A wait for a peer is BOUNDED
+ * (NKA_HIP_P2P_TIMEOUT_MS, default 5000): if a rank's sums do not arrive the gather stores NaNs, raises a status word and
+ * lets the grid drain; the next synchronising query (num_vec, get_state, state_digest ...) returns NKA_HIP_ECOMM.
+ * Capturable into a graph (the exchange number lives on the device).  nka_hip_p2p_detach, collective too (a peer must not
+ * write into a mailbox that has been freed: synchronise all ranks first), drops it; nka_hip_destroy calls it.
+ * Where hipIpc is refused (export or attach returns NKA_HIP_ECOMM) the caller falls back to the RCCL hook:
+ * nka_amd/dist.py attach_allreduce(ladder=("p2p", "rccl", ...)) decides that collectively.
+ * STATUS: a prototype, proven with ranks sharing one GPU (tests/test_p2p_exchange.py); over xGMI it needs a measured win
+ * over RCCL's 336-byte all-reduce before it is preferred. */
+int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64);
+int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank);
+int nka_hip_p2p_detach(nka_hip_t a);
+
 /* Run the installed all-reduce hook once on `count` doubles at device address
  * buf_dev, on the handle's stream (no-op without a hook): lets a launcher check
  * the communicator before the first update. */

@@ -45,6 +45,9 @@ SIGNATURES = {
     "nka_hip_comm_library": (C.c_int, [C.c_char_p, C.c_int32]),
     "nka_hip_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "nka_hip_allreduce_now": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "nka_hip_p2p_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "nka_hip_p2p_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "nka_hip_p2p_detach": (C.c_int, [C.c_void_p]),
     "nka_hip_state_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nka_hip_set_host_dot": (C.c_int, [C.c_void_p, HOST_DOT_FN, C.c_void_p]),
     "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),

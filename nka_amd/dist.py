@@ -97,6 +97,24 @@ def attach_rccl(acc, rank: int, world_size: int, group=None):
     return acc
 
 
+def attach_p2p(acc, rank: int, world_size: int, group=None):
+    """The peer-to-peer exchange (include/nka_hip.h: nka_hip_p2p_export / _attach): every rank exports the hipIpc handle
+    of its mailbox, the handles are gathered over `group` (any backend), every rank maps its peers.  Raises on the rank
+    where a step fails; attach_allreduce turns that into a collective decision."""
+    import torch.distributed as dist
+    box = [None] * world_size
+    try:
+        mine = ("ok", acc.p2p_export(world_size))
+    except Exception as exc:          # noqa: BLE001 -- every rank must still take part in the gather below
+        mine = ("error", repr(exc))
+    dist.all_gather_object(box, mine, group=group)
+    bad = [(r, p) for r, (k, p) in enumerate(box) if k != "ok"]
+    if bad:
+        raise RuntimeError(f"peer-to-peer exchange: export failed on rank(s) {bad}")
+    acc.p2p_attach([p for _, p in box], world_size, rank)
+    return acc
+
+
 def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", group=None, data_group=None,
                      ladder=("rccl", "torch", "staged")) -> str:
     """Install the per-update all-reduce on `acc` and PROVE it before first use.
@@ -142,6 +160,15 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
                         print(f"[nka_amd.dist] rank {rank}: RCCL communicator failed: {exc!r}", file=sys.stderr, flush=True)
                         ok = False
                     ok = all_agree(ok, group, dev)
+            elif hook == "p2p":
+                # opt-in step ahead of "rccl" (ladder=("p2p", "rccl", ...)): mailboxes mapped through hipIpc; where IPC is
+                # refused on ANY rank every rank drops to the next step
+                try:
+                    attach_p2p(acc, rank, world_size, group)
+                except Exception as exc:          # noqa: BLE001
+                    print(f"[nka_amd.dist] rank {rank}: peer-to-peer exchange failed: {exc!r}", file=sys.stderr, flush=True)
+                    ok = False
+                ok = all_agree(ok, group, dev)
             elif hook == "torch":
                 dg = data_group
                 try:
@@ -163,6 +190,8 @@ def attach_allreduce(acc, rank: int, world_size: int, prefer: str = "rccl", grou
         try:
             if hook == "rccl":
                 acc.drop_rccl()
+            if hook == "p2p":
+                acc.p2p_detach()
             acc.set_dot_prod(None)
         except Exception:                         # noqa: BLE001
             pass

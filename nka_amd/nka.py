@@ -193,6 +193,24 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_comm_info(self._handle(), C.byref(n), C.byref(r)), "comm_info", self._L)
         return int(n.value), int(r.value)
 
+    def p2p_export(self, nranks: int) -> bytes:
+        """Peer-to-peer exchange, step 1 (nka_hip_p2p_export): allocate this rank's mailbox; returns the 64-byte hipIpc
+        handle every peer needs."""
+        buf = C.create_string_buffer(64)
+        _check(self._L.nka_hip_p2p_export(self._handle(), int(nranks), buf), "p2p_export", self._L)
+        return buf.raw
+
+    def p2p_attach(self, handles, nranks: int, rank: int):
+        """Step 2 (nka_hip_p2p_attach): `handles` = the nranks 64-byte handles in rank order (bytes or a list of bytes)."""
+        blob = b"".join(handles) if not isinstance(handles, (bytes, bytearray)) else bytes(handles)
+        if len(blob) != 64 * nranks:
+            raise NKAError("p2p_attach: need nranks handles of 64 bytes")
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(self._L.nka_hip_p2p_attach(self._handle(), buf, int(nranks), int(rank)), "p2p_attach", self._L)
+
+    def p2p_detach(self):
+        _check(self._L.nka_hip_p2p_detach(self._handle()), "p2p_detach", self._L)
+
     def drop_rccl(self):
         _check(self._L.nka_hip_comm_destroy(self._handle()), "comm_destroy", self._L)
 
