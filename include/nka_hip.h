@@ -66,6 +66,37 @@ enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C =
  * nka_hip_flavor() reports the flavour a handle runs. */
 enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
 
+/* ---- NUMERICAL CONTRACT ----------------------------------------------------------------------------------------------
+ * What nka_hip_accel_update returns, held against the COMPILED reference (oracle/_ref: /root/reference built here without
+ * floating-point contraction) on the same call sequence.  err(x) = ||x - f_exact||_2 / ||f_in||_2, f_exact = the same calls
+ * in extended precision (oracle/nka_oracle_exact.c, itself held to a 60-digit restatement, oracle/oracle_mp.py);
+ * tests/parity_util.py is the executable form of every line below.
+ *  1. DECISIONS.  s == 0 (relax, F08:275), the capacity and dependence drops (F08:301-345), slot numbers, list order,
+ *     free-list order and num_vec equal the reference's after EVERY call: compared with == in every test and in every soak
+ *     sequence (about 19 000 random call sequences in round 4; none differed).  With reference-order sums that holds by
+ *     construction; with the fast passes a pivot within rounding distance of vtol^2 could in principle fall the other way.
+ *  2. REFERENCE-ORDER SUMS (nka_hip_set_sum_order(NKA_HIP_SUMS_REFERENCE_ORDER); the default up to n = 64): the returned f
+ *     -- and h, c, every stored vector -- carry the BITS of the reference flavour the handle runs, at any n, on one rank or
+ *     sharded (the ranks continue one another's running sums).  Validation speed beyond a few thousand elements.
+ *  3. FAST PASSES (the default beyond n = 64): sums in blocks with fma, the Gram row of the normalised difference from raw
+ *     sums -- other last bits than the reference's sequential sums, and closer to f_exact than those from n ~ 1e3 up.  Over a
+ *     call sequence
+ *           max err(f_device) <= max(base, F * max err(f_reference)),   base = 1e-12 (1e-10 for n >= 1e7),
+ *           F = 2 for n > 512, 4 within one tile of the kernels (n <= 512),
+ *     i.e. within the stated tolerance wherever the reference is, and never further from the truth than F times the
+ *     reference's own worst distance on the same calls (ill-conditioned sequences -- pivots down to vtol, a tiny difference
+ *     norm s -- put the REFERENCE 1e-10 ... 1e-6 from the truth; no fixed figure can hold there).  An EMPIRICAL bar with a
+ *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs, all but three with n <= 9 elements; the three
+ *     beyond one tile (1660, 1028, 771 elements: 2.7 x, 3.5 x, 3.4 x instead of 2 x) are replayed by the suite with a cap
+ *     on their ratio (tests/golden/soak_cases.json).  DIRECTLY against the reference: wherever err(f_reference) <= base / 2,
+ *     ||f_device - f_reference|| / ||f_in|| <= 2 * base is asserted; at n = 2e7, m = 20 (independent and dependent inputs)
+ *     <= 1e-10 on every call, unscaled (tests/test_hip_fullsize.py).
+ *  4. FLAVOURS.  The default flavour evaluates the combine as the C reference does, f + c*(v - w), against src-F08's
+ *     (f - c*w) + c*v: last-bit differences, inside every bound above; NKA_HIP_FLAVOR_F08 gives the src-F08 statement.
+ *  5. Sharded runs return the same bits on every rank (one reduction result, added in one order), and -- fast passes -- bits
+ *     that depend on the number of ranks like any blocked sum; the bounds of 3 hold unchanged (soak: 3 ranks, 5 600 sequences).
+ */
+
 /* ---- lifecycle --------------------------------------------------------- */
 
 /* Replaces  call a%init(vlen, mvec)  (F08:185-200)  /  nka_init(vlen, mvec,

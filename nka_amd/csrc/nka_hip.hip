@@ -356,14 +356,30 @@ constexpr int win_ring_pairs() {
   return MAXK % 2 == 0 ? 2 : MAXK % 3 == 0 ? 3 : MAXK % 5 == 0 ? 5 : MAXK % 7 == 0 ? 7 : MAXK;
 }
 
-// instantiated for EVERY width 1..32 so that no list length needs padding
+// Instantiated for EVERY width 1..32 so that no list length needs padding: a padded ring slot is a cache hit that starves
+// the window (PA at m = 5 through the width-8 kernel: +20 %; exact against padded widths -7...-14 % at m = 5 / 10,
+// profiles/r02/ab_inproc_window_matrix.txt).  A maintainer who prefers a small library builds with
+// -DNKA_WINDOW_WIDTH_STEP=4 (`make WIDTH_STEP=4`): widths 4, 8, ... 32 only, every other list length padded to the next one
+// -- same bits, nka_hip.o 3.4 -> 1.6 MB and 34 -> 18 s of compile time on this image's 8 cores (measured in round 5, DESIGN.md
+// section 4; libnka_hip.so 5.9 -> 4.1 MB: the other 2.9 MB are the abstract-vector kernels of vec_ops.o), at that price.
+#ifndef NKA_WINDOW_WIDTH_STEP
+#define NKA_WINDOW_WIDTH_STEP 1
+#endif
+static_assert(NKA_WINDOW_WIDTH_STEP == 1 || NKA_WINDOW_WIDTH_STEP == 4, "NKA_WINDOW_WIDTH_STEP: 1 (every width) or 4");
+#if NKA_WINDOW_WIDTH_STEP == 1
+#define NKA_WIDTH_CASES CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) \
+  CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) \
+  CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
+static inline int window_width(int w) { return w; }
+#else
+#define NKA_WIDTH_CASES CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+static inline int window_width(int w) { return ((std::max(w, 1) + 3) / 4) * 4; }
+#endif
 int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc) {
 #define CASE(L) \
   case L: return launch_dots_win_1<L, win_ring<L>()>(a, f, bpc);
-  switch (width) {
-    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
-    CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
-    CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
+  switch (window_width(width)) {
+    NKA_WIDTH_CASES
   }
 #undef CASE
   return 0;
@@ -453,13 +469,12 @@ int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) 
   // One vector per pair, tiles by tickets: a ring of 5 beats the ring of 4 (in-process A/B at m = 20:
   // 3.351 vs 3.406 ms at n = 1e8, 0.435 vs 0.442 at 1.25e7; ring of 10: 3.340 / 0.437), while the static
   // mapping prefers 4 (n = 1e7: 0.359 vs 0.366 ms).  Among the widths 1..32 only 20 has both divisors.
+  width = window_width(width);
   if (COMB == 2 && width == 20 && pb_tickets_apply(a)) return launch_combine_win_1<20, 2, 5>(a, f, bpc);
 #define CASE(K) \
   case K: return launch_combine_win_k<K, COMB>(a, f, bpc);
   switch (width) {
-    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
-    CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27)
-    CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
+    NKA_WIDTH_CASES
   }
 #undef CASE
   return 0;

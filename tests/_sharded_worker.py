@@ -92,6 +92,27 @@ def main():
             raise AssertionError("expected a RuntimeError")
         except RuntimeError as exc:
             assert "no hook left" in str(exc)
+        # the opt-in first step "p2p" (mailboxes through hipIpc): ONE rank cannot export its mailbox -> every rank takes part
+        # in the gather of the handles all the same (nobody is left waiting), learns of the failure, and moves on together
+        class P2PAcc(FakeAcc):
+            def p2p_export(self, nranks):
+                if rank == world - 1:
+                    raise OSError("hipIpcGetMemHandle refused")
+                return bytes(64)
+
+            def p2p_attach(self, handles, nranks, r):
+                raise AssertionError("attach must not be reached when an export failed")
+
+            def p2p_detach(self):
+                self.log.append("p2p-detach")
+
+            def set_dot_prod(self, fn):
+                pass
+        nd.attach_staged_allreduce = lambda acc, group=None: acc.log.append("staged")
+        nd.check_allreduce = lambda acc, r, w: True
+        fake = P2PAcc()
+        assert nd.attach_allreduce(fake, rank, world, prefer="p2p", ladder=("p2p", "staged")) == "staged"
+        assert fake.log == ["p2p-detach", "staged"], fake.log
         nd.attach_staged_allreduce = saved_staged
     finally:
         nd.rccl_preflight, nd.check_allreduce, nd.attach_torch_allreduce = saved

@@ -103,3 +103,60 @@ def test_raw_sums_switch_changes_last_bits_only_and_no_decision(oracle):
         assert a.state().list_order() == b.state().list_order()
         worst = max(worst, np.linalg.norm(fa - fb) / np.linalg.norm(x))
     assert 0 < worst < 1e-11
+
+
+# ---- the truth of the parity rule, checked INDEPENDENTLY: 60-digit restatement in mpmath ------------------
+@pytest.mark.parametrize("name", S.scenario_names())
+def test_extended_precision_truth_agrees_with_an_independent_60_digit_restatement(oracle, name):
+    """oracle/oracle_mp.py: the algorithm written a third time (other data structures, no shared code) in 60-digit
+    arithmetic.  On every golden scenario the extended-precision run -- the `exact` of tests/parity_util.py -- takes the
+    same decisions and returns the same vectors to FAR below the distances the rule measures: the truth's own uncertainty
+    is at most a thousandth of the reference's distance from it (or the rounding of its double outputs)."""
+    from oracle import oracle_mp
+    g = S.load(name)
+    n, m = int(g["n"]), int(g["mvec"])
+    ext, ref = oracle.OracleExact(n, m), oracle_mp.MpNKA(n, m)
+    orders = {"ext": [], "mp": []}
+    outs_e, tr_e = S.replay(ext, g, after_update=lambda u, a: orders["ext"].append(a.state().list_order()))
+    outs_m, tr_m = S.replay(ref, g, after_update=lambda u, a: orders["mp"].append(a.list_order()))
+    assert np.array_equal(tr_e, tr_m) and np.array_equal(tr_e, g["num_vec"])
+    assert orders["ext"] == orders["mp"]                                     # slot for slot
+    _, err_ref = P.fixture_truth(g, oracle)
+    ups = [int(i) for op, i, _ in g["ops"] if int(op) == 0]
+    for u, idx in enumerate(ups):
+        nx = max(float(np.linalg.norm(g["inputs"][idx])), 1e-300)
+        d = float(np.linalg.norm(outs_e[u] - outs_m[u])) / nx
+        assert d <= max(5e-16, 1e-3 * err_ref[u]), (name, u, d, err_ref[u])
+
+
+@pytest.mark.parametrize("seed,n,m", [(3069, 3, 21), (985, 5, 21), (1610, 7, 8), (11, 40, 6), (12, 9, 3)])
+def test_truth_on_random_sequences_of_the_sizes_where_the_soak_recorded_exceedances(oracle, seed, n, m):
+    """The exceedances of the soak (tests/golden/soak_cases.json) sit at n <= 9: ill-conditioned by construction (a handful
+    of elements, up to 21 vectors).  There the truth itself must be beyond doubt: random sequences of the soak's mix (fresh,
+    dependent, repeated and zero inputs, relax, restart, set_vec_tol) through the extended-precision run and the 60-digit one."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_ops import array_ops
+    from oracle import oracle_mp
+    rng = np.random.default_rng(seed)
+    ext, ref, dbl = oracle.OracleExact(n, m), oracle_mp.MpNKA(n, m), oracle.OracleNKA(n, m)
+    err_ref = 0.0
+    for step, op in enumerate(array_ops(rng, n, 60)):
+        if op[0] == "update":
+            x = op[1]
+            fe, fm, fd = x.copy(), x.copy(), x.copy()
+            ext.accel_update(fe); ref.accel_update(fm); dbl.accel_update(fd)
+            nx = float(np.linalg.norm(x))
+            if nx > 0 and ext.state().list_order() == dbl.state().list_order():
+                err_ref = max(err_ref, float(np.linalg.norm(fd - fm)) / nx)
+                d = float(np.linalg.norm(fe - fm)) / nx
+                assert d <= max(5e-16, 1e-3 * err_ref), (seed, step, d, err_ref)
+        elif op[0] == "relax":
+            ext.relax(); ref.relax(); dbl.relax()
+        elif op[0] == "restart":
+            ext.restart(); ref.restart(); dbl.restart()
+        elif op[0] == "set_vec_tol":
+            ext.set_vec_tol(op[1]); ref.set_vec_tol(op[1]); dbl.set_vec_tol(op[1])
+        assert ext.num_vec() == ref.num_vec(), (seed, step)
+        assert ext.state().list_order() == ref.list_order(), (seed, step)

@@ -1,0 +1,82 @@
+"""The soak's recorded exceedances as regression fixtures.  tests/golden/soak_cases.json names the
+sequences of the round-4 soak that ended beyond the truth rule's allowance -- by generator call (kind, seed, world), not by
+arrays.  Each one is replayed here through the same code the soak ran (tools/fuzz_gpu.py): decisions must still be exact
+after every call, and err_dev / err_ref at the end of the sequence may not exceed the RECORDED ratio x 1.25 -- the known draw
+passes, a real regression of the arithmetic trips."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+import parity_util as P
+import scenarios as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(ROOT, "tests", "golden", "soak_cases.json")) as _fh:
+    CASES = json.load(_fh)["cases"]
+SLACK = 1.25
+
+
+def _ids(kind):
+    return [pytest.param(c, id=f"{c['kind']}-seed{c['seed']}-{c['elements']}el") for c in CASES if c["kind"] == kind]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _judge(case, dev, ref):
+    assert ref > 0.0
+    ratio = dev / ref
+    assert ratio <= case["ratio"] * SLACK, (case["kind"], case["seed"], f"err_dev {dev:.3e} / err_ref {ref:.3e} = {ratio:.2f} x",
+                                            f"recorded {case['ratio']} x")
+    return ratio
+
+
+@pytest.mark.parametrize("case", _ids("array"))
+def test_array_flavour_soak_case(torch_cuda, oracle, case):
+    import fuzz_gpu
+    import nka_amd
+    key = fuzz_gpu.one_seed(case["seed"], torch_cuda, oracle, P, S, nka_amd, strict=False)       # (decisions: asserted inside)
+    assert case["shape"] in key, (key, case["shape"])                                            # the generator still draws this shape
+    rec = P.WORST[key]
+    _judge(case, rec["err_dev_exact"], rec["err_ref_exact"])
+
+
+@pytest.mark.parametrize("case", _ids("vector"))
+def test_abstract_vector_flavour_soak_case(oracle, tmp_path, case):
+    import fuzz_gpu
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "nka_amd", "fortran")], check=True)
+    key = fuzz_gpu.one_seed_vector(case["seed"], oracle, P, S, str(tmp_path), world=case["world"], strict=False)
+    assert case["shape"] in key, (key, case["shape"])
+    rec = P.WORST[key]
+    _judge(case, rec["err_dev_exact"], rec["err_ref_exact"])
+
+
+@pytest.mark.parametrize("case", _ids("sharded"))
+def test_sharded_array_flavour_soak_case(case, tmp_path):
+    """`world` ranks sharing the GPU, the sums staged through gloo (tools/fuzz_gpu.py --sharded): one record per rank."""
+    out = str(tmp_path / "seed.txt")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--sharded", str(case["world"]), "--first-seed",
+                        str(case["seed"]), "--seeds", "1", "--out", out], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    worst = 0.0
+    for r in range(case["world"]):
+        text = open(f"{out}.rank{r}").read()
+        assert "FAIL" not in text, text[-2000:]
+        mt = re.search(r"^(?:ok|stop)\s+(fuzz sharded seed %d .*?): dev-exact (\S+) ref-exact (\S+)" % case["seed"], text, re.M)
+        assert mt, text[-1000:]
+        assert case["shape"] in mt.group(1), (mt.group(1), case["shape"])
+        worst = max(worst, _judge(case, float(mt.group(2)), float(mt.group(3))))
+    assert worst > 0.0

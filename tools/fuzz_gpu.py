@@ -45,6 +45,35 @@ from fuzz_ops import SIZES, array_ops, array_shape  # noqa: E402,F401
 BEYOND = []      # (key, err_dev, tol, err_ref) of sequences beyond the truth rule's allowance (soak runs: recorded, not fatal)
 
 
+def elements_of(key):
+    """Vector length of a sequence from its key: `n=1660` (array flavours) or `4x257` (abstract-vector: fields x length)."""
+    import re
+    mt = re.search(r"\bn=(\d+)", key)
+    if mt:
+        return int(mt.group(1))
+    mt = re.search(r"\b(\d+)x(\d+)\b", key)
+    return int(mt.group(1)) * int(mt.group(2)) if mt else 0
+
+
+def known_cases():
+    """(kind-independent) seeds of the sequences recorded in tests/golden/soak_cases.json: the known draws."""
+    import json
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "soak_cases.json")) as fh:
+            return {f"seed {c['seed']} " for c in json.load(fh)["cases"]}
+    except OSError:
+        return set()
+
+
+def unexplained_beyond():
+    """a soak run must not END WELL with a sequence of more than one tile (n > 512) beyond the rule's allowance
+    unless it is one of the recorded draws (tests/golden/soak_cases.json: replayed by the suite with a cap on its ratio).
+    Exceedances within one tile stay recorded-only: there device and reference are two draws of one rounding-error
+    distribution (tests/parity_util.py: truth_factor)."""
+    known = known_cases()
+    return [b for b in BEYOND if elements_of(b[0]) > 512 and not any(k in b[0] + " " for k in known)]
+
+
 def _pairwise_dot(x, y):
     return float(np.add.reduce(np.asarray(x) * np.asarray(y)))
 
@@ -333,7 +362,8 @@ def sharded_worker(args):
     t0, seed = time.time(), args.first_seed
     out = open(f"{args.out}.rank{rank}", "w")
     while True:
-        go = torch.tensor([1 if time.time() - t0 < args.seconds else 0])
+        more = (seed - args.first_seed < args.seeds) if args.seeds else (time.time() - t0 < args.seconds)
+        go = torch.tensor([1 if more else 0])
         dist.broadcast(go, 0)
         if not int(go.item()):
             break
@@ -358,15 +388,18 @@ def sharded_worker(args):
     if rank == 0:
         print(f"# seeds {args.first_seed}..{seed - 1} ran to their end on {dist.get_world_size()} ranks; rank 0: largest share of the allowance "
               f"{rmax:.2f}, beyond it {len(BEYOND)}, per-call stops tripped {len(P.STOPS)}")
+    bad = torch.tensor([len(unexplained_beyond())])
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
-    return 0
+    return 2 if int(bad.item()) else 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--seeds", type=int, default=0, help="run exactly this many seeds (default: as many as fit --seconds)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz.txt"))
     ap.add_argument("--vector", action="store_true")
     ap.add_argument("--hostdot", action="store_true")
@@ -386,7 +419,7 @@ def main():
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.sharded}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--sharded-worker",
-               "--seconds", str(args.seconds), "--first-seed", str(args.first_seed), "--out", args.out]
+               "--seconds", str(args.seconds), "--first-seed", str(args.first_seed), "--seeds", str(args.seeds), "--out", args.out]
         return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")).returncode
     import tempfile
     import torch
@@ -400,7 +433,7 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     t0, seed, failed = time.time(), args.first_seed, []
     with open(args.out, "w") as out:
-        while time.time() - t0 < args.seconds:
+        while (seed - args.first_seed < args.seeds) if args.seeds else (time.time() - t0 < args.seconds):
             try:
                 if args.vector or args.vector_sharded:
                     with tempfile.TemporaryDirectory() as tmpdir:
@@ -428,8 +461,14 @@ def main():
                    f"distance so far, {P.TRUTH_HARD_TINY:g} x within one tile) tripped -- recorded, sequence continued: {len(P.STOPS)} "
                    f"{[(k, w) for k, w, _, _ in P.STOPS]}")
         out.write(summary + "\n")
+        bad = unexplained_beyond()
+        if bad:
+            line = (f"# NOT OK: {len(bad)} sequence(s) of more than 512 elements beyond the allowance that tests/golden/"
+                    f"soak_cases.json does not list: {[(k, f'{d:.2e}', f'{t:.2e}') for k, d, t, _ in bad]}")
+            out.write(line + "\n")
+            summary += "\n" + line
     print(summary)
-    return 1 if failed else 0
+    return 1 if failed else (2 if bad else 0)
 
 
 if __name__ == "__main__":
