@@ -206,12 +206,12 @@ def config5_abstract_vector(steps: int = 20):
             moved = 8.0 * n * words
             out[key] = {"value": ups, "ms_per_step": ms, "bytes_moved_per_update": moved,
                         "achieved_GBps": moved / (ms * 1e-3) / 1e9, "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                        "contract_bytes_ratio": 8.0 * n * (11 + 3 * m) / moved,
                         "byte_model": ("8n(8+3m)" if compact == "0" else "8n(9+2m)")
                                       + ": update_norm2_dots 2+m (ONE pure-read pass for the norm and both inner-product "
                                       "rows; the normalisation of the new pair deferred to the combine), "
                                       "update/axpy_many_keep " + ("6+2m" if compact == "0" else "7+m")}
             if compact == "0":      # B_alg bounds the traffic of the reference rounding only (ratio 1.04): the BASELINE.md-style rate
+                out[key]["contract_bytes_ratio"] = 8.0 * n * (11 + 3 * m) / moved
                 out[key]["contract_GBps"] = 8.0 * n * (11 + 3 * m) / (ms * 1e-3) / 1e9
                 out[key]["contract_frac_of_peak"] = out[key]["contract_GBps"] / HBM_PEAK_GBPS
         except Exception as exc:   # an extra, never the measured path
@@ -267,15 +267,20 @@ def words_moved(flavor: str, L: int, k: int, out_of_place: bool = False):
     w; PB reads f and the k pairs (one vector per pair with compact storage, the
     pending pair always as two) and writes w1', v1', w_new, v_new, f -- out of place
     (nka_hip_accel_update_swap) w1', v1', v_new only."""
-    pb_reads = (2 + k) if flavor == "c" else (1 + 2 * k)
-    return {"PA_k_dots": 2 + L, "PB_k_combine": pb_reads + (3 if out_of_place else 5)}
+    # lists longer than 32 take the multi-pass kernels (k_dots / k_combine in passes of 32): every further pass of PA reads
+    # f and w1 again, every further pass of PB reads the running f and stores it once more
+    npa, npb = max(1, -(-L // 32)), max(1, -(-k // 32))
+    pb_reads = (1 + k) if flavor == "c" else (2 * k)
+    return {"PA_k_dots": L + 2 * npa, "PB_k_combine": pb_reads + npb + (2 if out_of_place else 4) + npb}
 
 
 def pmc_traffic(flavor: str, n_local: int, m: int):
     """HBM bytes per launch from the newest rocprofv3 PMC summary of THIS workload
     (tools/rocprof_bench.sh + tools/pmc_summary.py, committed under profiles/)."""
     import glob
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{flavor}.json")), reverse=True):
+    cands = glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{flavor}.json")) + \
+        glob.glob(os.path.join(ROOT, "profiles", "r*", "*", f"pmc_traffic_{flavor}.json"))      # (shard sizes: profiles/rNN/shard_<n>/)
+    for cand in sorted(cands, reverse=True):
         try:
             with open(cand) as fh:
                 pm = json.load(fh)
@@ -753,6 +758,43 @@ def main(argv=None):
     k_steady = m if args.workload == "full" else min(m, args.drop_dim)     # vectors the subspace holds in steady state
     steady = (nv == k_steady)
 
+    # the ONE exchange of a sharded update by itself: 2 + 2 mvec doubles through the installed hook, back to back on the kernel
+    # stream (device events; max over ranks) -- the latency figure that decides between RCCL and the peer-to-peer exchange
+    exchange = None
+    if world > 1 or hook_box[0] != "none":
+        # (every rank passes the same two barriers whatever happens locally)
+        err, us_local = None, 0.0
+        reps = 200 if hook_box[0] != "staged" else 20
+        xb = torch.zeros(2 + 2 * m, dtype=torch.float64, device=dev)
+        try:
+            for _ in range(20):
+                acc.allreduce_now(xb)
+        except Exception as exc:      # an extra, never the measured path
+            err = repr(exc)
+        sync_all()
+        try:
+            if err is None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    acc.allreduce_now(xb)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                us_local = e0.elapsed_time(e1) / reps * 1e3
+        except Exception as exc:
+            err = repr(exc)
+        sync_all()
+        us = torch.tensor([us_local if err is None else float("inf")], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(us, op=dist.ReduceOp.MAX)
+        if float(us.item()) != float("inf"):
+            exchange = {"hook": hook_box[0], "doubles": 2 + 2 * m, "us_back_to_back": float(us.item()), "reps": reps,
+                        "what": "nka_hip_allreduce_now through the installed hook, back to back on the kernel stream, device events, "
+                                "max over ranks; inside an update the exchange sits between the final sums and the scalar step "
+                                "(the peer-to-peer exchange is then fused into those two kernels: no kernel of its own)"}
+        else:
+            exchange = {"error": err or "failed on another rank"}
+
     # what every rank saw: which GPU, which RCCL, how many ranks ITS communicator connected, its digest of the
     # replicated state -- so that a multi-GPU record proves by itself that RCCL reduced over N ranks
     rank_info = None
@@ -943,6 +985,10 @@ def main(argv=None):
             out["replica_check"] = replica_check
         if rank_info:
             out["ranks"] = rank_info
+        if exchange:
+            out["exchange"] = exchange
+            if "us_back_to_back" in exchange:
+                out["roofline"]["exchange_us_back_to_back"] = exchange["us_back_to_back"]      # (flat: survives a scalars-only record)
         if hook_box[0] == "rccl":
             out["config"]["rccl_library"] = nka_amd.nka.rccl_library()
         if also is not None:

@@ -77,6 +77,23 @@ def main():
         dist.barrier()                           # (nobody frees a mailbox a peer may still write into)
         a.delete(); b.delete()
 
+    # ---- the same mailboxes as the transport of the reference-order chain: the single-rank reference's bits ------
+    n, m = 5003, 5
+    lo, hi = nd.slice_bounds(n, world, rank)
+    e = nka_amd.nka().init(hi - lo, m, flavor=0)
+    assert nd.attach_allreduce(e, rank, world, prefer="p2p", ladder=("p2p",)) == "p2p"
+    e.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+    full = O.OracleNKA(n, m, 0)
+    for t in range(10):
+        x = synth.fill_numpy(99, t, 0, n, n)
+        f = x.copy()
+        full.accel_update(f)
+        ft = torch.from_numpy(x[lo:hi].copy()).cuda()
+        e.accel_update(ft)
+        assert np.array_equal(ft.cpu().numpy(), f[lo:hi]), (rank, t)
+    dist.barrier()
+    e.delete()
+
     # ---- the ladder: one rank cannot export -> EVERY rank runs the next hook ---------------------------------
     c = nka_amd.nka().init(1000, 3)
     if rank == world - 1:

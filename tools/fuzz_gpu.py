@@ -283,7 +283,14 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
     n = int(rng.choice([1, 2, 3, 4, 5, 7, 255, 512, 513, 1025, 2049, 4099])) if rng.random() < 0.7 else int(rng.integers(1, 9000))
     m = int(rng.integers(1, 25))
     flavor = int(rng.integers(0, 3))
-    key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}"
+    # Round 5: seeds from 100 000 on rotate through the transports and sum modes that round added -- the peer-to-peer exchange
+    # (mailboxes through hipIpc) in place of the staged hook on odd seeds, and on every other pair of seeds the sums in the
+    # reference's order, continued from rank to rank: the outputs must then be the unsharded oracle's BITS after every call.
+    # (Seeds below 100 000 keep their meaning: tests/golden/soak_cases.json names some of them.)
+    p2p = seed >= 100_000 and seed % 2 == 1
+    same_bits = seed >= 100_000 and (seed // 2) % 2 == 1
+    key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}" + \
+          ((" p2p" if p2p else " staged") + (" sums reference" if same_bits else " sums blocked") if seed >= 100_000 else "")
     lo, hi = nd.slice_bounds(n, world, rank)
 
     def hook(ptr, count, stream):
@@ -292,8 +299,17 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         dev.copy_(host)
 
-    acc = nka_amd.nka().init(hi - lo, m, flavor=flavor)
-    acc.set_dot_prod(hook)
+    def attach(a):
+        if p2p:
+            nd.attach_p2p(a, rank, world)
+        else:
+            a.set_dot_prod(hook)
+        a.set_shard(rank, world)
+        if same_bits:
+            a.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+        return a
+
+    acc = attach(nka_amd.nka().init(hi - lo, m, flavor=flavor))
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)
     basis = rng.standard_normal((3, n))
@@ -321,6 +337,8 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
                 acc.accel_update(ft)
             out = ft.cpu().numpy()
             nx = np.linalg.norm(x)
+            if same_bits:
+                assert np.array_equal(out, f[lo:hi]), (key, rank, step, float(np.abs(out - f[lo:hi]).max()) if hi > lo else 0.0)
             if nx > 0:
                 # this rank's share of the global error (the slices' squares add up to the whole)
                 P.check(float(np.linalg.norm(out - f[lo:hi]) / nx), acc.state(), key, where=step, spread=spread.value,
@@ -334,6 +352,13 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
         elif r < 0.96:
             vt = float(10.0 ** rng.uniform(-3, -0.3))
             acc.set_vec_tol(vt); ora.set_vec_tol(vt); spread.set_vec_tol(vt)
+        elif p2p:
+            # a deep copy does not inherit the mailboxes (they belong to the original, like an RCCL communicator): the copy
+            # refuses to run until it has a reduction of its own -- attach one, collectively, and let the original go
+            new = acc.copy()
+            dist.barrier()
+            acc.delete()
+            acc = attach(new)
         else:
             acc = acc.copy()
         sa, so = acc.state(), ora.state()
@@ -342,6 +367,9 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
         digs = nd.replica_digests(acc)
         assert all(d == digs[0] for d in digs), (key, rank, step, digs)
     assert acc.defined(), key
+    if p2p:
+        dist.barrier()                              # (nobody frees a mailbox a peer may still write into)
+        acc.delete()
     BEYOND.extend(P.finish([key], strict))          # the truth rule, per sequence (tests/parity_util.py)
     return key
 
