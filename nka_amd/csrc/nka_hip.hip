@@ -320,22 +320,22 @@ int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) 
   const int g = grid_for(a, 0, VEC, occ, MAXL + 2);
   hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, g, pass, npass * MAXL, a->p2p_fused ? a->p2p : P2P{});
+                     a->partials, g, pass, npass * MAXL, pass * MAXL, a->p2p_fused ? a->p2p : P2P{});
   return g;
 }
 
 // rolling-window PA: ring of W registers, `bpc` blocks per CU
 template <int MAXL, int W>
-int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc) {
+int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc, int base, int pass, int ncover) {
   static const int occ = occupancy_of(k_dots_win<MAXL, W>);
   const int64_t ntile = a->n / (kBlock * 2);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
-  hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials);
+  hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, base);
   // (Round 3 measured forming these sums -- and the scalar step -- in the tail of the PA launch, by the block that
   //  finishes last: 2-4 us SLOWER per update than the launches it saves, profiles/r03/ab_small_pa_tail_not_kept.txt.)
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, (int)g, 0, MAXL, a->p2p_fused ? a->p2p : P2P{});
+                     a->partials, (int)g, pass, ncover < 0 ? MAXL : ncover, base, a->p2p_fused ? a->p2p : P2P{});
   return (int)g;
 }
 
@@ -375,9 +375,10 @@ static inline int window_width(int w) { return w; }
 #define NKA_WIDTH_CASES CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
 static inline int window_width(int w) { return ((std::max(w, 1) + 3) / 4) * 4; }
 #endif
-int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc) {
+// (base, pass, ncover: the balanced passes of a list longer than kMaxPerPass, enqueue_pa; one launch: 0, 0, its own width)
+int launch_dots_win(int width, const nka_hip_state *a, const double *f, int bpc, int base = 0, int pass = 0, int ncover = -1) {
 #define CASE(L) \
-  case L: return launch_dots_win_1<L, win_ring<L>()>(a, f, bpc);
+  case L: return launch_dots_win_1<L, win_ring<L>()>(a, f, bpc, base, pass, ncover);
   switch (window_width(width)) {
     NKA_WIDTH_CASES
   }
@@ -425,7 +426,7 @@ int launch_combine_w(int maxk, const nka_hip_state *a, double *f, int pass, int 
 // rolling-window PB: ring of W pairs, `bpc` blocks per CU; every width 1..32 (no padding);
 // T = 16-byte pieces per thread, stream and tile (2 only for short lists, see launch_combine_win_k)
 template <int MAXK, int COMB, int W, int T = 1>
-int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc, int base) {
   static const int occ = occupancy_of(k_combine_win<MAXK, COMB, W, T>);
   const int64_t ntile = a->n / (kBlock * 2 * T);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
@@ -440,7 +441,7 @@ int launch_combine_win_1(const nka_hip_state *a, double *f, int bpc) {
   if (ng > 0 && (g % ng != 0 || ntile >= ((int64_t)1 << 31) - 2 * kMaxGrid || !a->tickets)) ng = 0;
   const int tail = (ntile * (kBlock * 2 * T) < a->n) ? 1 : 0;     // the ragged tail has a block of its own (k_combine_win)
   hipLaunchKernelGGL((k_combine_win<MAXK, COMB, W, T>), dim3((int)g + tail), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f,
-                     ng > 0 ? a->tickets : nullptr, std::max(ng, 1), a->pb_flags);
+                     ng > 0 ? a->tickets : nullptr, std::max(ng, 1), a->pb_flags, base);
   return (int)g;
 }
 
@@ -455,24 +456,24 @@ bool pb_tickets_apply(const nka_hip_state *a) {
 // 1.733); from m = 10 (17 words) on the narrow tile with two counters is as good or better
 // (2.110 vs 2.148 ms; two-vector m = 5, 16 words: 2.040 vs 2.028) -- profiles/r02/ab_inproc_tile_tickets.txt.
 template <int K, int COMB>
-int launch_combine_win_k(const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win_k(const nka_hip_state *a, double *f, int bpc, int base) {
   constexpr int W = (COMB == 2 ? win_ring<K>() : win_ring_pairs<K>());
   constexpr int words = (COMB == 2 ? K + 2 : 2 * K + 1) + 5;
   if constexpr (words <= 14) {
-    if (a->pb_tile == 2 || (a->pb_tile < 0 && pb_tickets_apply(a))) return launch_combine_win_1<K, COMB, W, 2>(a, f, bpc);
+    if (a->pb_tile == 2 || (a->pb_tile < 0 && pb_tickets_apply(a))) return launch_combine_win_1<K, COMB, W, 2>(a, f, bpc, base);
   }
-  return launch_combine_win_1<K, COMB, W, 1>(a, f, bpc);
+  return launch_combine_win_1<K, COMB, W, 1>(a, f, bpc, base);
 }
 
 template <int COMB>
-int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc, int base) {
   // One vector per pair, tiles by tickets: a ring of 5 beats the ring of 4 (in-process A/B at m = 20:
   // 3.351 vs 3.406 ms at n = 1e8, 0.435 vs 0.442 at 1.25e7; ring of 10: 3.340 / 0.437), while the static
   // mapping prefers 4 (n = 1e7: 0.359 vs 0.366 ms).  Among the widths 1..32 only 20 has both divisors.
   width = window_width(width);
-  if (COMB == 2 && width == 20 && pb_tickets_apply(a)) return launch_combine_win_1<20, 2, 5>(a, f, bpc);
+  if (COMB == 2 && width == 20 && pb_tickets_apply(a)) return launch_combine_win_1<20, 2, 5>(a, f, bpc, base);
 #define CASE(K) \
-  case K: return launch_combine_win_k<K, COMB>(a, f, bpc);
+  case K: return launch_combine_win_k<K, COMB>(a, f, bpc, base);
   switch (width) {
     NKA_WIDTH_CASES
   }
@@ -480,13 +481,19 @@ int launch_combine_win_w(int width, const nka_hip_state *a, double *f, int bpc) 
   return 0;
 }
 
-int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f, int bpc) {
+int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f, int bpc, int base = 0) {
   switch (flavor) {
-    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_win_w<1>(width, a, f, bpc);
-    case NKA_HIP_FLAVOR_C: return launch_combine_win_w<2>(width, a, f, bpc);
-    default: return launch_combine_win_w<0>(width, a, f, bpc);
+    case NKA_HIP_FLAVOR_F08_VECTOR: return launch_combine_win_w<1>(width, a, f, bpc, base);
+    case NKA_HIP_FLAVOR_C: return launch_combine_win_w<2>(width, a, f, bpc, base);
+    default: return launch_combine_win_w<0>(width, a, f, bpc, base);
   }
 }
+
+// A list of `total` > kMaxPerPass entries in the fewest passes of BALANCED widths (33 -> 17 + 16, 70 -> 24 + 23 + 23): every
+// pass then runs the rolling-window kernel at (nearly) its exact width instead of one full pass of 32 and one that is mostly
+// padding (measured in round 5, profiles/r05/multipass.txt: mvec = 33 at 0.58 of the roofline against 0.76 at mvec = 32).
+static inline int balanced_passes(int total) { return (total + kMaxPerPass - 1) / kMaxPerPass; }
+static inline int balanced_width(int total, int npass, int p) { return total / npass + (p < total % npass ? 1 : 0); }
 
 int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
 
@@ -926,7 +933,15 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
     else if (nl <= 11) ROWS(11);
     else if (nl <= 21) ROWS(21);
     else if (nl <= 33) ROWS(33);
-    else ROWS(48);
+    else if (nl <= 48) ROWS(48);
+    else {
+      // 49..63 list entries (mvec 48..62): the working arrays exceed the 64 KiB a kernel gets without asking
+      static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_rows<63>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)solve_wave_smem_bytes(kSolveWaveMax - 1));
+      if (raised != hipSuccess) return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+      ROWS(63);
+    }
 #undef ROWS
   } else {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), a->state_in_global ? 0 : lst_smem_bytes(a->mvec), s, a->ctl, mode,
@@ -953,6 +968,13 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
   if (pa_pipe < 0) pa_pipe = exact ? 201 : 0;
   if (vec == 2 && npass == 1 && pa_pipe > 200 && pa_pipe < 210) {     // rolling window, 200 + blocks per CU
     launch_dots_win(exact ? older_ub : maxl, a, f, std::max(1, pa_pipe - 200));
+  } else if (vec == 2 && older_ub > kMaxPerPass && a->pa_pipe != 0) {  // a long list: balanced passes of the window kernel
+    const int np = balanced_passes(older_ub);
+    for (int p = 0, base = 0; p < np; p++) {
+      const int w = balanced_width(older_ub, np, p);
+      launch_dots_win(w, a, f, a->pa_pipe > 200 ? a->pa_pipe - 200 : 1, base, p, older_ub);
+      base += w;
+    }
   } else {
     for (int p = 0; p < npass; p++) {
       if (vec == 2) launch_dots_w(maxl, a, f, p, npass);
@@ -981,6 +1003,20 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   }
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
     launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (vec == 2 && comb_ub > kMaxPerPass && a->pb_pipe != 0 && !(a->pb_flags & (kPbNoStoreW | kPbNoStoreF))) {
+    // a long list, in place: balanced passes of the window kernel, f carrying the running value (k_combine_win, PASSES);
+    // the out-of-place entry keeps the all-loads-in-flight passes below (its running value lives in v_new)
+    const int np = balanced_passes(comb_ub), keep = a->pb_flags;
+    for (int p = 0, base = 0; p < np; p++) {
+      const int w = balanced_width(comb_ub, np, p);
+      a->pb_flags = keep | (p > 0 ? kPbNotFirst : 0) | (p + 1 < np ? kPbNotLast : 0);
+      launch_combine_win(a->flavor, w, a, f, a->pb_pipe > 200 ? a->pb_pipe - 200 : 1, base);
+      base += w;
+    }
+    a->pb_flags = keep;
     HIP_TRY(hipGetLastError());
     return 0;
   }

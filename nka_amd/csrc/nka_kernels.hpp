@@ -487,9 +487,12 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 // with vector j+W of this tile or vector j+W-MAXL of the block's next tile), and f, w1
 // of the next tile are requested as soon as this tile's copies are in d / fq.  Same
 // products, same per-thread accumulation order => same bits as k_dots.  Single pass, VEC = 2.
+// `base` (round 5): the first plan entry of this launch.  A list longer than kMaxPerPass is served by several launches of
+// BALANCED exact widths (33 = 17 + 16: enqueue_pa), each on its own part of the plan; only the launch with base == 0 has its
+// first two sums (d^2, <f,d>) used (k_finalize_dots).
 template <int MAXL, int W>
 __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                     double *__restrict__ partials) {
+                                                     double *__restrict__ partials, int base) {
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr int NACC = 2 * MAXL + 2;
@@ -497,8 +500,8 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   NKA_STAMP0(ctl, 10);
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
-  const int nolder = ctl.ic[IC_PLAN_NOLDER];
-  const long long *pw = ctl.plan_w();
+  const int nolder = ctl.ic[IC_PLAN_NOLDER] - base;        // entries of the plan from `base` on (<= 0: none, every slot dead)
+  const long long *pw = ctl.plan_w() + base;
   const double *w1p = vs.w + ctl.pc[PC_FIRST_W];           // (read whether pending or not: no branch around a load)
   const double *w1 = pending ? w1p : f;
   // every plan slot is requested at once, whether the list reaches it or not (the plan array is longer than any
@@ -589,7 +592,7 @@ constexpr int kFinThreads = 64;
 // scalar step gathers them; red[] is then written by that gather.
 template <int MAXL>
 __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const double *__restrict__ partials, int G,
-                                                               int pass, int ncover, P2P x) {
+                                                               int pass, int ncover, int base, P2P x) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
   const bool p2p = x.base != nullptr;
@@ -601,7 +604,8 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
   r = wave_sum(r);
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int pending = ctl.ic[IC_PLAN_PENDING];
-  const int base = pass * MAXL;
+  // (`base` = first plan entry of this pass: pass * MAXL for the passes of equal width, the running sum of the widths
+  //  for the balanced passes of the window kernels)
   if (pass == 0 && c == 0)
     for (int p = ncover + lane; p < ctl.mvec; p += kFinThreads) {
       if (p2p) {
@@ -854,6 +858,8 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
 // w1' = (w1-f)/s, v1' = v1/s formed in registers and stored back.  The last pass
 // stores v_new = f_out.
 enum { kPbNoStoreW = 1, kPbNoStoreF = 2,     // `flags` of PB in an out-of-place update (nka_hip_accel_update_swap)
+       kPbNotFirst = 8, kPbNotLast = 16,      // rolling-window PB over a list longer than kMaxPerPass: not the first / not the
+                                              // last of its passes (enqueue_pb; in place only)
        kPbReverse = 4 };                      // rolling-window PB: walk the tiles from the END of the vectors, i.e. in the
                                               // reverse of PA's order (diagnostic builds only, see NKA_F_TEMPORAL)
 
@@ -1021,8 +1027,13 @@ __device__ __forceinline__ void ticket_finish(unsigned *tickets, int ng, int G) 
   }
 }
 
+// PASSES (round 5).  A list longer than kMaxPerPass pairs is combined by several launches of balanced exact widths, each on
+// the pairs [base, base + MAXK) of the plan, f carrying the running value in between (the k loop of F08:395-399 cut into
+// consecutive pieces: same statements in the same order, same bits).  The FIRST pass (no kPbNotFirst) normalises the pending
+// pair -- pair 0 of the plan -- and stores w_new = f_in; the LAST (no kPbNotLast) stores v_new = f_out; every pass stores f.
 template <int MAXK, int COMB, int W, int T = 1>
-__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng, int flags) {
+__global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double *f, unsigned *tickets, int ng, int flags,
+                                                        int base) {
   // T = 16-byte pieces per thread, stream and tile (tile = 512*T elements, 4*T KiB per stream and
   // block): T = 2 halves the ticket rate, which is what lets SHORT lists use one counter (a
   // single counter saturates near 60-75 tickets/us; tools/hbm_probe mode i: 12 + 5 streams move
@@ -1042,14 +1053,16 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
   const bool has_tail = ntile * TILE < vs.n;
   const int G = (int)gridDim.x - (has_tail ? 1 : 0);       // tile blocks
   const bool tail_block = has_tail && (int)blockIdx.x == G;
-  const int ncomb = ctl.ic[IC_NCOMB];
+  const int ncomb_all = ctl.ic[IC_NCOMB];
+  const int ncomb = ncomb_all - base;                      // pairs of the plan from `base` on (this launch applies the first MAXK)
   double *wnew = vs.w + ctl.pc[PC_NEW_W], *vnew = vs.w + ctl.pc[PC_NEW_V];
-  const long long *cw = ctl.comb_w(), *cv = ctl.comb_v();
-  const double *cc = ctl.comb_c();
+  const long long *cw = ctl.comb_w() + base, *cv = ctl.comb_v() + base;
+  const double *cc = ctl.comb_c() + base;
   // (uniform: out-of-place update.  The two scalar branches around the stores cost the in-place path nothing measurable:
   //  interleaved A/B against a build with unconditional stores, profiles/r04/ab_pb_flags.txt)
-  const bool store_w = !(flags & kPbNoStoreW), store_f = !(flags & kPbNoStoreF);
-  const bool norm0 = ctl.ic[IC_NORMED] != 0;
+  const bool first_pass = !(flags & kPbNotFirst), last_pass = !(flags & kPbNotLast);
+  const bool store_w = !(flags & kPbNoStoreW) && first_pass, store_f = !(flags & kPbNoStoreF), store_v = last_pass;
+  const bool norm0 = first_pass && ctl.ic[IC_NORMED] != 0;
   const double s = ctl.dc[DC_S];
   const double rs = 1.0 / s;
 
@@ -1100,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
         rv[j][q] = ld<VEC>(vk[j] + DEAD_OFF(j < ncomb, e) + q * (kBlock * VEC));
       }
   }
-  list_word_publish(ctl, ncomb, flags & kPbNoStoreW);      // (behind the first ring of loads: nothing waits for it)
+  if (first_pass) list_word_publish(ctl, ncomb_all, flags & kPbNoStoreW);      // (behind the first ring of loads: nothing waits for it)
   // ticket counter of this block's group; ticket k of group g is tile (k + 2G/ng)*ng + g
   const unsigned grp = tickets ? blockIdx.x % (unsigned)ng : 0u;
   unsigned *const my_ticket = tickets ? tickets + grp * kTicketStride : nullptr;
@@ -1175,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
     }
 #pragma unroll
     for (int q = 0; q < T; q++) {
-      st(vnew + e + q * (kBlock * VEC), x[q]);
+      if (store_v) st(vnew + e + q * (kBlock * VEC), x[q]);
       if (store_f) st(f + e + q * (kBlock * VEC), x[q]);
     }
 #ifdef NKA_SOLVE_STAMPS
@@ -1207,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_win(Ctl ctl, Vecs vs, double
         }
       }
       if (store_w) wnew[i] = fin;
-      vnew[i] = x;
+      if (store_v) vnew[i] = x;
       if (store_f) f[i] = x;
     }
   }
@@ -1527,7 +1540,7 @@ static __global__ __launch_bounds__(kSolveThreads) __attribute__((unused)) void 
 // to lanes, LDS column exchange with two barriers per column: 42.9 k), a ds_bpermute variant
 // (50 k, not kept), this one: 26.4 k.  The rare path without a new pair (after relax / s == 0)
 // keeps the first version's gather-and-substitute code.
-constexpr int kSolveWaveMax = 48;
+constexpr int kSolveWaveMax = 63;     // (round 5: 48 -> 63, one more instantiation: the lanes were there; mvec <= 62)
 
 __host__ __device__ inline size_t solve_wave_smem_bytes(int mvec) {
   const int nl = mvec + 1;

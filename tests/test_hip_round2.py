@@ -128,10 +128,12 @@ def test_state_digest_tracks_the_replicated_state(torch_cuda):
     assert a.state_digest() != b.state_digest()     # one perturbed element changes the sums
 
 
-@pytest.mark.parametrize("m", [47, 48, 90, 140])
+@pytest.mark.parametrize("m", [47, 48, 62, 63, 90, 140])
 def test_large_mvec_up_to_the_lds_limit(torch_cuda, oracle, m):
-    """mvec up to the documented limit of 140: the wavefront solve (mvec+1 <= 48),
-    the one-lane solve beyond, and the opt-in above 64 KiB of dynamic LDS (mvec >= 88)."""
+    """mvec up to the documented limit of 140: the wavefront solve (mvec+1 <= 63 since round 5: 47 / 48 straddle the
+    48-row instantiation, 62 is the last subspace of the 63-row one, which needs more than 64 KiB of dynamic LDS), the
+    one-lane solve beyond (63, 90, 140), and its opt-in above 64 KiB (mvec >= 88).  Lists longer than 32 also exercise the
+    balanced passes of the window kernels (33..64 entries in two passes, 65..96 in three, ...)."""
     import nka_amd
     n = 600
     rng = np.random.default_rng(m)
