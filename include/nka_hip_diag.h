@@ -30,7 +30,11 @@ extern "C" {
  * "serial_solve" = 0/1: the scalar step on one wavefront (k_solve_rows) or as the reference's loops on one lane.
  * Results are bit-identical across variants.
  * "list_word" = 0/1: 0 ignores (and stops publishing) the list word -- the host's own count of the list length
- * only, the behaviour before round 4 (nka_hip_list_bound). */
+ * only, the behaviour before round 4 (nka_hip_list_bound).
+ * Round 5: "pb_reverse" = 0/1: the rolling-window PB walks its tiles from the END of the vectors, the reverse of PA's order
+ * (the Infinity-Cache study, profiles/r05/ab_mall_reuse.txt).  "prime_pad": list lengths 23, 29, 31 are primes, the only
+ * ring of their window kernels is the whole width (up to 311 VGPRs and scratch in PA): -1 automatic (= 1) both passes run them
+ * at the next width with one dead ring slot; 0 = exact widths everywhere (profiles/r05/multipass.txt).  Same bits. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */

@@ -226,6 +226,10 @@ struct nka_hip_state {
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
   int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
+  int prime_pad = -1;         // list lengths 23, 29, 31 (primes: the only ring of their window kernels is the whole width -- up to 311
+                              // VGPRs and scratch in PA, every load of a tile in flight in PB) run the next width with ONE dead ring
+                              // slot: -1 / 1 on (automatic), 0 off.  In-process A/B at n = 1e7 (profiles/r05/multipass.txt): update
+                              // -12.7 % at m = 31, -3.4 % at 29, -0.3 % at 23 (compact); -11 / -4.4 / -2.9 % in the src-F08 rounding
   bool state_in_global = false;  // mvec > 140: h, c and the links no longer fit the LDS of one CU; the one-lane
                                  // scalar kernels then work on the control block in global memory (slow, unlimited)
   bool serial_solve = false;  // NKA_HIP_SERIAL_SOLVE=1: reference loops verbatim on one lane
@@ -493,7 +497,20 @@ int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f,
 // pass then runs the rolling-window kernel at (nearly) its exact width instead of one full pass of 32 and one that is mostly
 // padding (measured in round 5, profiles/r05/multipass.txt: mvec = 33 at 0.58 of the roofline against 0.76 at mvec = 32).
 static inline int balanced_passes(int total) { return (total + kMaxPerPass - 1) / kMaxPerPass; }
-static inline int balanced_width(int total, int npass, int p) { return total / npass + (p < total % npass ? 1 : 0); }
+// The widths whose only ring is the whole width (win_ring / win_ring_pairs: primes) AND large: 23, 29, 31.
+static inline bool heavy_prime(int w) { return w == 23 || w == 29 || w == 31; }
+// widths[0..np): balanced, then one vector moved between two passes wherever that removes a heavy prime without making another
+static inline void balanced_widths(int total, int np, int *w) {
+  for (int p = 0; p < np; p++) w[p] = total / np + (p < total % np ? 1 : 0);
+  for (int i = 0; i < np; i++) {
+    if (!heavy_prime(w[i])) continue;
+    for (int j = 0; j < np; j++) {
+      if (j == i) continue;
+      if (w[i] + 1 <= kMaxPerPass && w[j] > 1 && !heavy_prime(w[j] - 1)) { w[i]++; w[j]--; break; }          // (w[i] + 1 is even)
+      if (w[j] + 1 <= kMaxPerPass && !heavy_prime(w[j] + 1) && !heavy_prime(w[i] - 1)) { w[i]--; w[j]++; break; }
+    }
+  }
+}
 
 int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
 
@@ -853,6 +870,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_pipe = src->pb_pipe;
   b->pb_tile = src->pb_tile;
   b->pb_tickets = src->pb_tickets;
+  b->prime_pad = src->prime_pad;
   b->serial_solve = src->serial_solve;
   b->sum_order = src->sum_order;
   b->shard_rank = src->shard_rank;
@@ -967,13 +985,16 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
   const bool exact = vec == 2 && older_ub >= 1 && older_ub <= kMaxPerPass;
   if (pa_pipe < 0) pa_pipe = exact ? 201 : 0;
   if (vec == 2 && npass == 1 && pa_pipe > 200 && pa_pipe < 210) {     // rolling window, 200 + blocks per CU
-    launch_dots_win(exact ? older_ub : maxl, a, f, std::max(1, pa_pipe - 200));
+    int w = exact ? older_ub : maxl;
+    if (a->prime_pad != 0 && heavy_prime(w)) w++;       // one dead ring slot instead of a ring as wide as the list (state: prime_pad)
+    launch_dots_win(w, a, f, std::max(1, pa_pipe - 200));
   } else if (vec == 2 && older_ub > kMaxPerPass && a->pa_pipe != 0) {  // a long list: balanced passes of the window kernel
     const int np = balanced_passes(older_ub);
+    std::vector<int> wd((size_t)np);
+    balanced_widths(older_ub, np, wd.data());
     for (int p = 0, base = 0; p < np; p++) {
-      const int w = balanced_width(older_ub, np, p);
-      launch_dots_win(w, a, f, a->pa_pipe > 200 ? a->pa_pipe - 200 : 1, base, p, older_ub);
-      base += w;
+      launch_dots_win(wd[(size_t)p], a, f, a->pa_pipe > 200 ? a->pa_pipe - 200 : 1, base, p, older_ub);
+      base += wd[(size_t)p];
     }
   } else {
     for (int p = 0; p < npass; p++) {
@@ -1002,7 +1023,9 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
     pipe = (a->flavor == NKA_HIP_FLAVOR_C || tickets || (double)a->n * (2.0 * comb_ub + 6.0) >= 1.0e9) ? 201 : 0;
   }
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
-    launch_combine_win(a->flavor, std::max(comb_ub, 1), a, f, pipe - 200);     // exact width: no padding
+    int w = std::max(comb_ub, 1);                                             // exact width: no padding ...
+    if (a->prime_pad != 0 && heavy_prime(w)) w++;                            // ... but for 23, 29, 31 (see prime_pad): one dead slot
+    launch_combine_win(a->flavor, w, a, f, pipe - 200);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1010,11 +1033,12 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
     // a long list, in place: balanced passes of the window kernel, f carrying the running value (k_combine_win, PASSES);
     // the out-of-place entry keeps the all-loads-in-flight passes below (its running value lives in v_new)
     const int np = balanced_passes(comb_ub), keep = a->pb_flags;
+    std::vector<int> wd((size_t)np);
+    balanced_widths(comb_ub, np, wd.data());
     for (int p = 0, base = 0; p < np; p++) {
-      const int w = balanced_width(comb_ub, np, p);
       a->pb_flags = keep | (p > 0 ? kPbNotFirst : 0) | (p + 1 < np ? kPbNotLast : 0);
-      launch_combine_win(a->flavor, w, a, f, a->pb_pipe > 200 ? a->pb_pipe - 200 : 1, base);
-      base += w;
+      launch_combine_win(a->flavor, wd[(size_t)p], a, f, a->pb_pipe > 200 ? a->pb_pipe - 200 : 1, base);
+      base += wd[(size_t)p];
     }
     a->pb_flags = keep;
     HIP_TRY(hipGetLastError());
@@ -1916,6 +1940,9 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
     a->pb_tickets = value;
+  } else if (k == "prime_pad") {      // -1 automatic = 1: list lengths 23 / 29 / 31 run the next width (one dead ring slot); 0: exact widths
+    if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1");
+    a->prime_pad = value;
   } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)
     a->pb_reverse = value != 0;
   } else if (k == "serial_solve") {

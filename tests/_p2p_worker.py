@@ -77,6 +77,41 @@ def main():
         dist.barrier()                           # (nobody frees a mailbox a peer may still write into)
         a.delete(); b.delete()
 
+    # ---- a captured update replays the exchange: its number lives on the device, not in a kernel argument -----------
+    n, m = 65536, 4
+    lo, hi = nd.slice_bounds(n, world, rank)
+    side = torch.cuda.Stream()
+    static = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(side):
+        a = nka_amd.nka().init(hi - lo, m)
+        assert nd.attach_allreduce(a, rank, world, prefer="p2p", ladder=("p2p",)) == "p2p"
+        b = nka_amd.nka().init(hi - lo, m)
+        b.set_dot_prod(rank_ordered_staged)
+        for t in range(m + 3):
+            x = synth.fill_numpy(31, t, 0, n, n)
+            static.copy_(torch.from_numpy(x[lo:hi].copy()))
+            fb = static.clone()
+            a.accel_update(static)
+            b.accel_update(fb)
+            torch.cuda.synchronize()
+            assert torch.equal(static, fb), (rank, t)
+        assert a.capture_safe()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            a.accel_update(static)
+        for t in range(m + 3, m + 9):
+            x = synth.fill_numpy(31, t, 0, n, n)
+            static.copy_(torch.from_numpy(x[lo:hi].copy()))
+            fb = static.clone()
+            g.replay()
+            b.accel_update(fb)
+            torch.cuda.synchronize()
+            assert torch.equal(static, fb), (rank, "replay", t)
+            assert a.state_digest() == b.state_digest(), (rank, "replay", t)
+    dist.barrier()
+    del g
+    a.delete(); b.delete()
+
     # ---- the same mailboxes as the transport of the reference-order chain: the single-rank reference's bits ------
     n, m = 5003, 5
     lo, hi = nd.slice_bounds(n, world, rank)

@@ -121,3 +121,38 @@ def test_out_of_place_entry_refuses_buffers_the_library_holds(torch_cuda):
         torch.cuda.synchronize()
         assert torch.equal(got, want), t
     assert a.state_digest() == twin.state_digest() and a.defined()
+
+
+@pytest.mark.parametrize("flavor", [0, 2])
+@pytest.mark.parametrize("m", [23, 29, 31, 33, 46, 62])
+def test_padded_prime_widths_and_balanced_passes_change_no_bit(torch_cuda, oracle, flavor, m):
+    """Round 5: list lengths 23, 29, 31 run the window kernels of the next width with one dead ring slot (`prime_pad`), and
+    lists longer than 32 run BALANCED passes of the window kernels (33 = 17 + 16, 46 = 24 + 22: the heavy prime 23 avoided,
+    62 = 32 + 30) where they used to run passes of 32 of the all-loads-in-flight kernels.  Same sums in the same order, an
+    elementwise combine cut at another place: every output bit must equal the forms they replace (`prime_pad` = 0, `pa_pipe` =
+    `pb_pipe` = 0), and the decisions the oracle's."""
+    import nka_amd
+    torch = torch_cuda
+    n = 40961
+    rng = np.random.default_rng(100 * m + flavor)
+    basis = rng.standard_normal((3, n))
+    new = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor)          # automatic choices (the product's)
+    old = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor)
+    old.set_tuning("prime_pad", 0)
+    if m > 32:
+        old.set_tuning("pa_pipe", 0)
+        old.set_tuning("pb_pipe", 0)
+    ora = oracle.OracleNKA(n, m, flavor)
+    for t in range(m + 8):
+        x = rng.standard_normal(3) @ basis if t % 9 == 7 else rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        a, b = torch.from_numpy(x.copy()).cuda(), torch.from_numpy(x.copy()).cuda()
+        new.accel_update(a)
+        old.accel_update(b)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (m, flavor, t, float((a - b).abs().max()))
+        assert new.state_digest() == old.state_digest(), (m, flavor, t)
+        if t % 6 == 0 or t >= m:
+            assert new.state().list_order() == ora.state().list_order(), (m, flavor, t)
+    assert new.num_vec() == ora.num_vec() and new.defined()
