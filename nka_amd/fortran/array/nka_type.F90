@@ -67,6 +67,9 @@ module nka_type
     procedure :: set_dot_prod
     procedure :: set_allreduce
     procedure :: use_rccl
+    procedure :: p2p_export
+    procedure :: p2p_attach
+    procedure :: p2p_detach
     procedure :: vec_len
     procedure :: num_vec
     procedure :: max_vec
@@ -191,6 +194,29 @@ contains
     integer, intent(in) :: nranks, rank
     call nka_hip_check(nka_hip_comm_init_rank(this%handle, id128, int(nranks, c_int32_t), &
                                               int(rank, c_int32_t)), 'nka%use_rccl')
+  end subroutine
+
+  !! Opt-in: the peer-to-peer exchange in place of the all-reduce kernel (include/nka_hip.h, nka_hip_p2p_*).  Collective:
+  !! every rank calls p2p_export(nranks, mine), the caller gathers the 64-byte handles in rank order by any means (an
+  !! MPI_Allgather of 64 characters), every rank calls p2p_attach(all, nranks, rank) with rank counted from 0.
+  subroutine p2p_export(this, nranks, handle64)
+    class(nka), intent(inout) :: this
+    integer, intent(in) :: nranks
+    character(kind=c_char), intent(out) :: handle64(64)
+    call nka_hip_check(nka_hip_p2p_export(this%handle, int(nranks, c_int32_t), handle64), 'nka%p2p_export')
+  end subroutine
+
+  subroutine p2p_attach(this, handles, nranks, rank)
+    class(nka), intent(inout) :: this
+    character(kind=c_char), intent(in) :: handles(:)          ! 64*nranks characters
+    integer, intent(in) :: nranks, rank
+    if (size(handles) < 64*nranks) call nka_hip_check(-1_c_int, 'nka%p2p_attach: need 64*nranks characters')
+    call nka_hip_check(nka_hip_p2p_attach(this%handle, handles, int(nranks, c_int32_t), int(rank, c_int32_t)), 'nka%p2p_attach')
+  end subroutine
+
+  subroutine p2p_detach(this)
+    class(nka), intent(inout) :: this
+    call nka_hip_check(nka_hip_p2p_detach(this%handle), 'nka%p2p_detach')
   end subroutine
 
   integer function vec_len(this)                              ! F08:238-241

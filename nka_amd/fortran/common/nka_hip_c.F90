@@ -135,6 +135,23 @@ module nka_hip_c
       character(kind=c_char), intent(in) :: id128(128)
       integer(c_int32_t), value :: nranks, rank
     end function
+    ! peer-to-peer exchange (opt-in, include/nka_hip.h): handle64 = a hipIpcMemHandle_t; handles = nranks of them in rank order
+    integer(c_int) function nka_hip_p2p_export(handle, nranks, handle64) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_char
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nranks
+      character(kind=c_char), intent(out) :: handle64(64)
+    end function
+    integer(c_int) function nka_hip_p2p_attach(handle, handles, nranks, rank) bind(C)
+      import :: c_int, c_int32_t, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: handles(*)
+      integer(c_int32_t), value :: nranks, rank
+    end function
+    integer(c_int) function nka_hip_p2p_detach(handle) bind(C)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+    end function
     integer(c_int) function nka_hip_set_timing(handle, capacity) bind(C)
       import :: c_int, c_int32_t, c_ptr
       type(c_ptr), value :: handle

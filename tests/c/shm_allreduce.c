@@ -90,3 +90,24 @@ int shm_allreduce(void *ctx, double *vals, int32_t count) {
 }
 
 uint32_t shm_ar_calls(void *ctx) { return ctx ? __atomic_load_n(&((shm_ar *)ctx)->area->calls, __ATOMIC_RELAXED) : 0u; }
+
+/* All-gather of `nbytes` (<= 512) opaque bytes per rank, in rank order -- where a real caller would use MPI_Allgather: the
+ * hipIpc handles of the peer-to-peer exchange (nka_hip_p2p_export / _attach), which are NOT numbers and must not be summed. */
+int shm_allgather(void *ctx, const void *mine, int32_t nbytes, void *all) {
+  shm_ar *c = (shm_ar *)ctx;
+  if (!c || nbytes < 0 || (size_t)nbytes > sizeof(double) * SHM_AR_MAXCOUNT) return 1;
+  shm_ar_area *a = c->area;
+  const char *src = (const char *)mine;
+  char *slot = (char *)&a->slot[(size_t)c->rank * SHM_AR_MAXCOUNT];
+  for (int i = 0; i < nbytes; i++) slot[i] = src[i];
+  if (barrier(c)) return 2;
+  for (int r = 0; r < c->world; r++) {
+    const char *s = (const char *)&a->slot[(size_t)r * SHM_AR_MAXCOUNT];
+    for (int i = 0; i < nbytes; i++) ((char *)all)[(size_t)r * nbytes + i] = s[i];
+  }
+  if (barrier(c)) return 2;
+  return 0;
+}
+
+/* a plain barrier of the ranks (before a rank frees memory its peers may still write into) */
+int shm_barrier(void *ctx) { return ctx ? barrier((shm_ar *)ctx) : 1; }

@@ -42,3 +42,49 @@ def test_bench_rehearsal_with_the_peer_to_peer_exchange():
     assert d["n_gpus"] == 2 and d["config"]["steady_state"] and "all-reduce=p2p" in d["config"]["parallelism"]
     assert all(r["hook"] == "p2p" for r in d["ranks"]) and len({r["state_digest"] for r in d["ranks"]}) == 1
     assert all(c["identical"] for c in d["replica_check"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fortran_caller_sharded_through_the_peer_to_peer_exchange(world, tmp_path):
+    """nka_amd/fortran/array/nka_p2p_driver.F90: a sharded caller written the reference's way (module nka_type, accel_update
+    on a host array, every process the same calls on its slice: F08:58-64) whose ranks reduce through `call accel%p2p_export`
+    / `p2p_attach` -- one process per rank sharing the box's GPU, the hipIpc handles gathered through a mapped file.  Against
+    the unsharded oracle: num_vec after every call exact, the assembled result within the truth rule."""
+    import numpy as np
+    import parity_util as P
+    from oracle import oracle_py as O
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "nka_amd", "fortran")], check=True)
+    exe = os.path.join(ROOT, "nka_amd", "fortran", "build", "nka_p2p_driver")
+    n, m, calls = 30011, 6, 16
+    shm = tmp_path / "exchange.shm"
+    shm.write_bytes(bytes(4096 + 8 * 64 * world))
+    outs = [tmp_path / f"out{r}.bin" for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NKA_HIP_P2P_TIMEOUT_MS="20000")
+    procs = [subprocess.Popen([exe, str(n), str(m), str(calls), str(outs[r]), str(r), str(world), str(shm)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    raws = [np.fromfile(o, dtype=np.float64) for o in outs]
+    bounds = [tuple(int(v) for v in np.frombuffer(r[:2].tobytes(), dtype=np.int64)) for r in raws]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
+    flavor = O.C_FLAVOR                      # the front ends' default: compact storage
+    ora, spread = O.OracleNKA(n, m, flavor), P.Spread(O, n, m)
+    pos = [2] * world
+    for t in range(1, calls + 1):
+        x = raws[0][pos[0]:pos[0] + n].copy()
+        f = x.copy()
+        ora.accel_update(f)
+        spread.update(x)
+        got, nvs = np.empty(n), []
+        for r, (lo, hi) in enumerate(bounds):
+            assert np.array_equal(raws[r][pos[r]:pos[r] + n], x)                 # every rank drew the same global input
+            nvs.append(int(raws[r][pos[r] + n]))
+            got[lo:hi] = raws[r][pos[r] + n + 1:pos[r] + n + 1 + (hi - lo)]
+            pos[r] += n + 1 + (hi - lo)
+        err = float(np.linalg.norm(got - f) / np.linalg.norm(x))
+        P.check(err, ora.state(), f"Fortran caller sharded x{world} through the peer-to-peer exchange", where=t, spread=spread.value,
+                truth=spread.truth(got, x))
+        if t == 7:                                                               # (the driver relaxes, then writes num_vec)
+            ora.relax(); spread.relax()
+        assert nvs == [ora.num_vec()] * world, (t, nvs, ora.num_vec())
+    assert all("final num_vec" in lg for lg in logs)

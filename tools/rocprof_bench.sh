@@ -16,5 +16,12 @@ echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu-baseline --flavor $FL --steps 4 "$@" > "$OUT/bench_under_pmc_write.log" 2>&1
 echo "pmc write rc=$?"
 mkdir -p "$ROOT/gpurun_out/profiles_$TAG"
-python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$ROOT/gpurun_out/profiles_$TAG" --flavor $FL | tail -30
+# (the vector length / subspace size of the run, for the words-per-element columns: --vlen / --mvec among the bench arguments)
+N=1e8; M=20; prev=""
+for arg in "$@"; do
+  [ "$prev" = "--vlen" ] && N=$arg
+  [ "$prev" = "--mvec" ] && M=$arg
+  prev=$arg
+done
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$ROOT/gpurun_out/profiles_$TAG" --flavor $FL --n $N --mvec $M | tail -30
 cp "$OUT/bench_under_trace.log" "$ROOT/gpurun_out/profiles_$TAG/bench_under_trace_$FL.log"
