@@ -98,8 +98,8 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  *     i.e. within the stated tolerance wherever the reference is, and never further from the truth than F times the
  *     reference's own worst distance on the same calls (ill-conditioned sequences -- pivots down to vtol, a tiny difference
  *     norm s -- put the REFERENCE 1e-10 ... 1e-6 from the truth; no fixed figure can hold there).  An EMPIRICAL bar with a
- *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 4 of 10 953 sharded records in round 5,
- *     all but four with n <= 9 elements; the four beyond one tile (1660, 1028, 771, 1013 elements: 2.7 x, 3.5 x, 3.4 x, 2.05 x
+ *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 5 in round 5 (10 953 sharded records, 2 387 other sequences),
+ *     all but five with n <= 9 elements (one more with 510, within one tile); the four beyond one tile (1660, 1028, 771, 1013 elements: 2.7 x, 3.5 x, 3.4 x, 2.05 x
  *     instead of 2 x) are replayed by the suite with a cap
  *     on their ratio (tests/golden/soak_cases.json).  DIRECTLY against the reference: wherever err(f_reference) <= base / 2,
  *     ||f_device - f_reference|| / ||f_in|| <= 2 * base is asserted; at n = 2e7, m = 20 (independent and dependent inputs)
