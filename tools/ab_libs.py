@@ -37,7 +37,7 @@ def main():
     n, m = int(a.vlen), a.mvec
     fl = {"f08": nka_amd.FLAVOR_F08, "c": nka_amd.FLAVOR_C, "f08vec": nka_amd.FLAVOR_F08_VECTOR}[a.flavor]
     accs = [nka_amd.nka(lib=os.path.join(ROOT, p) if not os.path.isabs(p) else p).init(n, m, flavor=fl) for p in a.libs]
-    P = min(m + 6, 30)
+    P = m + 6                    # (distinct inputs for the whole fill: a repeated input would be dropped as dependent)
     pool = torch.empty((P, n + (n % 2)), dtype=torch.float64, device="cuda")
     work = torch.empty(n + (n % 2), dtype=torch.float64, device="cuda")
 
