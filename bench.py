@@ -795,6 +795,41 @@ def main(argv=None):
         else:
             exchange = {"error": err or "failed on another rank"}
 
+    # Opt-in (NKA_BENCH_P2P_PROBE=1, N > 1): the same 2 + 2 mvec doubles through the PEER-TO-PEER EXCHANGE on a small accelerator
+    # of its own, back to back -- the figure to hold against `us_back_to_back` of the RCCL hook on the day a multi-GPU node runs
+    # this (include/nka_hip.h: "needs a measured win over RCCL before it is preferred").  Bounded: every wait gives up after
+    # 200 ms, a failed set-up or self-test is recorded and nothing else is touched.
+    if world > 1 and exchange and os.environ.get("NKA_BENCH_P2P_PROBE") == "1" and hook_box[0] != "p2p":
+        os.environ.setdefault("NKA_HIP_P2P_TIMEOUT_MS", "200")
+        probe_acc, perr, pus = None, None, 0.0
+        try:
+            probe_acc = nka_amd.nka().init(4096, m)
+            nd.attach_allreduce(probe_acc, rank, world, prefer="p2p", ladder=("p2p",))
+            xb = torch.zeros(2 + 2 * m, dtype=torch.float64, device=dev)
+            for _ in range(20):
+                probe_acc.allreduce_now(xb)
+            torch.cuda.synchronize(dev)
+            probe_acc.num_vec()                        # (raises if a wait timed out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                probe_acc.allreduce_now(xb)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            probe_acc.num_vec()
+            pus = e0.elapsed_time(e1) / 200 * 1e3
+        except Exception as exc:      # an extra, never the measured path
+            perr = repr(exc)
+        sync_all()
+        pt = torch.tensor([pus if perr is None else float("inf")], dtype=torch.float64)
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        exchange["p2p_probe"] = ({"us_back_to_back": float(pt.item()), "reps": 200,
+                                  "what": "k_p2p_allreduce (one send-and-gather kernel per call) on mailboxes mapped through hipIpc"}
+                                 if float(pt.item()) != float("inf") else {"error": perr or "failed on another rank"})
+        if probe_acc is not None:
+            sync_all()
+            probe_acc.delete()
+
     # what every rank saw: which GPU, which RCCL, how many ranks ITS communicator connected, its digest of the
     # replicated state -- so that a multi-GPU record proves by itself that RCCL reduced over N ranks
     rank_info = None
