@@ -23,6 +23,9 @@
 // That moves 8n(8+L+2k) bytes per update -- 8n(9+L+k) compact -- against the
 // 8n(11+L+2k) of the three-pass schedule of SURVEY.md 8(d), with ONE
 // synchronisation point.
+// Round 5: lists longer than 32 run PA and PB as balanced passes of the same window kernels (`base` into the plans);
+// with several ranks the final sums can go straight into every rank's mailbox and the scalar step gathers them (struct
+// P2P: no communication kernel); the reference-order pass k_dots_ordered continues the running sums from rank to rank.
 //
 // Everything is fp64 and bandwidth bound (0.29 flop/byte): no MFMA.  Vectors are
 // slot-major, each slot contiguous and 256-B aligned, read with 16-B/lane
