@@ -9,15 +9,16 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$ROOT/gpurun_out/scale_rehearsal.txt}
+HOOK=${2:-rccl}          # rccl (default) | p2p: the hook forced on the one rank (round 5: the peer-to-peer exchange with its own mailbox)
 cd "$ROOT"
 : > "$OUT"
-echo "# one MI355X running the shard of an N-GPU job (n_global = 1e8, mvec = 20, default flavour); RCCL hook forced, one rank" | tee -a "$OUT"
+echo "# one MI355X running the shard of an N-GPU job (n_global = 1e8, mvec = 20, default flavour); hook '$HOOK' forced, one rank" | tee -a "$OUT"
 PORT=29600
 for N in 1 2 4 8; do
   NL=$((100000000 / N))
   PORT=$((PORT + 1))
   NKA_BENCH_FORCE_HOOK=1 NKA_BENCH_SECONDARY=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
-      --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 1 --vlen $NL --steps 40 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > /tmp/scale_$N.json
+      --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 1 --vlen $NL --steps 40 --no-cpu-baseline --allreduce $HOOK 2>/dev/null | grep '^{' | tail -1 > /tmp/scale_$N.json
   python3 - "$N" /tmp/scale_$N.json <<'PY' | tee -a "$OUT"
 import json, sys
 N, path = int(sys.argv[1]), sys.argv[2]
@@ -26,7 +27,7 @@ try:
     r = d["ranks"][0]
     print(f"N={N} n_local={d['config']['n_local']:>9d}: {1e3 * d['ms_per_step']:8.1f} us/update  hook={r['hook']} "
           f"comm(nranks,rank)={r['comm_nranks_rank']} replica_check={[c['identical'] for c in d.get('replica_check', [])]} "
-          f"whole-update frac {d['roofline']['whole_update']['frac']:.3f}")
+          f"whole-update frac {d['roofline']['whole_update']['frac']:.3f} exchange back to back {d.get('exchange', {}).get('us_back_to_back', float('nan')):.1f} us")
 except Exception as exc:
     print(f"N={N}: no bench line ({exc})")
 PY
@@ -42,4 +43,5 @@ if 1 in t:
     print("# projected strong scaling t(1)/t_shard(N) (one rank: no xGMI hop in the all-reduce):",
           ", ".join(f"N={n}: {t[1] / t[n]:.2f}x" for n in sorted(t)))
 PY
-timeout -k 10 300 python tools/rccl_latency.py 12500000 2>/dev/null | grep -v amdgpu.ids | tee -a "$OUT"
+[ "$HOOK" = rccl ] && timeout -k 10 300 python tools/rccl_latency.py 12500000 2>/dev/null | grep -v amdgpu.ids | tee -a "$OUT"
+exit 0
