@@ -291,7 +291,8 @@ int nka_hip_comm_library(char *path, int32_t len);
  * how many ranks RCCL really connected. */
 int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
 
-/* PEER-TO-PEER EXCHANGE (opt-in, one node): the sums of an update without a communication kernel.  Every rank owns a
+/* PEER-TO-PEER EXCHANGE (opt-in, one node): the sums of an update without a communication kernel -- one more way to supply
+ * the global reduction the reference leaves to its caller (F08:58-64, set_dot_prod F08:209-214).  Every rank owns a
  * mailbox in fine-grained device memory which its peers map through hipIpc; the final-sums kernel of an update writes
  * each sum straight into every rank's mailbox (value, then the exchange number released at system scope) and the scalar
  * step starts by waiting for the N rows and adding them IN RANK ORDER -- the same additions in the same order on every

@@ -34,7 +34,9 @@ extern "C" {
  * Round 5: "pb_reverse" = 0/1: the rolling-window PB walks its tiles from the END of the vectors, the reverse of PA's order
  * (the Infinity-Cache study, profiles/r05/ab_mall_reuse.txt).  "prime_pad": list lengths 23, 29, 31 are primes, the only
  * ring of their window kernels is the whole width (up to 311 VGPRs and scratch in PA): -1 automatic (= 1) both passes run them
- * at the next width with one dead ring slot; 0 = exact widths everywhere (profiles/r05/multipass.txt).  Same bits. */
+ * at the next width with one dead ring slot; 0 = exact widths everywhere (profiles/r05/multipass.txt).  Same bits.
+ * "fail_after_solve" = 1: the NEXT update returns NKA_HIP_EHIP right behind its enqueued scalar step, as a failing HIP call
+ * there would: the handle must then be poisoned (every later call but destroy: NKA_HIP_ESTATE). */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */

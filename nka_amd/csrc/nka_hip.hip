@@ -226,6 +226,8 @@ struct nka_hip_state {
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
   int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
+  int fail_after_solve = 0;   // diagnostic switch "fail_after_solve": the next update fails as if a HIP call behind its scalar step had
+                              // (the test of the poisoned-handle path: the failure itself cannot be provoked from outside)
   int prime_pad = -1;         // list lengths 23, 29, 31 (primes: the only ring of their window kernels is the whole width -- up to 311
                               // VGPRs and scratch in PA, every load of a tile in flight in PB) run the next width with ONE dead ring
                               // slot: -1 / 1 on (automatic), 0 off.  In-process A/B at n = 1e7 (profiles/r05/multipass.txt): update
@@ -1348,6 +1350,12 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     bool armed = true;
     ~Poison() { if (armed) a->poisoned = true; }
   } poison{a};
+#ifdef NKA_DIAGNOSTIC
+  if (a->fail_after_solve) {
+    a->fail_after_solve = 0;
+    return fail(NKA_HIP_EHIP, "accel_update: injected failure behind the scalar step (diagnostic switch fail_after_solve)");
+  }
+#endif
   if (int rc = record(a, 2)) return rc;
 
   const int comb_ub = a->pending ? std::min(a->list_ub, (int)a->mvec) : a->list_ub;
@@ -1940,6 +1948,8 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
     if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(NKA_HIP_EINVAL, "pb_tickets: -1 (auto), 0 (static tile mapping), 1, 2, 4, 8 (ticket counters)");
     a->pb_tickets = value;
+  } else if (k == "fail_after_solve") {   // 1: the NEXT update returns NKA_HIP_EHIP right behind its enqueued scalar step
+    a->fail_after_solve = value != 0;
   } else if (k == "prime_pad") {      // -1 automatic = 1: list lengths 23 / 29 / 31 run the next width (one dead ring slot); 0: exact widths
     if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1");
     a->prime_pad = value;

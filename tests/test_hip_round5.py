@@ -156,3 +156,26 @@ def test_padded_prime_widths_and_balanced_passes_change_no_bit(torch_cuda, oracl
         if t % 6 == 0 or t >= m:
             assert new.state().list_order() == ora.state().list_order(), (m, flavor, t)
     assert new.num_vec() == ora.num_vec() and new.defined()
+
+
+def test_a_failure_behind_the_scalar_step_poisons_the_handle(torch_cuda):
+    """once the scalar step of an update is in the stream, the lists, the factor and (out of place) the slot ->
+    buffer tables move on whatever the host does next; a HIP failure behind it used to leave host bookkeeping and device
+    state apart, silently.  Now the handle is POISONED: the failing call returns its error, every later update, restart and
+    relax returns NKA_HIP_ESTATE, destroy still works.  The failure is injected by the diagnostic build."""
+    import nka_amd
+    torch = torch_cuda
+    n, m = 4096, 3
+    for swap in (False, True):
+        a = nka_amd.nka(diagnostic=True).init(n, m)
+        x = [torch.randn(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+        a.accel_update(x[0])
+        a.accel_update(x[1])
+        a.set_tuning("fail_after_solve", 1)
+        with pytest.raises(nka_amd.NKAError, match="injected failure"):
+            a.accel_update_swap(x[2]) if swap else a.accel_update(x[2])
+        for call in (lambda: a.accel_update(x[3]), a.restart, a.relax, lambda: a.accel_update_swap(x[3])):
+            with pytest.raises(nka_amd.NKAError, match="Destroy the handle|destroy the handle"):
+                call()
+        torch.cuda.synchronize()
+        a.delete()                                         # nka_hip_destroy on a poisoned handle: fine
