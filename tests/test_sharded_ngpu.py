@@ -42,10 +42,10 @@ def test_n_gpu_rccl_sharded_run_against_the_tiled_oracle():
     oracle's on the 97 656-element problem, identical state digests, comm_info() == (N, rank), global error against the
     tiled oracle <= 1e-10 under the truth rule.  (torch.cuda.device_count() does not initialise the GPU in this process.)"""
     import torch
-    ngpu = torch.cuda.device_count()
+    ngpu = min(torch.cuda.device_count(), 8)          # (one node: BASELINE configs[3] names 8)
     if ngpu < 2:
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device); rehearsed below with ranks sharing the GPU")
-    out = _run(ngpu, {"NKA_NGPU_MODE": "rccl", "NKA_NGPU_N0": "97656", "NKA_NGPU_R": "1024", "NKA_NGPU_MVEC": "20"}, 1500)
+    out = _run(ngpu, {"NKA_NGPU_MODE": "rccl", "NKA_NGPU_N0": "97656", "NKA_NGPU_R": "1024", "NKA_NGPU_MVEC": "20"}, 800)
     assert out.count("hook=rccl") == 2 and f"comm=({ngpu}, 0)" in out, out[-2000:]
 
 
