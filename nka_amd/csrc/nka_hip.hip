@@ -1203,7 +1203,7 @@ static bool ordered_sums(const nka_hip_state *a) {
 }
 
 // Does [p, p + n) touch memory the library holds -- the slot-major allocations or a buffer it has taken over -- that it
-// has NOT lent to the caller?  (A handful of buffers: linear scans.)
+// has NOT lent to the caller?  (Ordered sets: a caller that hands over a fresh buffer every iteration makes them long.)
 static bool held_by_library(const nka_hip_state *a, const double *p) {
   if (a->lent.count(p)) return false;
   const int64_t n = std::max<int64_t>(a->n, 1);
@@ -1657,6 +1657,8 @@ int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64) {
 int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank) {
   if (!a || !handles) return fail(NKA_HIP_EINVAL, "null argument");
   if (!a->p2p_mail || nranks != a->p2p_ranks) return fail(NKA_HIP_ESTATE, "p2p_attach: call nka_hip_p2p_export(nranks) first");
+  if (a->p2p.base || a->p2p_dev || !a->p2p_opened.empty())
+    return fail(NKA_HIP_ESTATE, "p2p_attach: already attached (nka_hip_p2p_detach, then export and attach again, collectively)");
   if (rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "p2p_attach: bad rank");
   HIP_TRY(hipSetDevice(a->device));
   const int cap = std::max(a->ctl.red_count(), 64);
