@@ -98,7 +98,7 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  *     i.e. within the stated tolerance wherever the reference is, and never further from the truth than F times the
  *     reference's own worst distance on the same calls (ill-conditioned sequences -- pivots down to vtol, a tiny difference
  *     norm s -- put the REFERENCE 1e-10 ... 1e-6 from the truth; no fixed figure can hold there).  An EMPIRICAL bar with a
- *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 5 in round 5 (10 953 sharded records, 2 387 other sequences),
+ *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 11 in round 5 (26 127 sharded records, 2 828 other sequences),
  *     all but five with n <= 9 elements (one more with 510, within one tile); the four beyond one tile (1660, 1028, 771, 1013 elements: 2.7 x, 3.5 x, 3.4 x, 2.05 x
  *     instead of 2 x) are replayed by the suite with a cap
  *     on their ratio (tests/golden/soak_cases.json).  DIRECTLY against the reference: wherever err(f_reference) <= base / 2,
@@ -451,7 +451,7 @@ int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const 
 /* The scale-and-dot stage as a PURE READ, and the combine stage normalising the new pair itself
  * ("pending pair": entry 0 of its lists is the raw pair the first call left untouched):
  *   dot_pair_many_scaled:   with w' = a*(pre_a*f + w) [pre != 0; else a*w] formed in registers only:
- *                           vals_w[j] = <w',ys[j]>, vals_f[j] = <f,ys[j]>, *cross = <f,w'> ; count <= 24
+ *                           vals_w[j] = <w',ys[j]>, vals_f[j] = <f,ys[j]>, *cross = <f,w'> ; any count (balanced groups of <= 24)
  *   update_many_keep_pend:  update_many_keep with xs[0] = w, ys[0] = v rewritten on the way as
  *                           w <- a*(pre_a*z_in + w) [pre], v <- a*v [, subtract: v <- (-1)*w + v]
  *   axpy_many_keep_pend:    axpy_many_keep for compact storage: xs[0] = v, pend_w = w, subtract implied
@@ -464,7 +464,8 @@ int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const doubl
                                      double *host_vals_w, double *host_vals_f, double *host_cross);
 /* The norm stage and the scale-and-dot stage as ONE pure-read pass (override of
  * vector%update_norm2_dots): with d = a*x + z formed in registers only,
- *   *host_dd = <d,d>, vals_z[j] = <d,ys[j]>, vals_x[j] = <x,ys[j]>, *cross = <x,d>     (RAW sums, count <= 24)
+ *   *host_dd = <d,d>, vals_z[j] = <d,ys[j]>, vals_x[j] = <x,ys[j]>, *cross = <x,d>     (RAW sums; any count: balanced groups of <= 24 vectors,
+ *                           each forming d in registers again)
  * The accelerator takes s = sqrt(<d,d>) and scales the d-sums by 1/s itself -- the Gram row of the normalised
  * pair as fl(<d,w_k>/s) instead of the sum of fl(d_i/s)*w_k,i, like pass PA of the array flavours: last-bit
  * differences, decisions and tolerance unaffected -- and hands the whole pending normalisation to the combine

@@ -152,6 +152,10 @@ static __global__ __launch_bounds__(kBlock) void k_dot_ordered(int64_t n, const 
 
 // ---- batched hooks: one pass for many dots / many axpys -----------
 constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24; window kernels: every width 1..24); longer lists run several launches
+// ... of BALANCED widths (round 5; 25 = 13 + 12, not 24 + 1: a launch that is nearly all padding costs as much as a full one --
+// profiles/r05/multipass.txt): group p of a list of `count` entries
+static inline int many_groups(int count) { return count <= kManyMax ? 1 : (count + kManyMax - 1) / kManyMax; }
+static inline int many_group_width(int count, int p) { const int np = many_groups(count); return count / np + (p < count % np ? 1 : 0); }
 struct ManyArgs {
   const double *x[kManyMax];
   const double *y[kManyMax];
@@ -801,11 +805,12 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
     if (PAIRS) if (int rc = nka_detail::check_device_span(ys[j], n, who)) return rc;
   }
   int base = 0;
-  do {   // at least one launch: with count == 0 the two keeps are still written
+  const int ngroups = many_groups(count);
+  for (int grp = 0; grp < ngroups; grp++) {   // at least one launch: with count == 0 the two keeps are still written
     ManyArgs m{};
-    m.count = std::max(0, std::min(kManyMax, count - base));
-    double *kin = (base == 0) ? keep_in : nullptr;
-    double *kout = (base + kManyMax >= count) ? keep_out : nullptr;
+    m.count = many_group_width(count, grp);
+    double *kin = (grp == 0) ? keep_in : nullptr;
+    double *kout = (grp == ngroups - 1) ? keep_out : nullptr;
     bool v2 = al16(z) && (!kin || al16(kin)) && (!kout || al16(kout));
     for (int j = 0; j < m.count; j++) {
       m.x[j] = xs[base + j];
@@ -834,8 +839,8 @@ int update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
 #undef LAUNCHW
 #undef LAUNCH1
     HIP_TRYV(hipGetLastError());
-    base += kManyMax;
-  } while (base < count);
+    base += m.count;
+  }
   return 0;
 }
 
@@ -1328,9 +1333,18 @@ static int nka_hip_vec_dot_pair_many_scaled_entry(nka_hip_vec_ws_t ws, int64_t n
   if (ws && ws->sum_order == 1)     // (the vector types fall back to the deferred hooks then: dot(), whose sum IS ordered)
     return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
                                  "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
-  if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_dot_pair_many_scaled: more than 24 vectors");
-  return scale_dot_pair_many_impl(ws, n, const_cast<double *>(w), const_cast<double *>(w), a, 0, pre, pre_a, f, ys, count,
-                                  host_vals_w, host_vals_f, host_cross, 0);
+  // (a list longer than one launch: balanced groups, each forming w' in registers again -- a pure-read stage, nothing to undo;
+  //  <f,w'> comes from the first group)
+  const int ngroups = many_groups(count);
+  for (int grp = 0, base = 0; grp < ngroups; grp++) {
+    const int wdt = many_group_width(count, grp);
+    double cross = 0.0;
+    if (int rc = scale_dot_pair_many_impl(ws, n, const_cast<double *>(w), const_cast<double *>(w), a, 0, pre, pre_a, f, ys + base, wdt,
+                                          host_vals_w + base, host_vals_f + base, &cross, 0)) return rc;
+    if (grp == 0 && host_cross) *host_cross = cross;
+    base += wdt;
+  }
+  return 0;
 }
 int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre, double pre_a,
                                      const double *f, const double *const *ys, int32_t count, double *host_vals_w,
@@ -1350,10 +1364,22 @@ static int nka_hip_vec_diff_norm_dot_pair_many_entry(nka_hip_vec_ws_t ws, int64_
     return nka_detail::set_error(NKA_HIP_ESTATE, "this batched reduction sums in blocks; with reference-order sums "
                                  "(nka_hip_vec_set_sum_order) the vector type must use dot() / norm2()");
   if (!host_dd) return nka_detail::set_error(NKA_HIP_EINVAL, "bad argument");
-  if (count > kManyMax) return nka_detail::set_error(NKA_HIP_EINVAL, "vec_diff_norm_dot_pair_many: more than 24 vectors");
+  // (a list longer than one launch: balanced groups, d = a*x + z formed in registers again by each -- pure read; <d,d> and
+  //  <x,d> come from the first group)
   *host_dd = 0.0;
-  return scale_dot_pair_many_impl(ws, n, const_cast<double *>(z), const_cast<double *>(z), 1.0, 0, 1, a, x, ys, count,
-                                  host_vals_z, host_vals_x, host_cross, 0, host_dd);
+  const int ngroups = many_groups(count);
+  for (int grp = 0, base = 0; grp < ngroups; grp++) {
+    const int wdt = many_group_width(count, grp);
+    double cross = 0.0, dd = 0.0;
+    if (int rc = scale_dot_pair_many_impl(ws, n, const_cast<double *>(z), const_cast<double *>(z), 1.0, 0, 1, a, x, ys + base, wdt,
+                                          host_vals_z + base, host_vals_x + base, &cross, 0, &dd)) return rc;
+    if (grp == 0) {
+      *host_dd = dd;
+      if (host_cross) *host_cross = cross;
+    }
+    base += wdt;
+  }
+  return 0;
 }
 int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
                                         const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,

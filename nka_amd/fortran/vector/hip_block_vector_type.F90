@@ -429,8 +429,7 @@ contains
 
   !! The norm AND both inner-product rows in one pure-read pass (R (2+L)n): the raw sums of
   !! d = a*x + this; nothing is stored, the accelerator scales by 1/s and the combine stage
-  !! normalises the pair.  Lists beyond one launch (or NKA_HIP_VEC_FUSE_NORM=0, or the
-  !! deferral switched off) take the separate stages.
+  !! normalises the pair.  (NKA_HIP_VEC_FUSE_NORM=0, or the deferral switched off: the separate stages.)
   function update_norm2_dots_fused(this, a, x, ys, idx, vals_this, vals_x, cross, stored, fused) result(s)
     class(hip_block_vector), intent(inout) :: this
     real(r8), intent(in) :: a
@@ -445,7 +444,8 @@ contains
     vals_this = 0.0_r8
     vals_x = 0.0_r8
     cross = 0.0_r8
-    fused = size(idx) <= 24 .and. defer_scale_enabled() .and. fuse_norm_enabled() .and. .not. reference_order(this)
+    fused = defer_scale_enabled() .and. fuse_norm_enabled() .and. .not. reference_order(this)      ! (any list length since round 5:
+                                                                  ! the library runs balanced groups of at most 24 vectors)
     if (.not. fused) then
       s = update_norm2_fused(this, a, x, stored)
       return
@@ -506,9 +506,9 @@ contains
           do j = 1, size(idx)
             ptrs(j) = ys(idx(j))%base
           end do
-          !! Asked whether it stored, and the list fits one launch: a PURE-READ pass (R (2+L)n, no
+          !! Asked whether it stored: a PURE-READ pass (R (2+L)n, no
           !! store stream); the pair is normalised by the combine stage, which reads it anyway.
-          defer = present(scaled) .and. size(idx) <= 24 .and. defer_scale_enabled()
+          defer = present(scaled) .and. defer_scale_enabled()
           if (present(scaled)) scaled = .not. defer
           if (defer) then
             call nka_hip_check(nka_hip_vec_dot_pair_many_scaled(this%ws, this%nred, this%base, a, pre, pa, f%base, ptrs, &
