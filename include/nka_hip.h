@@ -303,7 +303,7 @@ int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
  *                                                   (it also serves nka_hip_allreduce_now and the reference-order chain,
  *                                                   as one small send-and-gather kernel).
  * One process per GPU (hipIpc does not map a handle into the process that exported it).  A wait for a peer is BOUNDED
- * (NKA_HIP_P2P_TIMEOUT_MS, default 5000): if a rank's sums do not arrive the gather stores NaNs, raises a status word and
+ * (NKA_HIP_P2P_TIMEOUT_MS, default 10000): if a rank's sums do not arrive the gather stores NaNs, raises a status word and
  * lets the grid drain; the next synchronising query (num_vec, get_state, state_digest ...) returns NKA_HIP_ECOMM.
  * Capturable into a graph (the exchange number lives on the device).  nka_hip_p2p_detach, collective too (a peer must not
  * write into a mailbox that has been freed: synchronise all ranks first), drops it; nka_hip_destroy calls it.
