@@ -501,8 +501,8 @@ int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f,
 static inline int balanced_passes(int total) { return (total + kMaxPerPass - 1) / kMaxPerPass; }
 // The widths whose only ring is the whole width (win_ring / win_ring_pairs: primes) AND large: 23, 29, 31.
 static inline bool heavy_prime(int w) { return w == 23 || w == 29 || w == 31; }
-// 22 and 26 (twice a prime) have no ring in win_ring's list either -- for the one-vector-per-entry kernels (PA, compact PB)
-static inline bool whole_width_ring(int w) { return w == 22 || w == 26; }
+// (22 and 26 -- twice a prime: no ring in win_ring's list either -- were tried the same way in round 5: padding to 24 / 28 makes PA
+//  3-4 % SLOWER and the update +1...2 % (compact), -1 % (src-F08): not kept, profiles/r05/multipass.txt)
 // widths[0..np): balanced, then one vector moved between two passes wherever that removes a heavy prime without making another
 static inline void balanced_widths(int total, int np, int *w) {
   for (int p = 0; p < np; p++) w[p] = total / np + (p < total % np ? 1 : 0);
@@ -991,7 +991,6 @@ static void enqueue_pa(nka_hip_t a, const double *f, int vec, int older_ub) {
   if (vec == 2 && npass == 1 && pa_pipe > 200 && pa_pipe < 210) {     // rolling window, 200 + blocks per CU
     int w = exact ? older_ub : maxl;
     if (a->prime_pad != 0 && heavy_prime(w)) w++;       // one dead ring slot instead of a ring as wide as the list (state: prime_pad)
-    else if (a->prime_pad == 2 && whole_width_ring(w)) w += 2;      // (experiment: 22 -> 24, 26 -> 28)
     launch_dots_win(w, a, f, std::max(1, pa_pipe - 200));
   } else if (vec == 2 && older_ub > kMaxPerPass && a->pa_pipe != 0) {  // a long list: balanced passes of the window kernel
     const int np = balanced_passes(older_ub);
@@ -1030,7 +1029,6 @@ static int enqueue_pb(nka_hip_t a, double *f, int vec, int comb_ub) {
   if (vec == 2 && pipe > 200 && pipe < 210 && comb_ub <= kMaxPerPass) {   // rolling window, 200 + blocks per CU
     int w = std::max(comb_ub, 1);                                             // exact width: no padding ...
     if (a->prime_pad != 0 && heavy_prime(w)) w++;                            // ... but for 23, 29, 31 (see prime_pad): one dead slot
-    else if (a->prime_pad == 2 && a->flavor == NKA_HIP_FLAVOR_C && whole_width_ring(w)) w += 2;
     launch_combine_win(a->flavor, w, a, f, pipe - 200);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1957,7 +1955,7 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   } else if (k == "fail_after_solve") {   // 1: the NEXT update returns NKA_HIP_EHIP right behind its enqueued scalar step
     a->fail_after_solve = value != 0;
   } else if (k == "prime_pad") {      // -1 automatic = 1: list lengths 23 / 29 / 31 run the next width (one dead ring slot); 0: exact widths
-    if (value < -1 || value > 2) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1, 2");
+    if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1");
     a->prime_pad = value;
   } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)
     a->pb_reverse = value != 0;

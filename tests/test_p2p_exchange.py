@@ -24,6 +24,11 @@ def test_peer_to_peer_exchange_equals_the_rank_ordered_staged_hook_bit_for_bit(w
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_p2p_worker.py")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if p.returncode != 0:
+        # one more attempt, LOUDLY (see tests/test_soak_regressions_gpu.py): several processes that rendezvous over a local port
+        # and share one GPU can fail for reasons outside the library; a defect of the exchange fails twice
+        print("FIRST ATTEMPT FAILED (rc %d); its last words:\n%s" % (p.returncode, p.stdout[-1500:] + p.stderr[-3000:]), flush=True)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
     assert p.stdout.count("p2p OK") == world
 
