@@ -9,5 +9,5 @@ include/nka_hip.h).  This package holds only what that path needs:
 There is NO CPU fallback: without the HIP library every entry point raises.
 """
 from ._lib import build, lib_path, load  # noqa: F401
-from .nka import (FLAVOR_C, FLAVOR_DEFAULT, FLAVOR_F08, FLAVOR_F08_VECTOR, SUMS_AUTO, SUMS_BLOCKED,  # noqa: F401
+from .nka import (FLAVOR_C, FLAVOR_DEFAULT, FLAVOR_F08, FLAVOR_F08_VECTOR, SUMS_AUTO, SUMS_BLOCKED, SUMS_BLOCKED_ROUNDED,  # noqa: F401
                   SUMS_REFERENCE_ORDER, NKAError, nka)

@@ -249,6 +249,7 @@ struct nka_hip_state {
   void *p2p_dev = nullptr;            // offsets table, exchange counter, status word
   int p2p_ranks = 0;                  // ranks the mailbox was sized for
   bool p2p_fused = false;             // the PA being enqueued sends its sums itself (update_impl)
+  int pa_normed = 0;                  // the PA being enqueued sums on the ROUNDED w1' (NKA_HIP_SUMS_BLOCKED_ROUNDED): 0 no, 1 d/s, 3 (1/s)*d
   int shard_rank = -1, shard_n = 0;   // position of this rank's slice in the global vector (nka_hip_set_shard; set by
                                       // nka_hip_comm_init_rank too): only the sharded reference-order sums need it
   bool needs_comm = false;    // a deep copy of an accelerator that reduced through the built-in RCCL communicator: the
@@ -324,9 +325,9 @@ template <int MAXL, int VEC>
 int launch_dots_1(const nka_hip_state *a, const double *f, int pass, int npass) {
   static const int occ = occupancy_of(k_dots<MAXL, VEC>);
   const int g = grid_for(a, 0, VEC, occ, MAXL + 2);
-  hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass);
+  hipLaunchKernelGGL((k_dots<MAXL, VEC>), dim3(g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, pass, a->pa_normed);
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, g, pass, npass * MAXL, pass * MAXL, a->p2p_fused ? a->p2p : P2P{});
+                     a->partials, g, pass, npass * MAXL, pass * MAXL, a->p2p_fused ? a->p2p : P2P{}, a->pa_normed ? 1 : 0);
   return g;
 }
 
@@ -337,11 +338,11 @@ int launch_dots_win_1(const nka_hip_state *a, const double *f, int bpc, int base
   const int64_t ntile = a->n / (kBlock * 2);
   int64_t g = (int64_t)a->num_cu * std::min(occ, std::max(1, bpc));
   g = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, std::max<int64_t>(ntile, 1)), kMaxGrid));
-  hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, base);
+  hipLaunchKernelGGL((k_dots_win<MAXL, W>), dim3((int)g), dim3(kBlock), 0, a->stream, a->ctl, a->vs, f, a->partials, base, a->pa_normed);
   // (Round 3 measured forming these sums -- and the scalar step -- in the tail of the PA launch, by the block that
   //  finishes last: 2-4 us SLOWER per update than the launches it saves, profiles/r03/ab_small_pa_tail_not_kept.txt.)
   hipLaunchKernelGGL((k_finalize_dots<MAXL>), dim3(2 * MAXL + 2), dim3(kFinThreads), 0, a->stream, a->ctl,
-                     a->partials, (int)g, pass, ncover < 0 ? MAXL : ncover, base, a->p2p_fused ? a->p2p : P2P{});
+                     a->partials, (int)g, pass, ncover < 0 ? MAXL : ncover, base, a->p2p_fused ? a->p2p : P2P{}, a->pa_normed ? 1 : 0);
   return (int)g;
 }
 
@@ -1326,6 +1327,28 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
       HIP_TRY(hipGetLastError());
     }
     mode |= kSolvePrenorm;
+  } else if (a->sum_order == NKA_HIP_SUMS_BLOCKED_ROUNDED && (a->pending || older_ub > 0)) {
+    // The fast passes with the Gram row AS THE REFERENCE DEFINES IT: first the norm in a pass of its own (two streams: +2 of
+    // 49 words), then PA on the ROUNDED w1' = fl(d/s) -- the vector PB stores -- so that <w1',w_k> and <f,w1'> are inner
+    // products of stored vectors (F08:283-290, 371), summed in blocks with fma.  What is left of the device's deviations
+    // is the summation order and the fma, both CLOSER to the exact sums than the reference's sequential ones.  Sharded: two
+    // exchanges per update (the norm, then the rows) through the installed hook.
+    RoctxRange range("nka:norm pass + PA on the rounded w1'");
+    if (a->pending) {
+      const int g = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)a->num_cu, std::max<int64_t>(a->n / (kBlock * 2), 1)));
+      hipLaunchKernelGGL(k_norm_diff, dim3(g), dim3(kBlock), 0, s, a->ctl, a->vs, f, a->partials);
+      hipLaunchKernelGGL(k_norm_fin, dim3(1), dim3(64), 0, s, a->ctl, a->partials, g);
+      HIP_TRY(hipGetLastError());
+      if (a->allreduce)
+        if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+    }
+    a->pa_normed = (mode & kSolveRcp) ? 3 : 1;
+    enqueue_pa(a, f, vec, older_ub);
+    a->pa_normed = 0;
+    HIP_TRY(hipGetLastError());
+    if (a->allreduce)
+      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red() + 1, a->ctl.red_count() - 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+    mode |= kSolvePrenorm;
   } else if (a->pending || older_ub > 0) {
     RoctxRange range("nka:PA dots + all-reduce");
     // peer-to-peer exchange: the final sums go straight into every rank's mailbox and the scalar step gathers them -- no
@@ -1882,8 +1905,9 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
 
 int nka_hip_set_sum_order(nka_hip_t a, int32_t order) {
   if (!a) return fail(NKA_HIP_EINVAL, "null handle");
-  if (order != NKA_HIP_SUMS_AUTO && order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED)
-    return fail(NKA_HIP_EINVAL, "set_sum_order: NKA_HIP_SUMS_AUTO, _REFERENCE_ORDER or _BLOCKED");
+  if (order != NKA_HIP_SUMS_AUTO && order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED &&
+      order != NKA_HIP_SUMS_BLOCKED_ROUNDED)
+    return fail(NKA_HIP_EINVAL, "set_sum_order: NKA_HIP_SUMS_AUTO, _REFERENCE_ORDER, _BLOCKED or _BLOCKED_ROUNDED");
   if (order == NKA_HIP_SUMS_REFERENCE_ORDER && a->mvec > kOrdMaxMvec)
     return fail(NKA_HIP_EINVAL, "set_sum_order: reference-order sums are offered up to mvec = " + std::to_string(kOrdMaxMvec));
   a->sum_order = order;

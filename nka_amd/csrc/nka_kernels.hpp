@@ -417,12 +417,23 @@ __device__ __forceinline__ void setc(d2 &x, int i, double val) { x[i] = val; }
 // hit) into accumulators that are discarded, which keeps every load of a tile
 // unconditional so that all MAXL+2 of them are in flight together.
 // acc: [0] sum d^2, [1] <f,d>, [2+j] <d,w_j>, [2+MAXL+j] <f,w_j>.
+// `normed` (round 5, NKA_HIP_SUMS_BLOCKED_ROUNDED): the norm is already known -- red[0] holds the GLOBAL sum d^2 of a pass of
+// its own (k_norm_diff) -- and the sums are formed on the ROUNDED w1' = fl(d/s) (bit 1 of `normed`: fl((1/s)*d), the
+// F08-vector flavour), the value PB stores: acc[1] = <f,w1'>, acc[2+j] = <w1',w_j> as the reference defines them (F08:286-290,
+// 371), in blocks and with fma.  The scalar step then takes them as they are (kSolvePrenorm).
+__device__ __forceinline__ double pa_operand(double d, int normed, double s, double rs) {
+  if (normed == 0) return d;
+  if (s == 0.0) return 0.0;                       // (the scalar step relaxes, F08:275: these sums are dead)
+  return (normed & 2) ? rs * d : d / s;
+}
+
 template <int MAXL, int VEC>
 __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                 double *__restrict__ partials, int pass) {
+                                                 double *__restrict__ partials, int pass, int normed) {
   using V = typename VecT<VEC>::type;
   constexpr int NACC = 2 * MAXL + 2;
   const int G = gridDim.x;
+  const double s_n = normed ? sqrt(ctl.red()[0]) : 1.0, rs_n = 1.0 / s_n;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int base = pass * MAXL;
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 #pragma unroll
     for (int q = 0; q < VEC; q++) {
       const double fq = ex(fv, q);
-      const double d = ex(w1v, q) - fq;            // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+      const double d = pa_operand(ex(w1v, q) - fq, normed, s_n, rs_n);      // F08:266 ((-1)*f + w1 in F08V:237: same bits)
       acc[0] = fma(d, d, acc[0]);
       acc[1] = fma(fq, d, acc[1]);
 #pragma unroll
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
   if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fq = f[i];
-      const double d = w1[i] - fq;
+      const double d = pa_operand(w1[i] - fq, normed, s_n, rs_n);
       acc[0] = fma(d, d, acc[0]);
       acc[1] = fma(fq, d, acc[1]);
 #pragma unroll
@@ -478,6 +489,52 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
     }
   }
   block_reduce_store<NACC>(acc, partials, G);
+}
+
+// The norm pass of NKA_HIP_SUMS_BLOCKED_ROUNDED: sum d^2 with d = w1 - f (F08:266-267) over this rank's slice, two streams,
+// per-block partial sums in column 0 of `partials` (k_norm_fin adds them in a fixed order).
+static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_norm_diff(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                                                         double *__restrict__ partials) {
+  const int G = gridDim.x;
+  const double *w1 = vs.w + ctl.pc[PC_FIRST_W];
+  const bool v2 = (reinterpret_cast<uintptr_t>(f) % 16) == 0;      // (slot bases are 256-byte aligned)
+  double acc = 0.0;
+  int64_t done = 0;
+  if (v2) {
+    const int64_t ntile = vs.n / (kBlock * 2);
+    for (int64_t t = blockIdx.x; t < ntile; t += G) {
+      const int64_t e = t * (kBlock * 2) + threadIdx.x * 2;
+      const d2 fv = ld<2>(f + e), wv = ld<2>(w1 + e);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double d = wv[q] - fv[q];
+        acc = fma(d, d, acc);
+      }
+    }
+    done = ntile * (kBlock * 2);
+  }
+  // scalar path: the ragged tail (last block), or everything when f is not 16-byte aligned (grid-stride over elements)
+  if (v2) {
+    if ((int)blockIdx.x == G - 1)
+      for (int64_t i = done + threadIdx.x; i < vs.n; i += kBlock) {
+        const double d = w1[i] - f[i];
+        acc = fma(d, d, acc);
+      }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < vs.n; i += (int64_t)G * kBlock) {
+      const double d = w1[i] - f[i];
+      acc = fma(d, d, acc);
+    }
+  }
+  const double one[1] = {acc};
+  block_reduce_store<1>(one, partials, G);
+}
+// ... and its final sum, one wavefront, into red[0] (zero without a pending pair: nothing stale reaches the exchange)
+static __global__ __launch_bounds__(64) __attribute__((unused)) void k_norm_fin(Ctl ctl, const double *__restrict__ partials, int G) {
+  double r = 0.0;
+  for (int b = threadIdx.x; b < G; b += 64) r += partials[b];
+  r = wave_sum(r);
+  if (threadIdx.x == 0) ctl.red()[0] = ctl.ic[IC_PLAN_PENDING] ? r : 0.0;
 }
 
 // PA with a SMALL ROLLING WINDOW of loads.  tools/hbm_probe (mode f) showed that a
@@ -495,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 // first two sums (d^2, <f,d>) used (k_finalize_dots).
 template <int MAXL, int W>
 __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                     double *__restrict__ partials, int base) {
+                                                     double *__restrict__ partials, int base, int normed) {
   constexpr int VEC = 2;
   using V = typename VecT<VEC>::type;
   constexpr int NACC = 2 * MAXL + 2;
@@ -503,6 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   NKA_STAMP0(ctl, 10);
   const int G = gridDim.x;
   const int pending = ctl.ic[IC_PLAN_PENDING];
+  const double s_n = normed ? sqrt(ctl.red()[0]) : 1.0, rs_n = 1.0 / s_n;      // (see k_dots: sums on the rounded w1')
   const int nolder = ctl.ic[IC_PLAN_NOLDER] - base;        // entries of the plan from `base` on (<= 0: none, every slot dead)
   const long long *pw = ctl.plan_w() + base;
   const double *w1p = vs.w + ctl.pc[PC_FIRST_W];           // (read whether pending or not: no branch around a load)
@@ -544,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
 #pragma unroll
     for (int q = 0; q < VEC; q++) {
       fq[q] = ex(fv, q);
-      dq[q] = ex(w1v, q) - fq[q];                      // F08:266
+      dq[q] = pa_operand(ex(w1v, q) - fq[q], normed, s_n, rs_n);      // F08:266 (and F08:283 when the norm is known)
       acc[0] = fma(dq[q], dq[q], acc[0]);
       acc[1] = fma(fq[q], dq[q], acc[1]);
     }
@@ -568,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void k_dots_win(Ctl ctl, Vecs vs, const dou
   if ((int)blockIdx.x == G - 1) {  // ragged tail, scalar
     for (int64_t i = ntile * (kBlock * VEC) + threadIdx.x; i < vs.n; i += kBlock) {
       const double fq = f[i];
-      const double d = w1[i] - fq;
+      const double d = pa_operand(w1[i] - fq, normed, s_n, rs_n);
       acc[0] = fma(d, d, acc[0]);
       acc[1] = fma(fq, d, acc[1]);
 #pragma unroll
@@ -595,7 +653,7 @@ constexpr int kFinThreads = 64;
 // scalar step gathers them; red[] is then written by that gather.
 template <int MAXL>
 __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const double *__restrict__ partials, int G,
-                                                               int pass, int ncover, int base, P2P x) {
+                                                               int pass, int ncover, int base, P2P x, int keep0 = 0) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
   const bool p2p = x.base != nullptr;
@@ -624,7 +682,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_dots(Ctl ctl, const do
   int dst = -1;
   bool live = false;
   if (c < 2) {
-    if (pass == 0) { dst = c; live = pending != 0; }
+    if (pass == 0 && !(keep0 && c == 0)) { dst = c; live = pending != 0; }      // (keep0: red[0] holds the norm of a pass of its own)
   } else if (c < 2 + MAXL) {
     const int p = base + (c - 2);
     if (p < ctl.mvec) { dst = 2 + p; live = pending && p < nolder; }

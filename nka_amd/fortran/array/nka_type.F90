@@ -92,7 +92,7 @@ module nka_type
   end type nka
 
   public :: NKA_HIP_FLAVOR_F08, NKA_HIP_FLAVOR_F08_VECTOR, NKA_HIP_FLAVOR_C, NKA_HIP_FLAVOR_DEFAULT
-  public :: NKA_HIP_SUMS_AUTO, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED
+  public :: NKA_HIP_SUMS_AUTO, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED, NKA_HIP_SUMS_BLOCKED_ROUNDED
 
 contains
 
@@ -275,7 +275,9 @@ contains
 
   !! How the inner products are summed (nka_hip_set_sum_order, include/nka_hip.h): NKA_HIP_SUMS_REFERENCE_ORDER = every sum
   !! as the reference forms it (an update then returns the reference's bits at any n; single rank; slow beyond a few
-  !! thousand elements), NKA_HIP_SUMS_BLOCKED = the fast passes at every n, NKA_HIP_SUMS_AUTO (default) = reference order
+  !! thousand elements), NKA_HIP_SUMS_BLOCKED = the fast passes at every n, NKA_HIP_SUMS_BLOCKED_ROUNDED = the fast passes with
+  !! the norm first and the Gram row on the rounded w1' (+4-5 % time, the closest to the reference the fast passes get),
+  !! NKA_HIP_SUMS_AUTO (default) = reference order
   !! where it costs nothing (n <= 64).
   subroutine set_sum_order(this, order)
     class(nka), intent(inout) :: this

@@ -11,7 +11,8 @@ module nka_hip_c
   integer(c_int), parameter :: NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2
   !! resolved by nka_hip_create: environment NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
   integer(c_int), parameter :: NKA_HIP_FLAVOR_DEFAULT = -1
-  integer(c_int), parameter :: NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2
+  integer(c_int), parameter :: NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2, &
+                               NKA_HIP_SUMS_BLOCKED_ROUNDED = 3
 
   interface
     integer(c_int) function nka_hip_create(handle, vlen_local, mvec, vtol, flavor, device, stream) bind(C)

@@ -17,7 +17,7 @@ from . import _lib
 
 FLAVOR_F08, FLAVOR_F08_VECTOR, FLAVOR_C = 0, 1, 2
 FLAVOR_DEFAULT = -1     # resolved by the library: NKA_HIP_FLAVOR, else compact storage (include/nka_hip.h)
-SUMS_AUTO, SUMS_REFERENCE_ORDER, SUMS_BLOCKED = 0, 1, 2     # nka_hip_set_sum_order (include/nka_hip.h)
+SUMS_AUTO, SUMS_REFERENCE_ORDER, SUMS_BLOCKED, SUMS_BLOCKED_ROUNDED = 0, 1, 2, 3     # nka_hip_set_sum_order (include/nka_hip.h)
 
 
 class NKAError(RuntimeError):

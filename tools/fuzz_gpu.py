@@ -78,13 +78,19 @@ def _pairwise_dot(x, y):
     return float(np.add.reduce(np.asarray(x) * np.asarray(y)))
 
 
-def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, strict=True):
+def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, strict=True, sums=None):
     rng, n, m, flavor = array_shape(seed, hostdot)
     # how the sums are formed (nka_hip_set_sum_order), by seed: the fast blocked passes at every n / the default (reference
-    # order up to n = 64) / reference order at every n -- where the order is the reference's the outputs must be its BITS
-    sums = (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER)[seed % 3]
+    # order up to n = 64) / reference order at every n -- where the order is the reference's the outputs must be its BITS.
+    # Seeds from 300 000 on rotate through FOUR modes: the fourth is NKA_HIP_SUMS_BLOCKED_ROUNDED (round 5: the norm first, the
+    # Gram row on the rounded w1').  `sums` overrides the rotation (the regression test replays recorded seeds in another mode).
+    names = {nka_amd.SUMS_BLOCKED: "blocked", nka_amd.SUMS_AUTO: "auto", nka_amd.SUMS_REFERENCE_ORDER: "reference",
+             nka_amd.SUMS_BLOCKED_ROUNDED: "rounded"}
+    if sums is None:
+        sums = (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER)[seed % 3] if seed < 300_000 else \
+            (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER, nka_amd.SUMS_BLOCKED_ROUNDED)[seed % 4]
     same_bits = not hostdot and (sums == nka_amd.SUMS_REFERENCE_ORDER or (sums == nka_amd.SUMS_AUTO and n <= 64))
-    key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}" + ("" if hostdot else f" sums {('blocked', 'auto', 'reference')[seed % 3]}")
+    key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}" + ("" if hostdot else f" sums {names[sums]}")
     acc = nka_amd.nka().init(n, m, flavor=flavor).set_sum_order(sums)
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)
@@ -289,8 +295,14 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
     # (Seeds below 100 000 keep their meaning: tests/golden/soak_cases.json names some of them.)
     p2p = seed >= 100_000 and seed % 2 == 1
     same_bits = seed >= 100_000 and (seed // 2) % 2 == 1
+    # ... and from 300 000 on every other reference-order slot is taken by NKA_HIP_SUMS_BLOCKED_ROUNDED (the norm first -- a second
+    # exchange per update --, then the Gram row on the rounded w1'): judged by the truth rule like the fast passes
+    rounded = seed >= 300_000 and same_bits and (seed // 4) % 2 == 1
+    if rounded:
+        same_bits = False
     key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}" + \
-          ((" p2p" if p2p else " staged") + (" sums reference" if same_bits else " sums blocked") if seed >= 100_000 else "")
+          ((" p2p" if p2p else " staged") + (" sums rounded" if rounded else " sums reference" if same_bits else " sums blocked")
+           if seed >= 100_000 else "")
     lo, hi = nd.slice_bounds(n, world, rank)
 
     def hook(ptr, count, stream):
@@ -307,6 +319,8 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
         a.set_shard(rank, world)
         if same_bits:
             a.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+        if rounded:
+            a.set_sum_order(nka_amd.SUMS_BLOCKED_ROUNDED)
         return a
 
     acc = attach(nka_amd.nka().init(hi - lo, m, flavor=flavor))
