@@ -298,11 +298,13 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
     # ... and from 300 000 on every other reference-order slot is taken by NKA_HIP_SUMS_BLOCKED_ROUNDED (the norm first -- a second
     # exchange per update --, then the Gram row on the rounded w1'): judged by the truth rule like the fast passes
     rounded = seed >= 300_000 and same_bits and (seed // 4) % 2 == 1
+    if os.environ.get("NKA_FUZZ_FORCE_ROUNDED") == "1" and not same_bits:
+        rounded = True           # (the regression test replays recorded blocked-mode seeds with the Gram row on the rounded w1')
     if rounded:
         same_bits = False
     key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}" + \
           ((" p2p" if p2p else " staged") + (" sums rounded" if rounded else " sums reference" if same_bits else " sums blocked")
-           if seed >= 100_000 else "")
+           if seed >= 100_000 else (" sums rounded" if rounded else ""))
     lo, hi = nd.slice_bounds(n, world, rank)
 
     def hook(ptr, count, stream):
