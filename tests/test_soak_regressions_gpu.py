@@ -89,7 +89,7 @@ def test_sharded_array_flavour_soak_case(case, tmp_path):
     assert worst > 0.0
 
 
-@pytest.mark.parametrize("case", [c for c in _ids("sharded") if c.values[0]["elements"] > 512])
+@pytest.mark.parametrize("case", [c for c in _ids("sharded") if c.values[0]["elements"] > 512 and "rounded" not in c.values[0]["shape"]])
 def test_sharded_soak_cases_beyond_one_tile_stay_within_the_rule_with_the_rounded_gram_row(case, tmp_path):
     """The recorded sharded exceedances beyond one tile (n = 1 660 and n = 1 013 over three ranks), replayed with
     NKA_HIP_SUMS_BLOCKED_ROUNDED (the norm first -- a second exchange per update --, the Gram row on the rounded w1'): the one
