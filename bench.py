@@ -60,6 +60,8 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  widths, physical roofline at the actual list length with PMC traffic.
   out_of_place_entry (N = 1, headline run only): the headline workload through the opt-in nka_hip_accel_update_swap
                  (two store streams less in PB; bit-identical results).
+  sum_mode_blocked_rounded (N = 1, headline run only): the headline workload in the opt-in sum mode NKA_HIP_SUMS_BLOCKED_ROUNDED
+                 (the norm first, the Gram row on the rounded w1': the closest to the reference the fast passes get).
   config2_n1e7_m10 (N = 1, headline run only): BASELINE configs[1] (n = 1e7, m = 10) measured in the same
                  run on the first 1e7 elements of the resident inputs (updates/s, whole-update fraction).
   config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
@@ -956,6 +958,19 @@ def main(argv=None):
         finally:
             a4.delete()                 # (before the input rows it holds are released)
 
+    def rounded_mode_extra():
+        """The opt-in sum mode NKA_HIP_SUMS_BLOCKED_ROUNDED on the headline workload: the norm in a pass of its own, then PA on the
+        rounded w1' (the Gram row as the reference defines it): 51 instead of 49 words per element and one kernel pair more."""
+        a6 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor]).set_sum_order(nka_amd.SUMS_BLOCKED_ROUNDED)
+        try:
+            e6, mean6, nv6, nv6_end, _, stats6 = measure(a6, "full")
+            return {"mode": "nka_hip_set_sum_order(NKA_HIP_SUMS_BLOCKED_ROUNDED): norm pass + PA on the rounded w1' (include/nka_hip.h)",
+                    "value": K / e6, "unit": "updates/s", "ms_per_step": 1e3 * e6 / K, "steady_state": bool(nv6 == m and nv6_end == m),
+                    "phase_ms": {"norm_pass_and_PA": mean6[0], "k_solve": mean6[1], "PB_k_combine": mean6[2]},
+                    "words_per_element": 2 + sum(words_moved(FLAVOR_NAMES[a6.flavor()], m, m).values())}
+        finally:
+            a6.delete()
+
     drops = None
     headline = world == 1 and (n_global, m) == (10**8, 20) and args.workload == "full" and not args.no_cpu_baseline
     if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
@@ -963,6 +978,12 @@ def main(argv=None):
             drops = with_drops_extra()
         except Exception as exc:           # an extra, never the measured path
             drops = {"value": None, "error": repr(exc)}
+    rounded = None
+    if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+        try:
+            rounded = rounded_mode_extra()
+        except Exception as exc:           # an extra, never the measured path
+            rounded = {"value": None, "error": repr(exc)}
     oop = None
     if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
         try:
@@ -1035,6 +1056,10 @@ def main(argv=None):
             out["with_drops"] = drops
         if oop is not None:
             out["out_of_place_entry"] = oop
+        if rounded is not None:
+            out["sum_mode_blocked_rounded"] = rounded
+            if rounded.get("value"):
+                out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]      # (flat: survives a scalars-only record)
         if headline:
             try:
                 c2 = config2_line()
