@@ -1127,6 +1127,8 @@ def main(argv=None):
                 nested, flat = reference_rounding_entry(also)
                 out["roofline"]["reference_rounding"] = nested
                 out["roofline"].update(flat)
+            if rounded is not None and rounded.get("value"):
+                out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]
             if host_arr is not None:
                 out["host_array_entry"] = host_arr
                 for kind in ("pageable", "pinned"):
