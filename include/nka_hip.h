@@ -210,14 +210,14 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
  *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden
  *       scenario of the reference among them) -- blocked otherwise.
- * A user dot product (nka_hip_set_host_dot) overrides all three.  Can be changed between updates.  REFERENCE_ORDER is
- * offered up to mvec = 250 (NKA_HIP_EINVAL beyond). */
-/*   NKA_HIP_SUMS_BLOCKED_ROUNDED  (round 5) the fast passes, but the norm first, in a short pass of its own (two streams: 51 instead
+ *   NKA_HIP_SUMS_BLOCKED_ROUNDED  (round 5) the fast passes, but the norm first, in a short pass of its own (two streams: 51 instead
  *       of 49 words per element, one more exchange when sharded), and PA then on the ROUNDED w1' = fl(d/s) -- the vector that is
  *       stored: <w1',w_k> and <f,w1'> are then inner products of the stored vectors, as the reference defines them (F08:283-290,
  *       371), instead of fl(<d,w_k>/s).  That removes the one deviation of the fast passes that is not "a more accurate sum":
- *       what remains is the blocked order and the fma.  For callers who put parity before the last 4-5 % of speed; the bounds
- *       of the numerical contract hold a fortiori (soak of this mode: profiles/r05/fuzz_soak.txt). */
+ *       what remains is the blocked order and the fma.  For callers who put parity before 5-9 % of speed
+ *       (profiles/r05/rounded_gram_row.txt); the bounds of the numerical contract are the same.
+ * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates.  REFERENCE_ORDER is
+ * offered up to mvec = 250 (NKA_HIP_EINVAL beyond). */
 enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2, NKA_HIP_SUMS_BLOCKED_ROUNDED = 3 };
 int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
 /* Position of this rank's slice in the global vector: slice `rank` of `nranks`, slices laid out in rank order (the
