@@ -523,7 +523,8 @@ typedef int (*nka_hip_host_allreduce_fn)(void *ctx, double *host_vals, int32_t c
  * (vector_class.F90), and the vector flavour of the accelerator returns the bits of the reference on the same vector
  * type.  Works with the parallel-aware reductions too (ordered partial sums per rank, summed by the hook -- the
  * reference's own parallel contract).  n sequential additions per dot product: a validation mode.
- * NKA_HIP_SUMS_BLOCKED (= _AUTO, the default): the fast reductions. */
+ * NKA_HIP_SUMS_BLOCKED (= _AUTO, the default): the fast reductions.  NKA_HIP_SUMS_BLOCKED_ROUNDED: the fast reductions, but the device
+ * vector types keep the norm stage a pass of its own, so that the Gram row is summed on the ROUNDED pair (see nka_hip_set_sum_order). */
 int nka_hip_vec_set_sum_order(nka_hip_vec_ws_t ws, int32_t order);
 int nka_hip_vec_get_sum_order(nka_hip_vec_ws_t ws);      /* NKA_HIP_SUMS_REFERENCE_ORDER or NKA_HIP_SUMS_BLOCKED; <0 on error */
 int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx);

@@ -1527,14 +1527,17 @@ int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, c
 // ---- parallel-aware reductions: hooks on the workspace (include/nka_hip.h) ------------------
 int nka_hip_vec_set_sum_order(nka_hip_vec_ws_t ws, int32_t order) {
   if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
-  if (order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED && order != NKA_HIP_SUMS_AUTO)
-    return nka_detail::set_error(NKA_HIP_EINVAL, "vec_set_sum_order: NKA_HIP_SUMS_REFERENCE_ORDER, _BLOCKED (or _AUTO = blocked)");
-  ws->sum_order = order == NKA_HIP_SUMS_REFERENCE_ORDER ? 1 : 0;
+  if (order != NKA_HIP_SUMS_REFERENCE_ORDER && order != NKA_HIP_SUMS_BLOCKED && order != NKA_HIP_SUMS_AUTO &&
+      order != NKA_HIP_SUMS_BLOCKED_ROUNDED)
+    return nka_detail::set_error(NKA_HIP_EINVAL, "vec_set_sum_order: NKA_HIP_SUMS_REFERENCE_ORDER, _BLOCKED (or _AUTO = blocked), _BLOCKED_ROUNDED");
+  // (3 = blocked sums, but the vector types keep the norm stage a pass of its own, so that the Gram row is summed on the ROUNDED
+  //  pair -- the reductions of this library sum in blocks either way: only the vector types read the difference)
+  ws->sum_order = order == NKA_HIP_SUMS_REFERENCE_ORDER ? 1 : order == NKA_HIP_SUMS_BLOCKED_ROUNDED ? 3 : 0;
   return 0;
 }
 int nka_hip_vec_get_sum_order(nka_hip_vec_ws_t ws) {
   if (!ws) return nka_detail::set_error(NKA_HIP_EINVAL, "null workspace");
-  return ws->sum_order == 1 ? NKA_HIP_SUMS_REFERENCE_ORDER : NKA_HIP_SUMS_BLOCKED;
+  return ws->sum_order == 1 ? NKA_HIP_SUMS_REFERENCE_ORDER : ws->sum_order == 3 ? NKA_HIP_SUMS_BLOCKED_ROUNDED : NKA_HIP_SUMS_BLOCKED;
 }
 
 int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx) {

@@ -84,7 +84,7 @@ module hip_block_vector_type
   public :: hip_block_vector_workspace
   public :: hip_block_vector_use_rccl, hip_block_vector_set_allreduce, hip_block_vector_set_host_allreduce
   public :: hip_block_vector_allreduce_now
-  public :: hip_block_vector_set_sum_order, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED
+  public :: hip_block_vector_set_sum_order, NKA_HIP_SUMS_REFERENCE_ORDER, NKA_HIP_SUMS_BLOCKED, NKA_HIP_SUMS_BLOCKED_ROUNDED
 
 contains
 
@@ -444,7 +444,8 @@ contains
     vals_this = 0.0_r8
     vals_x = 0.0_r8
     cross = 0.0_r8
-    fused = defer_scale_enabled() .and. fuse_norm_enabled() .and. .not. reference_order(this)      ! (any list length since round 5:
+    fused = defer_scale_enabled() .and. fuse_norm_enabled() .and. .not. reference_order(this) &     ! (any list length since round 5:
+            .and. nka_hip_vec_get_sum_order(this%ws) /= NKA_HIP_SUMS_BLOCKED_ROUNDED                ! (rounded: the norm stays a pass of its own)
                                                                   ! the library runs balanced groups of at most 24 vectors)
     if (.not. fused) then
       s = update_norm2_fused(this, a, x, stored)
@@ -665,8 +666,9 @@ contains
     reference_order = nka_hip_vec_get_sum_order(this%ws) == NKA_HIP_SUMS_REFERENCE_ORDER
   end function
 
-  !! call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER | NKA_HIP_SUMS_BLOCKED): nka_hip_vec_set_sum_order
-  !! for every vector that shares the workspace (include/nka_hip.h).
+  !! call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER | NKA_HIP_SUMS_BLOCKED | NKA_HIP_SUMS_BLOCKED_ROUNDED):
+  !! nka_hip_vec_set_sum_order for every vector that shares the workspace (include/nka_hip.h).  _BLOCKED_ROUNDED keeps the norm stage
+  !! a pass of its own, so that the Gram row is summed on the rounded pair (what NKA_HIP_VEC_FUSE_NORM=0 did for the tests).
   subroutine hip_block_vector_set_sum_order(ws, order)
     type(c_ptr), intent(in) :: ws
     integer, intent(in) :: order

@@ -61,6 +61,7 @@ program nka_vector_driver
   character(256) :: mode, arg, outfile, shmfile, scriptfile
   integer :: nfield, mvec, ncalls, icompact = 0, rtile = 1, rank = 0, world = 1, irccl = 0
   logical :: compact, grid = .false., refsum = .false.   ! (compact argument + 10: sums in the reference's order)
+  logical :: rounded = .false.                           ! (compact argument + 20: NKA_HIP_SUMS_BLOCKED_ROUNDED)
   integer(i8) :: nper
   integer(i8) :: lcg_state = 1
 
@@ -92,7 +93,7 @@ program nka_vector_driver
     if (command_argument_count() >= 7) then
       call get_command_argument(7, arg); read(arg,*) icompact
     end if
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_check
   case ('script')
     call get_command_argument(6, outfile)
@@ -103,7 +104,7 @@ program nka_vector_driver
       call get_command_argument(10, arg); read(arg,*) world
       call get_command_argument(11, shmfile)
     end if
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_script
   case ('shard')
     call get_command_argument(6, outfile)
@@ -114,27 +115,27 @@ program nka_vector_driver
     if (command_argument_count() >= 11) then
       call get_command_argument(11, arg); read(arg,*) irccl
     end if
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_shard
   case ('checkgrid')
     call get_command_argument(6, outfile)
     if (command_argument_count() >= 7) then
       call get_command_argument(7, arg); read(arg,*) icompact
     end if
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_checkgrid
   case ('checktile')
     call get_command_argument(6, outfile)
     call get_command_argument(7, arg); read(arg,*) icompact
     call get_command_argument(8, arg); read(arg,*) rtile
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_checktile
   case ('bench', 'benchgrid')
     grid = trim(mode) == 'benchgrid'
     if (command_argument_count() >= 6) then
       call get_command_argument(6, arg); read(arg,*) icompact
     end if
-    refsum = icompact >= 10; compact = mod(icompact, 10) /= 0
+    refsum = icompact >= 10 .and. icompact < 20; rounded = icompact >= 20; compact = mod(icompact, 10) /= 0
     call run_bench
   case default
     error stop 'usage: nka_vector_driver check|bench NFIELD NPER MVEC NCALLS [OUTFILE]'
@@ -157,6 +158,7 @@ contains
     n = nfield * nper
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     call f%init(nfield, nper, ws)
     call accel%init(f, mvec, compact=compact)
     allocate(host(n), pool(n,3), coef(3))
@@ -206,6 +208,7 @@ contains
     hi = nper
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     if (world > 1) then
       call slice_bounds(nper, rank, lo, hi)
       shm = shm_ar_open(trim(shmfile)//c_null_char, int(world, c_int), int(rank, c_int))
@@ -279,6 +282,7 @@ contains
     nloc = hi - lo
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     shm = shm_ar_open(trim(shmfile)//c_null_char, int(world, c_int), int(rank, c_int))
     if (.not. c_associated(shm)) error stop 'shard: cannot map the all-reduce file'
     if (irccl /= 0) then            ! the device-side hook: RCCL on a one-rank communicator (this box has one GPU)
@@ -339,6 +343,7 @@ contains
     ny = int(nper)
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     call f%init_grid(nx, ny, ws)
     call accel%init(f, mvec, compact=compact)
     allocate(host(0:nx+1,0:ny+1), pool(0:nx+1,0:ny+1,3), coef(3))
@@ -388,6 +393,7 @@ contains
     nperbig = nper * rtile
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     call f%init(nfield, nperbig, ws)
     call accel%init(f, mvec, compact=compact)
     allocate(small(n0), big(nbig), pool(n0,3), coef(3))
@@ -445,6 +451,7 @@ contains
     ninp = warm + ncalls
     ws = hip_block_vector_workspace(0)
     if (refsum) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER)
+    if (rounded) call hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED)
     if (grid) then            ! NX = nfield, NY = nper: one field of NX*NY cells plus the ghost ring
       allocate(hip_grid_vector :: f)
       allocate(hip_grid_vector :: inputs(ninp))

@@ -84,6 +84,33 @@ def test_abstract_vector_flavour_on_device_block_vector(fortran_build, oracle, t
 @pytest.mark.gpu
 @pytest.mark.parametrize("compact", [0, 1])
 @pytest.mark.parametrize("mode,dims,mvec,ncalls", [("check", (4, 2503), 20, 45), ("check", (4, 25003), 30, 50),
+                                                   ("checkgrid", (33, 17), 20, 45)])
+def test_rounded_sum_mode_of_the_workspace_is_the_separate_norm_stage(fortran_build, tmp_path, mode, dims, mvec, ncalls,
+                                                                      compact):
+    """hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_BLOCKED_ROUNDED) (the driver's compact argument + 20) is the
+    caller-visible form of what NKA_HIP_VEC_FUSE_NORM=0 does for the tests: the norm as a pass of its own, the Gram
+    row summed on the rounded pair.  Same bits call after call, whatever the environment says about fusing."""
+    outs = []
+    for icompact, fuse in ((compact, "0"), (compact + 20, "1")):
+        out = tmp_path / f"r{icompact}.bin"
+        p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), mode, str(dims[0]), str(dims[1]),
+                            str(mvec), str(ncalls), str(out), str(icompact)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, NKA_HIP_VEC_FUSE_NORM=fuse))
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
+    fused = tmp_path / "fused.bin"                       # (and the mode is not a no-op: the fused default rounds differently)
+    p = subprocess.run([os.path.join(fortran_build, "nka_vector_driver"), mode, str(dims[0]), str(dims[1]),
+                        str(mvec), str(ncalls), str(fused), str(compact)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, NKA_HIP_VEC_FUSE_NORM="1"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    if mode == "check":
+        assert fused.read_bytes() != outs[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("mode,dims,mvec,ncalls", [("check", (4, 2503), 20, 45), ("check", (4, 25003), 30, 50),
                                                    ("checkgrid", (33, 17), 20, 45), ("checkgrid", (7, 5), 3, 14)])
 def test_deferred_normalisation_through_the_front_end_is_bit_identical(fortran_build, tmp_path, mode, dims, mvec, ncalls,
                                                                        compact):
