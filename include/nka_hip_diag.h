@@ -36,7 +36,9 @@ extern "C" {
  * ring of their window kernels is the whole width (up to 311 VGPRs and scratch in PA): -1 automatic (= 1) both passes run them
  * at the next width with one dead ring slot; 0 = exact widths everywhere (profiles/r05/multipass.txt).  Same bits.
  * "fail_after_solve" = 1: the NEXT update returns NKA_HIP_EHIP right behind its enqueued scalar step, as a failing HIP call
- * there would: the handle must then be poisoned (every later call but destroy: NKA_HIP_ESTATE). */
+ * there would: the handle must then be poisoned (every later call but destroy: NKA_HIP_ESTATE).
+ * "chain_walk" = 0/1: reference-order sums of long vectors (k_chain_sums) walk every block element after element instead of
+ * taking whole blocks through the chain in integer arithmetic (chain_block_fast).  Same bits. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */
@@ -45,6 +47,13 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa_blocks_per_cu, int32_t pb_blocks_pe
 /* Measurement aid: mean device time (ms) of the pure-read pass PA of the NEXT update,
  * launched `reps` times back to back (it only writes scratch: state unchanged). */
 int nka_hip_debug_time_pa(nka_hip_t a, const double *f_dev, int32_t reps, float *ms_mean);
+
+/* Test bench of the reference-order sums of long vectors: start + x[0]*y[0] + x[1]*y[1] + ... (one rounding per product and
+ * per addition, in that order) over any two device arrays of n doubles, formed by the kernel the update uses (k_chain_sums, one
+ * workgroup).  walk = 1: every block element after element; 0: whole blocks through the chain where that is provably the same
+ * (chain_block_fast).  *ms (optional) = the kernel's device time.  The handle's state is not touched (scratch only). */
+int nka_hip_debug_chain_sum(nka_hip_t a, const double *x_dev, const double *y_dev, int64_t n, double start, int32_t walk,
+                            double *sum, float *ms);
 
 /* Diagnostic builds of the library (-DNKA_SOLVE_STAMPS) stamp the phases of the
  * one-wavefront scalar step with s_memtime; this returns the 16 stamps of the most

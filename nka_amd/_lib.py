@@ -123,6 +123,8 @@ DIAG_SIGNATURES = {
     "nka_hip_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nka_hip_set_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "nka_hip_debug_time_pa": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "nka_hip_debug_chain_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int32,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "nka_hip_get_stamps": (C.c_int, [C.c_void_p, _dp]),
     "nka_hip_vec_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
 }

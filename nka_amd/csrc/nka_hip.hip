@@ -225,6 +225,7 @@ struct nka_hip_state {
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
+  int chain_walk = 0;         // diagnostic switch "chain_walk": k_chain_sums walks every block element after element (A/B of chain_block_fast)
   int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
   int fail_after_solve = 0;   // diagnostic switch "fail_after_solve": the next update fails as if a HIP call behind its scalar step had
                               // (the test of the poisoned-handle path: the failure itself cannot be provoked from outside)
@@ -667,6 +668,15 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     }
   }
 
+  {   // ... and, for long vectors, a group of products per sum (k_chain_sums)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_sums), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kChainLdsBytes);
+    if (e != hipSuccess) {
+      delete a;
+      return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(e));
+    }
+  }
+
   // Slot-major storage (F08:163-164, 196): slot k holds n contiguous doubles;
   // the slot stride is padded to 256 B so every slot base allows 16-B loads.
   // (A skew of the slots across HBM channels was measured in round 2 and has no
@@ -876,6 +886,7 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tile = src->pb_tile;
   b->pb_tickets = src->pb_tickets;
   b->prime_pad = src->prime_pad;
+  b->chain_walk = src->chain_walk;
   b->serial_solve = src->serial_solve;
   b->sum_order = src->sum_order;
   b->shard_rank = src->shard_rank;
@@ -1226,17 +1237,31 @@ static bool held_by_library(const nka_hip_state *a, const double *p) {
 // order, so ANY hook that sums serves as the chain's transport.  N rounds for the norm (the Gram row needs the GLOBAL s
 // before w1' = d/s can be rounded), N rounds for the rows: 2N small exchanges and the serial walk of the whole global
 // vector per update -- validation speed, bits of the single-rank compiled reference.
+// (beyond one chunk of k_dots_ordered: one workgroup per sum, k_chain_sums)
+static bool chain_per_sum(const nka_hip_state *a, int rows) { return a->n > ord_chunk(rows); }
+
 static int ordered_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
   hipStream_t s = a->stream;
   const int N = a->shard_n, me = a->shard_rank;
   const int rows = 2 + older_ub, count = a->ctl.red_count();
   double *red = a->ctl.red();
+  const bool per_sum = chain_per_sum(a, rows);
   auto exchange = [&](double *buf, int cnt) -> int {
     if (int rc = a->allreduce(a->allreduce_ctx, buf, cnt, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
     return 0;
   };
   auto round = [&](int r, int phase, double *buf, int cnt) -> int {
-    if (r == me) {
+    if (r == me && per_sum) {
+      // every chain continues from what red[] holds: the prefix of the ranks before this one, or zeros on the first rank
+      // (the norm rounds exchange red[0] alone; the rows rounds everything behind it)
+      if (r == 0) HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)cnt, s));
+      if (phase == kOrdNorm)
+        hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
+      else
+        hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                           (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
+      HIP_TRY(hipGetLastError());
+    } else if (r == me) {
       hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
                          ord_chunk(rows), phase, r > 0 ? 1 : 0);
       HIP_TRY(hipGetLastError());
@@ -1322,8 +1347,18 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     RoctxRange range("nka:PA dots in the reference's order");
     if (a->pending || older_ub > 0) {
       const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
-      hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
-                         ord_chunk(rows), (int)kOrdAll, 0);
+      if (chain_per_sum(a, rows)) {
+        // long vectors: one workgroup per sum; the norm and the sums on f alone first, then those on the rounded w1'
+        HIP_TRY(hipMemsetAsync(a->ctl.red(), 0, sizeof(double) * (size_t)a->ctl.red_count(), s));
+        hipLaunchKernelGGL(k_chain_sums, dim3(1 + older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                           (int)kChainNorm, 1, older_ub, a->chain_walk, (const double *)nullptr);
+        if (a->pending)
+          hipLaunchKernelGGL(k_chain_sums, dim3(1 + older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                             (int)kChainRows, 0, older_ub, a->chain_walk, (const double *)nullptr);
+      } else {
+        hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
+                           ord_chunk(rows), (int)kOrdAll, 0);
+      }
       HIP_TRY(hipGetLastError());
     }
     mode |= kSolvePrenorm;
@@ -1936,6 +1971,32 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
 // Measurement aid: the PA launches of the NEXT update, `reps` times back to back on the
 // handle's stream, timed with HIP events (mean ms per repetition).  PA only writes
 // scratch (partials, red[]), so the state is unchanged.
+// start + x[0]*y[0] + x[1]*y[1] + ... as the per-sum reference-order kernel forms it (k_chain_sums on one workgroup),
+// over ANY two device arrays: the test bench of chain_block_fast (walk = 1: every block element after element).
+int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64_t n, double start, int32_t walk, double *sum,
+                            float *ms) {
+  if (!a || !sum || n < 0 || (n > 0 && (!x || !y))) return fail(NKA_HIP_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(a->device));
+  Vecs vs = a->vs;
+  vs.n = n;
+  double *slot = a->ctl.red() + 2 + a->mvec;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipMemcpyAsync(slot, &start, sizeof(double), hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  HIP_TRY(hipEventRecord(e0, a->stream));
+  hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, a->stream, a->ctl, vs, x, 0, (int)kChainProbe, 1, 0, (int)walk, y);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, a->stream));
+  HIP_TRY(hipMemcpyAsync(sum, slot, sizeof(double), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  if (ms) HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return 0;
+}
+
 int nka_hip_debug_time_pa(nka_hip_t a, const double *f, int32_t reps, float *ms_mean) {
   if (!a || !f || !ms_mean || reps < 1) return fail(NKA_HIP_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(a->device));
@@ -1981,6 +2042,8 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   } else if (k == "prime_pad") {      // -1 automatic = 1: list lengths 23 / 29 / 31 run the next width (one dead ring slot); 0: exact widths
     if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1");
     a->prime_pad = value;
+  } else if (k == "chain_walk") {     // 1: the per-sum reference-order kernel walks every block (no chain_block_fast): same bits, for A/B
+    a->chain_walk = value != 0;
   } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)
     a->pb_reverse = value != 0;
   } else if (k == "serial_solve") {

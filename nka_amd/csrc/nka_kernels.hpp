@@ -896,6 +896,377 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
     if (dst[q] >= 0 && (normed || !on_w1)) red[dst[q]] = acc[q];
 }
 
+// ---- The same sums, ONE WORKGROUP PER SUM (round 5, long vectors) ----------------------------------
+// k_dots_ordered walks every sum on one compute unit and waits for each chunk's loads before it adds: 40 ns per element.
+// A sequential sum is a chain of n dependent roundings whatever is done, but (1) the 2 + 2L sums of an update are
+// independent chains once the norm is known, (2) the products are not part of any chain and (3) -- see chain_block_fast --
+// while the running sum stays inside one binade its roundings are roundings to a FIXED grid, which is integer
+// arithmetic and therefore associative.  Here sum c has workgroup c to itself: all 256 threads load the next group of
+// elements and round the products into LDS while wavefront 0 takes the previous group through the chain, 512 elements
+// per step.  Two launches per update: set kChainNorm = the norm (block 0) and, with `with_f`, the sums on f alone (blocks
+// 1..ub); set kChainRows = with s from red[0], <f,w1'> (block 0), the Gram row on the ROUNDED w1' (blocks 1..ub) and,
+// with `with_f`, the sums on f alone (blocks ub+1..2ub) -- the sharded rounds of ordered_chain take the second form (their
+// norm rounds hold red[0] only).  EVERY chain starts from the value red[] holds: the host zeroes red[] where no prefix of
+// other ranks is to be continued (0 + p == p: the same bits as starting at 0).
+constexpr int kChainWaves = 8;
+constexpr int kChainThreads = 64 * kChainWaves;
+constexpr int kChainLaneElems = 16;                               // consecutive elements of a block per lane
+constexpr int kChainBlock = 64 * kChainLaneElems;                 // elements per step of the chain
+constexpr int kChainGroupBlocks = kChainWaves;                    // one block of a group per wavefront
+constexpr int kChainGroup = kChainGroupBlocks * kChainBlock;      // elements whose products are in LDS at a time
+constexpr int kChainPerThread = kChainGroup / kChainThreads;
+constexpr int kChainRow = 2 * 64 + 4;                             // doubles between the PAIR rows of a block in LDS: row k holds
+                                                                  // elements 2k, 2k+1 of every lane, lane after lane -- the
+                                                                  // lanes of a wavefront read 16 bytes each, side by side
+constexpr int kChainBlockLds = (kChainLaneElems / 2) * kChainRow;
+constexpr int kChainGroupLds = kChainGroupBlocks * kChainBlockLds;
+constexpr size_t kChainLdsBytes = sizeof(double) * kChainGroupLds;   // (dynamic: beyond the 64 KiB of static LDS)
+enum { kChainNorm = 0, kChainRows = 1, kChainProbe = 2 };   // (probe: <f, probe> from red[2 + mvec], diagnostic entry)
+enum { kChainKindNorm = 0, kChainKindFW1 = 1, kChainKindW1W = 2, kChainKindFW = 3 };
+// where element i of a group lies in LDS
+__device__ __forceinline__ int chain_idx(int i) {
+  const int blk = i / kChainBlock, ib = i % kChainBlock;
+  const int lane = ib / kChainLaneElems, j = ib % kChainLaneElems;
+  return blk * kChainBlockLds + (j / 2) * kChainRow + 2 * lane + (j & 1);
+}
+// the 16 products of lane `lane` of a block, in order
+__device__ __forceinline__ void chain_lane_read(double (&p)[kChainLaneElems], const double *blk, int lane) {
+  using V2 = typename VecT<2>::type;
+#pragma unroll
+  for (int k = 0; k < kChainLaneElems / 2; k++) {
+    const V2 v = *reinterpret_cast<const V2 *>(blk + k * kChainRow + 2 * lane);
+    p[2 * k] = v.x;
+    p[2 * k + 1] = v.y;
+  }
+}
+
+// a + p[0] + p[1] + ... + p[len-1] in THAT order, one rounding per addition: the chain as it stands (every lane does the
+// same additions on the same LDS words: no divergence, the sum stays wave-uniform).  One lane's worth (16 products) per
+// step, read while the additions of the step before wait for one another, two steps per trip (no register copies): the
+// loop is the chain of dependent v_add_f64 and little else (2.3 ns each, tools/micro/dep_add.hip).
+__device__ __forceinline__ double chain_block_serial(double a, const double *blk, int len) {
+#pragma clang fp contract(off)
+  const int ng = len / kChainLaneElems;                 // whole lanes
+  int g = 0;
+  if (ng >= 1) {
+    double A[kChainLaneElems], B[kChainLaneElems];
+    chain_lane_read(A, blk, 0);
+    for (; g + 2 <= ng; g += 2) {
+      chain_lane_read(B, blk, g + 1);
+#pragma unroll
+      for (int j = 0; j < kChainLaneElems; j++) a = a + A[j];
+      chain_lane_read(A, blk, g + 3 <= ng ? g + 2 : g);   // (the last trip re-reads: the loads stay unconditional)
+#pragma unroll
+      for (int j = 0; j < kChainLaneElems; j++) a = a + B[j];
+    }
+    if (g < ng) {                                        // (A holds lane g whenever a whole lane remains)
+#pragma unroll
+      for (int j = 0; j < kChainLaneElems; j++) a = a + A[j];
+      g++;
+    }
+  }
+  for (int i = g * kChainLaneElems; i < len; i++) a = a + blk[chain_idx(i)];
+  return a;
+}
+
+// reductions and one scan over the 64 lanes through DPP (row shifts, then the row broadcasts of gfx9)
+template <int CTRL, int RM> __device__ __forceinline__ float dpp_f32(float x, float old) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, RM, 0xf, false));
+}
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i32(int x, int old) {
+  return __builtin_amdgcn_update_dpp(old, x, CTRL, RM, 0xf, false);
+}
+template <int CTRL, int RM> __device__ __forceinline__ double dpp_f64(double x, double old) {
+  union { double d; int u[2]; } a, o, r;
+  a.d = x; o.d = old;
+  r.u[0] = __builtin_amdgcn_update_dpp(o.u[0], a.u[0], CTRL, RM, 0xf, false);
+  r.u[1] = __builtin_amdgcn_update_dpp(o.u[1], a.u[1], CTRL, RM, 0xf, false);
+  return r.d;
+}
+// lane l: the operation over lanes 0..l  (OP 0: +, 1: min, 2: max; `idn` the operation's identity: what lanes without a
+// source take)
+#define NKA_WAVE_SCAN(T, DPP)                                                                        \
+  x = op(x, DPP<0x111, 0xf>(x, idn)); x = op(x, DPP<0x112, 0xf>(x, idn)); x = op(x, DPP<0x114, 0xf>(x, idn)); \
+  x = op(x, DPP<0x118, 0xf>(x, idn)); x = op(x, DPP<0x142, 0xa>(x, idn)); x = op(x, DPP<0x143, 0xc>(x, idn)); \
+  return x;
+template <int OP> __device__ __forceinline__ float wave_scan_f32(float x, const float idn) {
+  auto op = [](float a, float b) { return OP == 0 ? a + b : OP == 1 ? fminf(a, b) : fmaxf(a, b); };
+  NKA_WAVE_SCAN(float, dpp_f32)
+}
+__device__ __forceinline__ int wave_scan_add_i32(int x) {
+  auto op = [](int a, int b) { return a + b; };
+  const int idn = 0;
+  NKA_WAVE_SCAN(int, dpp_i32)
+}
+__device__ __forceinline__ double wave_scan_add_f64(double x) {
+  auto op = [](double a, double b) { return a + b; };
+  const double idn = 0.0;
+  NKA_WAVE_SCAN(double, dpp_f64)
+}
+#undef NKA_WAVE_SCAN
+
+// One step of a chain over a FULL block of products without walking it element after element.
+// While  2^e <= |a| < 2^(e+1)  every representable neighbour of the running sum is a multiple of u = 2^(e-52), so
+// fl(a + p) = u * (S + R(p/u)) with S = |a|/u an integer in [2^52, 2^53) and R the rounding of t = p/u to an integer,
+// halves going to whichever neighbour makes S + R EVEN (round-to-nearest-even acts on the sum's significand).  The
+// additions of integers are exact and associative; the only thing a step inherits from its predecessors is the PARITY of
+// S, and only a halfway case reads it (after which the sum is even whatever it was).  So each lane takes 16 consecutive
+// products: r = rne(t) (t + 1.5*2^52 - 1.5*2^52), the halfway flag |t - r| == 0.5, the plain sum of the r's, its own
+// parity map and the corrections (+-1) a halfway case owes under either incoming parity; ballots carry the parity from
+// lane to lane and one prefix sum places every lane's excursion.  That SUMMARY of a block depends on the running sum only
+// through its sign and exponent (chain_block_summary), so the wavefronts of the workgroup take one block each under the
+// exponent the group starts with; wavefront 0 then walks the summaries (chain_block_apply): a block is accepted iff it
+// was summarised under the sum's present sign and exponent, every prefix provably stays inside the binade and every
+// |t| < 2^48 (r exact, lane sums exact; NaN and Inf fail the comparison).  The prefix bounds are kept in SINGLE precision,
+// rounded to nearest: they are off by < 2^31 units, and the acceptance window leaves 2^34 units (2^-18 of the binade)
+// at either end -- which also covers the corrections (<= 1024) and the one inexact case (sums beyond 2^53 are only ever
+// formed in blocks that leave the window by far more than their error).  Otherwise the block is summarised again under
+// the present exponent or, failing that, walked (chain_block_serial).  Same bits as the walk by construction;
+// tests/test_chain_sums_gpu.py holds the two to each other and to numpy's sequential accumulate on adversarial inputs
+// (halfway cases under both parities, binade crossings, cancellation, zeros, subnormals, overflow, NaN).
+struct ChainSummary {
+  double total;              // sum of the r's
+  float gmin, gmax;          // least / greatest prefix bound
+  int adj;                   // corrections if S starts even (low half) / odd (high half), each biased by kChainAdjBias
+  int hi;                    // sign and exponent word the summary assumed; 0: none, or a product out of range
+};
+constexpr int kChainAdjBias = 64 * kChainLaneElems;
+__device__ __forceinline__ bool chain_scalable(double a) {
+  const int ef = (__double2hiint(a) >> 20) & 0x7ff;
+  return ef >= 1023 - 900 && ef <= 1023 + 900;                    // not zero, subnormal, Inf, NaN; scale factors in range
+}
+__device__ __forceinline__ ChainSummary chain_block_summary(double a, const double *blk) {
+#pragma clang fp contract(off)
+  ChainSummary sm;
+  sm.hi = 0; sm.total = 0.0; sm.gmin = sm.gmax = 0.f; sm.adj = 0;
+  if (!chain_scalable(a)) return sm;
+  const int lane = threadIdx.x & 63;
+  const int hi = __double2hiint(a);
+  const int e = ((hi >> 20) & 0x7ff) - 1023;
+  const double scale = __hiloint2double((hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);    // +-2^(52-e): S > 0
+  constexpr double M = 6755399441055744.0;                         // 1.5 * 2^52
+  double base = 0.0, absl = 0.0;
+  int parw = 0, differ = 1, adj0 = 0, adj1 = 0;                    // (bit 0 of parw: parity under incoming parity 0; whether
+                                                                   //  parity 1 still differs)
+  double pl[kChainLaneElems];
+  chain_lane_read(pl, blk, lane);
+#pragma unroll
+  for (int j = 0; j < kChainLaneElems; j++) {
+    const double t = pl[j] * scale;                                // exact (a power of two), |t| tiny if it underflows
+    const double tm = t + M;                                       // rounds t to an integer, halves to even
+    const double r = tm - M;
+    const double diff = t - r;                                     // exact
+    if (fabs(diff) == 0.5) {                                       // halfway: r is the EVEN neighbour of t, r + 2 diff the odd one
+      const int tau = diff > 0.0 ? 1 : -1;
+      // r being even, S + r has the parity of S: an odd S takes the other neighbour, and the sum is even either way
+      if (parw & 1) adj0 += tau;
+      if ((parw ^ differ) & 1) adj1 += tau;
+      parw = 0; differ = 0;
+    } else {
+      parw ^= __double2loint(tm);
+    }
+    base = base + r;
+    absl = absl + fabs(r);
+  }
+  const int par = parw & 1;
+  const bool bad = !(absl < 0x1p48);                               // some |t| >= 2^48 / Inf / NaN (|t| <= |r| + 1/2 <= absl + 1/2)
+  // where the lane's excursion lies: the prefix before it +- its own absolute sum, in single precision
+  const float basef = (float)base, abslf = (float)absl;
+  const float exclf = wave_scan_f32<0>(basef, 0.f) - basef;
+  const float lo = wave_scan_f32<1>(exclf - abslf, __builtin_inff());
+  const float up = wave_scan_f32<2>(exclf + abslf, -__builtin_inff());
+  // the parity each lane starts from, if the block starts even; lanes before the first halfway case flip with the start
+  const unsigned long long T = __ballot(differ == 0), A = __ballot(par);
+  const unsigned long long lt = (1ull << lane) - 1ull, Tl = T & lt;
+  int q;
+  if (Tl == 0) q = __popcll(A & lt) & 1;
+  else {
+    const int h = 63 - __clzll(Tl);                                // the last lane before this one that met a halfway case
+    q = __popcll(A & lt & ~((1ull << h) - 1ull)) & 1;
+  }
+  const int qo = Tl == 0 ? q ^ 1 : q;
+  const int packed = ((q ? adj1 : adj0) + kChainLaneElems) | (((qo ? adj1 : adj0) + kChainLaneElems) << 16);
+  const int adjs = wave_scan_add_i32(packed);
+  const double tot = wave_scan_add_f64(base);
+  sm.total = readlane_f64(tot, 63);
+  sm.gmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
+  sm.gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(up), 63));
+  sm.adj = __builtin_amdgcn_readlane(adjs, 63);
+  sm.hi = __any(bad) ? 0 : (hi & (int)0xfff00000);
+  return sm;
+}
+// The running sum through summarised blocks.  S = |a| / u as long as blocks are accepted (ChainRun); leaving that form
+// gives the double back.
+struct ChainRun {
+  double S, unscale;
+  int hi;                    // sign and exponent word of the sum S stands for; 0: none (a is authoritative)
+};
+__device__ __forceinline__ void chain_run_enter(ChainRun &run, double a) {
+  run.hi = 0;
+  if (!chain_scalable(a)) return;
+  const int hi = __double2hiint(a);
+  const int e = ((hi >> 20) & 0x7ff) - 1023;
+  const double scale = __hiloint2double((hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);
+  run.unscale = __hiloint2double((hi & (int)0x80000000) | ((1023 - 52 + e) << 20), 0);
+  run.S = a * scale;                                               // exact, an integer in [2^52, 2^53)
+  run.hi = hi & (int)0xfff00000;
+}
+__device__ __forceinline__ bool chain_block_apply(ChainRun &run, const ChainSummary &sm) {
+#pragma clang fp contract(off)
+  if (sm.hi == 0 || run.hi != sm.hi) return false;
+  constexpr double kEdge = 0x1p34;
+  if (!(run.S + (double)sm.gmin >= 0x1p52 + kEdge) || !(run.S + (double)sm.gmax <= 0x1p53 - kEdge)) return false;
+  const int odd = __double2loint(run.S) & 1;                       // the parity of S: the last bit of the significand
+  const int adj = ((odd ? sm.adj >> 16 : sm.adj) & 0xffff) - kChainAdjBias;
+  run.S = run.S + (sm.total + (double)adj);
+  return true;
+}
+
+static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_sums(Ctl ctl, Vecs vs,
+                                                                                              const double *__restrict__ f,
+                                                                                              int rcp, int set, int with_f, int ub,
+                                                                                              int walk, const double *probe) {
+#pragma clang fp contract(off)      // products and additions stay separate roundings whatever the build's flags
+  extern __shared__ __attribute__((aligned(16))) double prod[];   // kChainLdsBytes
+  __shared__ ChainSummary summ[kChainGroupBlocks];
+  __shared__ double sh_a;
+  const int t = threadIdx.x, b = blockIdx.x, wave = t >> 6;
+  const int pending = ctl.ic[IC_PLAN_PENDING];
+  const int nolder = ctl.ic[IC_PLAN_NOLDER];
+  const int mvec = ctl.mvec;
+  const int64_t n = vs.n;
+  const long long *pw = ctl.plan_w();
+  double *red = ctl.red();
+  const double *w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f;
+  const double *wk = f;                               // the older w of this sum (kinds W1W, FW)
+  int kind, dst;
+  double s = 0.0;
+  if (set == kChainProbe) {
+    kind = kChainKindFW; dst = 2 + mvec; wk = probe;
+  } else if (set == kChainNorm) {
+    if (b == 0) {
+      if (!pending) return;
+      kind = kChainKindNorm; dst = 0;
+    } else {
+      const int p = b - 1;
+      if (!with_f || p >= nolder) return;
+      kind = kChainKindFW; dst = 2 + mvec + p; wk = vs.w + pw[p];
+    }
+  } else {
+    if (pending) s = sqrt(red[0]);                    // the GLOBAL sum d^2 (F08:267)
+    const bool normed = pending && s != 0.0;          // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
+    if (b == 0) {
+      if (!normed) return;
+      kind = kChainKindFW1; dst = 1;
+    } else if (b <= ub) {
+      const int k = b - 1;
+      if (!normed || k >= nolder) return;
+      kind = kChainKindW1W; dst = 2 + k; wk = vs.w + pw[k];
+    } else {
+      const int p = b - 1 - ub;
+      if (!with_f || p >= nolder) return;
+      kind = kChainKindFW; dst = 2 + mvec + p; wk = vs.w + pw[p];
+    }
+  }
+  const double rs = 1.0 / s;
+  const bool need_d = kind != kChainKindFW, need_w = kind == kChainKindW1W || kind == kChainKindFW;
+
+  double xf[kChainPerThread], xw1[kChainPerThread], xw[kChainPerThread];
+  auto load = [&](int64_t g0) {
+#pragma unroll
+    for (int j = 0; j < kChainPerThread; j++) {
+      const int64_t i = g0 + j * kChainThreads + t;
+      const bool in = i < n;
+      xf[j] = in ? f[i] : 0.0;
+      xw1[j] = (in && need_d) ? w1[i] : 0.0;
+      xw[j] = (in && need_w) ? wk[i] : 0.0;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int j = 0; j < kChainPerThread; j++) {
+      double p;
+      if (kind == kChainKindFW) p = xf[j] * xw[j];
+      else {
+        const double d = xw1[j] - xf[j];               // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+        if (kind == kChainKindNorm) p = d * d;
+        else {
+          const double wn = rcp ? rs * d : d / s;      // the value PB stores as w1' (F08:283; F08V:256)
+          p = (kind == kChainKindFW1) ? xf[j] * wn : wn * xw[j];
+        }
+      }
+      prod[chain_idx(j * kChainThreads + t)] = p;
+    }
+  };
+
+  double a = red[dst];                                 // 0, or the running sum of the ranks before this one
+  if (t == 0) sh_a = a;
+  if (n > 0) { load(0); store(); }
+  __syncthreads();
+#ifdef NKA_CHAIN_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = wall_clock64(), tn;
+#define NKA_CHAIN_STAMP(i) tn = wall_clock64(); st[i] += tn - tk; tk = tn;
+#else
+#define NKA_CHAIN_STAMP(i)
+#endif
+  for (int64_t g0 = 0; g0 < n; g0 += kChainGroup) {
+    const bool more = g0 + kChainGroup < n;
+    if (more) load(g0 + kChainGroup);                  // in flight while this group goes through the chain
+    NKA_CHAIN_STAMP(0)
+    const int glen = (int)(n - g0 < kChainGroup ? n - g0 : kChainGroup);
+    // every wavefront summarises its block under the sign and exponent the group starts with ...
+    const double a0 = sh_a;
+    const double *blk = prod + wave * kChainBlockLds;
+    const bool full = (wave + 1) * kChainBlock <= glen;
+    if (full && !walk) {
+      const ChainSummary sm = chain_block_summary(a0, blk);
+      if ((t & 63) == 0) summ[wave] = sm;
+    }
+    NKA_CHAIN_STAMP(1)
+    __syncthreads();
+    NKA_CHAIN_STAMP(2)
+    // ... and wavefront 0 takes the running sum through them
+    if (wave == 0) {
+      a = a0;
+      ChainRun run;
+      chain_run_enter(run, a);
+      for (int k = 0; k * kChainBlock < glen; k++) {
+        const double *bk = prod + k * kChainBlockLds;
+        const int len = glen - k * kChainBlock < kChainBlock ? glen - k * kChainBlock : kChainBlock;
+        bool done = false;
+        if (len == kChainBlock && !walk) {
+          ChainSummary sm = summ[k];
+          done = chain_block_apply(run, sm);
+          if (!done && run.hi != 0 && run.hi != sm.hi) {           // another binade by now: summarise under the present one
+            sm = chain_block_summary(run.S * run.unscale, bk);
+            done = chain_block_apply(run, sm);
+          }
+        }
+        if (!done) {
+          if (run.hi != 0) a = run.S * run.unscale;
+          a = chain_block_serial(a, bk, len);
+          chain_run_enter(run, a);
+        }
+      }
+      if (run.hi != 0) a = run.S * run.unscale;
+      if (t == 0) sh_a = a;
+    }
+    NKA_CHAIN_STAMP(3)
+    __syncthreads();
+    NKA_CHAIN_STAMP(4)
+    if (more) store();
+    NKA_CHAIN_STAMP(5)
+    __syncthreads();
+    NKA_CHAIN_STAMP(6)
+  }
+  if (t == 0) red[dst] = a;
+#ifdef NKA_CHAIN_STAMPS
+  if (t == 0 && set == kChainProbe)
+    for (int i = 0; i < 8; i++) ctl.stamps()[i] = (double)st[i];   // 10 ns ticks: load issue, summary, wait, apply, wait, store, wait
+#endif
+#undef NKA_CHAIN_STAMP
+}
+
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------
 // COMB 0: x/s          ; (f - c*w) + c*v       F08:282-283, 397
 // COMB 1: (1/s)*x      ; ((-c)*w + c*v) + f    F08V:255-256 scale(1/s), :374 update3_
