@@ -1348,13 +1348,14 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     if (a->pending || older_ub > 0) {
       const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
       if (chain_per_sum(a, rows)) {
-        // long vectors: one workgroup per sum; the norm and the sums on f alone first, then those on the rounded w1'
+        // long vectors: one workgroup per sum; the norm alone first (one chain: every other sum of the update would wait
+        // for it on idle compute units if it shared a launch with sums twice as long), then everything else side by side
         HIP_TRY(hipMemsetAsync(a->ctl.red(), 0, sizeof(double) * (size_t)a->ctl.red_count(), s));
-        hipLaunchKernelGGL(k_chain_sums, dim3(1 + older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                           (int)kChainNorm, 1, older_ub, a->chain_walk, (const double *)nullptr);
         if (a->pending)
-          hipLaunchKernelGGL(k_chain_sums, dim3(1 + older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                             (int)kChainRows, 0, older_ub, a->chain_walk, (const double *)nullptr);
+          hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                             (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
+        hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                           (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
       } else {
         hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
                            ord_chunk(rows), (int)kOrdAll, 0);

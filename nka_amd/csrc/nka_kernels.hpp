@@ -944,20 +944,23 @@ __device__ __forceinline__ void chain_lane_read(double (&p)[kChainLaneElems], co
 // same additions on the same LDS words: no divergence, the sum stays wave-uniform).  One lane's worth (16 products) per
 // step, read while the additions of the step before wait for one another, two steps per trip (no register copies): the
 // loop is the chain of dependent v_add_f64 and little else (2.3 ns each, tools/micro/dep_add.hip).
-__device__ __forceinline__ double chain_block_serial(double a, const double *blk, int len) {
+__device__ __forceinline__ double chain_block_serial(double a, const double *blk, int len, int g = 0) {   // (from lane g on)
 #pragma clang fp contract(off)
   const int ng = len / kChainLaneElems;                 // whole lanes
-  int g = 0;
-  if (ng >= 1) {
+  if (g < ng) {
     double A[kChainLaneElems], B[kChainLaneElems];
-    chain_lane_read(A, blk, 0);
+    chain_lane_read(A, blk, g);
     for (; g + 2 <= ng; g += 2) {
       chain_lane_read(B, blk, g + 1);
+      __builtin_amdgcn_sched_barrier(0);                 // (the reads of the NEXT lane go out before this lane's additions)
 #pragma unroll
       for (int j = 0; j < kChainLaneElems; j++) a = a + A[j];
+      __builtin_amdgcn_sched_barrier(0);
       chain_lane_read(A, blk, g + 3 <= ng ? g + 2 : g);   // (the last trip re-reads: the loads stay unconditional)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < kChainLaneElems; j++) a = a + B[j];
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (g < ng) {                                        // (A holds lane g whenever a whole lane remains)
 #pragma unroll
@@ -1017,13 +1020,72 @@ __device__ __forceinline__ double wave_scan_add_f64(double x) {
 // through its sign and exponent (chain_block_summary), so the wavefronts of the workgroup take one block each under the
 // exponent the group starts with; wavefront 0 then walks the summaries (chain_block_apply): a block is accepted iff it
 // was summarised under the sum's present sign and exponent, every prefix provably stays inside the binade and every
-// |t| < 2^48 (r exact, lane sums exact; NaN and Inf fail the comparison).  The prefix bounds are kept in SINGLE precision,
+// lane's sum of |r| < 2^51 (r exact, lane sums exact; NaN and Inf fail the comparison).  The prefix bounds are kept in SINGLE precision,
 // rounded to nearest: they are off by < 2^31 units, and the acceptance window leaves 2^34 units (2^-18 of the binade)
 // at either end -- which also covers the corrections (<= 1024) and the one inexact case (sums beyond 2^53 are only ever
 // formed in blocks that leave the window by far more than their error).  Otherwise the block is summarised again under
 // the present exponent or, failing that, walked (chain_block_serial).  Same bits as the walk by construction;
 // tests/test_chain_sums_gpu.py holds the two to each other and to numpy's sequential accumulate on adversarial inputs
 // (halfway cases under both parities, binade crossings, cancellation, zeros, subnormals, overflow, NaN).
+// what one lane makes of its 16 consecutive products under the scale of the sum's binade
+struct ChainLane {
+  double base, absl;         // sum of the r's; sum of their magnitudes (bounds every prefix inside the lane)
+  int par, differ;           // parity of the lane's sum if it starts even; whether starting odd still flips it (no halfway case met)
+  int adj0, adj1;            // corrections the halfway cases owe if the lane starts even / odd
+};
+__device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLaneElems], double scale, bool active) {
+#pragma clang fp contract(off)
+  constexpr double M = 6755399441055744.0;                         // 1.5 * 2^52
+  ChainLane ln;
+  ln.base = ln.absl = 0.0;
+  ln.differ = 1; ln.adj0 = ln.adj1 = 0;
+  int parw = 0;
+  bool halfway = false;
+#pragma unroll
+  for (int j = 0; j < kChainLaneElems; j++) {
+    const double t = (active ? pl[j] : 0.0) * scale;               // exact (a power of two), |t| tiny if it underflows
+    const double tm = t + M;                                       // rounds t to an integer, halves to even
+    const double r = tm - M;
+    const double diff = t - r;                                     // exact
+    halfway |= fabs(diff) == 0.5;
+    parw ^= __double2loint(tm);
+    ln.base = ln.base + r;
+    ln.absl = ln.absl + fabs(r);
+  }
+  if (__any(halfway)) {                                            // the parity bookkeeping in its own pass
+    parw = 0;
+#pragma unroll
+    for (int j = 0; j < kChainLaneElems; j++) {
+      const double t = (active ? pl[j] : 0.0) * scale;
+      const double tm = t + M;
+      const double diff = t - (tm - M);
+      if (fabs(diff) == 0.5) {                                     // halfway: r is the EVEN neighbour of t, r + 2 diff the odd one
+        const int tau = diff > 0.0 ? 1 : -1;
+        // r being even, S + r has the parity of S: an odd S takes the other neighbour, and the sum is even either way
+        if (parw & 1) ln.adj0 += tau;
+        if ((parw ^ ln.differ) & 1) ln.adj1 += tau;
+        parw = 0; ln.differ = 0;
+      } else {
+        parw ^= __double2loint(tm);
+      }
+    }
+  }
+  ln.par = parw & 1;
+  return ln;
+}
+// the parity each lane starts from if the block starts EVEN (q), and whether a block starting odd flips it (no halfway
+// case in any lane before this one)
+__device__ __forceinline__ void chain_lane_parity(const ChainLane &ln, int lane, int &q, bool &flips) {
+  const unsigned long long T = __ballot(ln.differ == 0), A = __ballot(ln.par);
+  const unsigned long long lt = (1ull << lane) - 1ull, Tl = T & lt;
+  flips = Tl == 0;
+  if (flips) q = __popcll(A & lt) & 1;
+  else {
+    const int h = 63 - __clzll(Tl);                                // the last lane before this one that met a halfway case
+    q = __popcll(A & lt & ~((1ull << h) - 1ull)) & 1;
+  }
+}
+
 struct ChainSummary {
   double total;              // sum of the r's
   float gmin, gmax;          // least / greatest prefix bound
@@ -1031,6 +1093,7 @@ struct ChainSummary {
   int hi;                    // sign and exponent word the summary assumed; 0: none, or a product out of range
 };
 constexpr int kChainAdjBias = 64 * kChainLaneElems;
+constexpr int kChainRoundWorth = 14;                              // lanes a round of chain_block_by_lanes must gain to be worth another
 __device__ __forceinline__ bool chain_scalable(double a) {
   const int ef = (__double2hiint(a) >> 20) & 0x7ff;
   return ef >= 1023 - 900 && ef <= 1023 + 900;                    // not zero, subnormal, Inf, NaN; scale factors in range
@@ -1044,50 +1107,22 @@ __device__ __forceinline__ ChainSummary chain_block_summary(double a, const doub
   const int hi = __double2hiint(a);
   const int e = ((hi >> 20) & 0x7ff) - 1023;
   const double scale = __hiloint2double((hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);    // +-2^(52-e): S > 0
-  constexpr double M = 6755399441055744.0;                         // 1.5 * 2^52
-  double base = 0.0, absl = 0.0;
-  int parw = 0, differ = 1, adj0 = 0, adj1 = 0;                    // (bit 0 of parw: parity under incoming parity 0; whether
-                                                                   //  parity 1 still differs)
   double pl[kChainLaneElems];
   chain_lane_read(pl, blk, lane);
-#pragma unroll
-  for (int j = 0; j < kChainLaneElems; j++) {
-    const double t = pl[j] * scale;                                // exact (a power of two), |t| tiny if it underflows
-    const double tm = t + M;                                       // rounds t to an integer, halves to even
-    const double r = tm - M;
-    const double diff = t - r;                                     // exact
-    if (fabs(diff) == 0.5) {                                       // halfway: r is the EVEN neighbour of t, r + 2 diff the odd one
-      const int tau = diff > 0.0 ? 1 : -1;
-      // r being even, S + r has the parity of S: an odd S takes the other neighbour, and the sum is even either way
-      if (parw & 1) adj0 += tau;
-      if ((parw ^ differ) & 1) adj1 += tau;
-      parw = 0; differ = 0;
-    } else {
-      parw ^= __double2loint(tm);
-    }
-    base = base + r;
-    absl = absl + fabs(r);
-  }
-  const int par = parw & 1;
-  const bool bad = !(absl < 0x1p48);                               // some |t| >= 2^48 / Inf / NaN (|t| <= |r| + 1/2 <= absl + 1/2)
+  const ChainLane ln = chain_lane_pass(pl, scale, true);
+  const bool bad = !(ln.absl < 0x1p51);                            // some |t| >= 2^51 / Inf / NaN: r = rne(t) and the lane's sums are exact below that
   // where the lane's excursion lies: the prefix before it +- its own absolute sum, in single precision
-  const float basef = (float)base, abslf = (float)absl;
+  const float basef = (float)ln.base, abslf = (float)ln.absl;
   const float exclf = wave_scan_f32<0>(basef, 0.f) - basef;
   const float lo = wave_scan_f32<1>(exclf - abslf, __builtin_inff());
   const float up = wave_scan_f32<2>(exclf + abslf, -__builtin_inff());
-  // the parity each lane starts from, if the block starts even; lanes before the first halfway case flip with the start
-  const unsigned long long T = __ballot(differ == 0), A = __ballot(par);
-  const unsigned long long lt = (1ull << lane) - 1ull, Tl = T & lt;
   int q;
-  if (Tl == 0) q = __popcll(A & lt) & 1;
-  else {
-    const int h = 63 - __clzll(Tl);                                // the last lane before this one that met a halfway case
-    q = __popcll(A & lt & ~((1ull << h) - 1ull)) & 1;
-  }
-  const int qo = Tl == 0 ? q ^ 1 : q;
-  const int packed = ((q ? adj1 : adj0) + kChainLaneElems) | (((qo ? adj1 : adj0) + kChainLaneElems) << 16);
+  bool flips;
+  chain_lane_parity(ln, lane, q, flips);
+  const int qo = flips ? q ^ 1 : q;
+  const int packed = ((q ? ln.adj1 : ln.adj0) + kChainLaneElems) | (((qo ? ln.adj1 : ln.adj0) + kChainLaneElems) << 16);
   const int adjs = wave_scan_add_i32(packed);
-  const double tot = wave_scan_add_f64(base);
+  const double tot = wave_scan_add_f64(ln.base);
   sm.total = readlane_f64(tot, 63);
   sm.gmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
   sm.gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(up), 63));
@@ -1120,6 +1155,180 @@ __device__ __forceinline__ bool chain_block_apply(ChainRun &run, const ChainSumm
   const int adj = ((odd ? sm.adj >> 16 : sm.adj) & 0xffff) - kChainAdjBias;
   run.S = run.S + (sm.total + (double)adj);
   return true;
+}
+
+// A block that does not go in whole (the sum meets an end of its binade inside it): lane by lane.  Under the sum's
+// present exponent and parity the lanes before the first one whose excursion may leave the binade are accepted as they
+// stand (their prefix sums, corrections included, are exact), that lane's 16 products are walked, and the rest is taken
+// again under the exponent the walk ends in -- as long as rounds pay (a round costs what walking ~14 lanes costs), then
+// the rest is walked.  One wavefront, the running sum known: nothing here is speculative.
+__device__ __forceinline__ double chain_block_by_lanes(double a, const double *blk, unsigned long long *cnt = nullptr) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  constexpr double kEdge = 0x1p34;
+  double pl[kChainLaneElems];
+  chain_lane_read(pl, blk, lane);
+  int first = 0, poor = 0;
+  for (int round = 0; round < 4 && 64 - first >= kChainRoundWorth && poor < 2; round++) {
+    ChainRun run;
+    chain_run_enter(run, a);
+    if (run.hi == 0) break;
+    const int e = ((run.hi >> 20) & 0x7ff) - 1023;
+    const double scale = __hiloint2double((run.hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);
+    const ChainLane ln = chain_lane_pass(pl, scale, lane >= first);
+    int q;
+    bool flips;
+    chain_lane_parity(ln, lane, q, flips);
+    if (flips) q ^= __double2loint(run.S) & 1;                     // the parity the block really starts from
+    const int adj = q ? ln.adj1 : ln.adj0;
+    const int adji = wave_scan_add_i32(adj);
+    const double incl = wave_scan_add_f64(ln.base);
+    const double excl = incl - ln.base;
+    const bool viol = !(ln.absl < 0x1p51) || !(run.S + (excl - ln.absl) >= 0x1p52 + kEdge) ||
+                      !(run.S + (excl + ln.absl) <= 0x1p53 - kEdge);
+    const unsigned long long m = __ballot(viol) & ~((1ull << first) - 1ull);   // (first < 64)
+    const int L = m ? __ffsll((long long)m) - 1 : 64;
+    if (L > first) {                                               // lanes first .. L-1: the inclusive sums AT lane L-1 (what
+      const double sum = readlane_f64(incl, L - 1);                //  lane L holds may be beyond 2^53 and inexact: its own
+      const int corr = __builtin_amdgcn_readlane(adji, L - 1);     //  `excl` is not to be trusted)
+      a = (run.S + (sum + (double)corr)) * run.unscale;
+    }
+    const int gained = L - first;
+    first = L;
+    if (L == 64) break;
+    poor = gained < kChainRoundWorth ? poor + 1 : 0;               // a round costs what walking ~14 lanes costs: two poor rounds
+                                                                   // in a row = the sum hovers at an end of its binade (or is small)
+    a = chain_block_serial(a, blk, (L + 1) * kChainLaneElems, L);  // lane L, element after element
+    first = L + 1;
+    if (cnt) { cnt[4] += 1; }                                      // (lanes walked one at a time)
+  }
+  if (cnt) { cnt[5] += 64 - first; }                               // (lanes walked as the rest of a block)
+  if (first < 64) a = chain_block_serial(a, blk, kChainBlock, first);
+  return a;
+}
+
+// The loop of one sum: `load(g0)` brings the operands of the group that starts at element g0 into the caller's registers
+// (wavefront w: block w of the group), `store()` rounds their products into the wavefront's block of `prod`.  Returns the
+// sum (valid in thread 0).  The whole workgroup calls it.
+struct ChainStamps {
+#ifdef NKA_CHAIN_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // 10 ns ticks of wavefront 0: load issue, summary, wait, apply, wait, store
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks: in a run / on their own / summarised again / lane by lane; lanes walked singly / as a rest
+#endif
+};
+template <class Load, class Store>
+__device__ __forceinline__ double chain_drive(double a, int64_t n, double *prod, ChainSummary *summ, double *sh_a_p, int walk,
+                                              ChainStamps &stamps, Load load, Store store) {
+#pragma clang fp contract(off)
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  double *myblk = prod + wave * kChainBlockLds;
+  if (t == 0) *sh_a_p = a;
+  if (n > 0) { load(0); store(); }
+  __syncthreads();
+#ifdef NKA_CHAIN_STAMPS
+  unsigned long long tk = wall_clock64(), tn;
+#define NKA_CHAIN_STAMP(i) tn = wall_clock64(); stamps.st[i] += tn - tk; tk = tn;
+#define NKA_CHAIN_COUNT(i, v) stamps.cnt[i] += (v);
+#define NKA_CHAIN_CNT stamps.cnt
+#else
+#define NKA_CHAIN_STAMP(i)
+#define NKA_CHAIN_COUNT(i, v)
+#define NKA_CHAIN_CNT nullptr
+#endif
+  for (int64_t g0 = 0; g0 < n; g0 += kChainGroup) {
+    const bool more = g0 + kChainGroup < n;
+    if (more) load(g0 + kChainGroup);                  // in flight while this group goes through the chain
+    NKA_CHAIN_STAMP(0)
+    const int glen = (int)(n - g0 < kChainGroup ? n - g0 : kChainGroup);
+    const int nfull = glen / kChainBlock, nblk = (glen + kChainBlock - 1) / kChainBlock;
+    // every wavefront summarises its block under the sign and exponent the group starts with ...
+    const double a0 = *sh_a_p;
+    if (wave < nfull && !walk) {
+      const ChainSummary sm = chain_block_summary(a0, myblk);
+      if (lane == 0) summ[wave] = sm;
+    }
+    NKA_CHAIN_STAMP(1)
+    __syncthreads();
+    NKA_CHAIN_STAMP(2)
+    // ... and wavefront 0 takes the running sum through them: lane k holds the summary of block k
+    if (wave == 0) {
+      a = a0;
+      ChainRun run;
+      chain_run_enter(run, a);
+      ChainSummary mine = summ[lane < kChainGroupBlocks ? lane : 0];
+      int k = 0;
+      while (k < nblk) {
+        if (run.hi != 0 && !walk && k < nfull) {
+          // every block from k on that applies whatever the parity of the sum: their totals as one prefix sum, each
+          // checked against the sum it would start from; the longest run of acceptable blocks goes in at once
+          const bool cand = lane >= k && lane < nfull;
+          const int ae = (mine.adj & 0xffff) - kChainAdjBias, ao = ((mine.adj >> 16) & 0xffff) - kChainAdjBias;
+          const bool usable = cand && mine.hi == run.hi;
+          // the parity each block starts from, if every block before it goes in: block i flips it by the parity of its
+          // total plus the correction it takes under the parity it meets (a short scalar chain over two bit masks)
+          const int tpar = __double2loint(fabs(mine.total) + 0x1p52) & 1;     // (|total| < 2^52 in any block that goes in)
+          const unsigned pe = (unsigned)__ballot(usable && ((tpar ^ ae) & 1)), po = (unsigned)__ballot(usable && ((tpar ^ ao) & 1));
+          unsigned odd = 0;
+          {
+            unsigned p = (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1u;   // (scalar: the chain runs on the SALU)
+            for (int i = k; i < nfull; i++) {
+              odd |= p << i;
+              p ^= ((p ? po : pe) >> i) & 1u;
+            }
+          }
+          const double tk_ = usable ? mine.total + (double)(((odd >> lane) & 1u) ? ao : ae) : 0.0;
+          double incl = tk_;
+          incl = incl + dpp_f64<0x111, 0xf>(incl, 0.0);
+          incl = incl + dpp_f64<0x112, 0xf>(incl, 0.0);
+          incl = incl + dpp_f64<0x114, 0xf>(incl, 0.0);
+          const double Sk = run.S + (incl - tk_);
+          constexpr double kEdge = 0x1p34;
+          const bool ok = usable && (Sk + (double)mine.gmin >= 0x1p52 + kEdge) && (Sk + (double)mine.gmax <= 0x1p53 - kEdge);
+          const unsigned long long need = ((1ull << nfull) - 1ull) & ~((1ull << k) - 1ull);
+          const unsigned long long failm = need & ~__ballot(ok);
+          const int F = failm ? __ffsll((long long)failm) - 1 : nfull;
+          if (F > k) {
+            run.S = run.S + readlane_f64(incl, F - 1);
+            NKA_CHAIN_COUNT(0, F - k)
+            k = F;
+            continue;
+          }
+        }
+        // block k on its own: under the parity of the sum, or summarised again under its present exponent, or walked
+        const double *bk = prod + k * kChainBlockLds;
+        const int len = glen - k * kChainBlock < kChainBlock ? glen - k * kChainBlock : kChainBlock;
+        bool done = false;
+        if (len == kChainBlock && !walk) {
+          ChainSummary sm = summ[k];
+          done = chain_block_apply(run, sm);
+          if (done) { NKA_CHAIN_COUNT(1, 1) }
+          if (!done && run.hi != 0 && run.hi != sm.hi) {           // another binade by now: summarise under the present one
+            sm = chain_block_summary(run.S * run.unscale, bk);
+            done = chain_block_apply(run, sm);
+            if (done) { NKA_CHAIN_COUNT(2, 1) }
+          }
+        }
+        if (!done) {
+          if (run.hi != 0) a = run.S * run.unscale;
+          if (len == kChainBlock && !walk) { NKA_CHAIN_COUNT(3, 1) }
+          a = (len == kChainBlock && !walk) ? chain_block_by_lanes(a, bk, NKA_CHAIN_CNT) : chain_block_serial(a, bk, len);
+          chain_run_enter(run, a);
+        }
+        k++;
+      }
+      if (run.hi != 0) a = run.S * run.unscale;
+      if (t == 0) *sh_a_p = a;
+    }
+    NKA_CHAIN_STAMP(3)
+    __syncthreads();
+    NKA_CHAIN_STAMP(4)
+    if (more) store();                                 // (each wavefront into its own block, which it alone summarises)
+    NKA_CHAIN_STAMP(5)
+  }
+  return a;
+#undef NKA_CHAIN_STAMP
+#undef NKA_CHAIN_COUNT
+#undef NKA_CHAIN_CNT
 }
 
 static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_sums(Ctl ctl, Vecs vs,
@@ -1169,102 +1378,66 @@ static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void 
     }
   }
   const double rs = 1.0 / s;
-  const bool need_d = kind != kChainKindFW, need_w = kind == kChainKindW1W || kind == kChainKindFW;
+  using V2 = typename VecT<2>::type;
+  const int lane = t & 63;
+  const bool vec16 = ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(wk)) & 15) == 0;
 
-  double xf[kChainPerThread], xw1[kChainPerThread], xw[kChainPerThread];
+  // Wavefront w loads, multiplies and summarises block w of a group (elements [1024 w, 1024 w + 1024)): pair j*64 + lane
+  // of the block per load, i.e. 1 KiB per wave instruction; the pair lands in LDS where the lane that owns it reads it.
+  constexpr int kPairs = kChainLaneElems / 2;          // 16-byte loads per thread and vector
+  V2 xf[kPairs], xw1[kPairs], xw[kPairs];
+  auto ldpair = [&](const double *p, int64_t i, bool full) -> V2 {
+    V2 v;
+    if (full && vec16) v = *reinterpret_cast<const V2 *>(p + i);
+    else if (full) { v.x = p[i]; v.y = p[i + 1]; }
+    else { v.x = i < n ? p[i] : 0.0; v.y = i + 1 < n ? p[i + 1] : 0.0; }
+    return v;
+  };
   auto load = [&](int64_t g0) {
+    const bool full = g0 + kChainGroup <= n;
+    const int64_t i0 = g0 + wave * kChainBlock + 2 * lane;
+    if (kind == kChainKindFW) {
 #pragma unroll
-    for (int j = 0; j < kChainPerThread; j++) {
-      const int64_t i = g0 + j * kChainThreads + t;
-      const bool in = i < n;
-      xf[j] = in ? f[i] : 0.0;
-      xw1[j] = (in && need_d) ? w1[i] : 0.0;
-      xw[j] = (in && need_w) ? wk[i] : 0.0;
+      for (int j = 0; j < kPairs; j++) { xf[j] = ldpair(f, i0 + j * 128, full); xw[j] = ldpair(wk, i0 + j * 128, full); }
+    } else if (kind == kChainKindW1W) {
+#pragma unroll
+      for (int j = 0; j < kPairs; j++) {
+        xf[j] = ldpair(f, i0 + j * 128, full); xw1[j] = ldpair(w1, i0 + j * 128, full); xw[j] = ldpair(wk, i0 + j * 128, full);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kPairs; j++) { xf[j] = ldpair(f, i0 + j * 128, full); xw1[j] = ldpair(w1, i0 + j * 128, full); }
     }
   };
+  double *myblk = prod + wave * kChainBlockLds;
   auto store = [&]() {
 #pragma unroll
-    for (int j = 0; j < kChainPerThread; j++) {
-      double p;
-      if (kind == kChainKindFW) p = xf[j] * xw[j];
+    for (int j = 0; j < kPairs; j++) {
+      V2 p;
+      if (kind == kChainKindFW) { p.x = xf[j].x * xw[j].x; p.y = xf[j].y * xw[j].y; }
       else {
-        const double d = xw1[j] - xf[j];               // F08:266 ((-1)*f + w1 in F08V:237: same bits)
-        if (kind == kChainKindNorm) p = d * d;
+        const double d0 = xw1[j].x - xf[j].x, d1 = xw1[j].y - xf[j].y;   // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+        if (kind == kChainKindNorm) { p.x = d0 * d0; p.y = d1 * d1; }
         else {
-          const double wn = rcp ? rs * d : d / s;      // the value PB stores as w1' (F08:283; F08V:256)
-          p = (kind == kChainKindFW1) ? xf[j] * wn : wn * xw[j];
+          const double n0 = rcp ? rs * d0 : d0 / s, n1 = rcp ? rs * d1 : d1 / s;   // the value PB stores as w1' (F08:283; F08V:256)
+          if (kind == kChainKindFW1) { p.x = xf[j].x * n0; p.y = xf[j].y * n1; }
+          else { p.x = n0 * xw[j].x; p.y = n1 * xw[j].y; }
         }
       }
-      prod[chain_idx(j * kChainThreads + t)] = p;
+      // pair j*64 + lane of the block = elements 2 (j*64 + lane), +1: lane (j*64 + lane) / 8 of the chain, pair row lane % 8
+      *reinterpret_cast<V2 *>(myblk + (lane % kPairs) * kChainRow + 2 * (j * (64 / kPairs) + lane / kPairs)) = p;
     }
   };
+  static_assert(kPairs == 8, "the pair mapping of load / store assumes 16 elements per lane");
 
-  double a = red[dst];                                 // 0, or the running sum of the ranks before this one
-  if (t == 0) sh_a = a;
-  if (n > 0) { load(0); store(); }
-  __syncthreads();
-#ifdef NKA_CHAIN_STAMPS
-  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = wall_clock64(), tn;
-#define NKA_CHAIN_STAMP(i) tn = wall_clock64(); st[i] += tn - tk; tk = tn;
-#else
-#define NKA_CHAIN_STAMP(i)
-#endif
-  for (int64_t g0 = 0; g0 < n; g0 += kChainGroup) {
-    const bool more = g0 + kChainGroup < n;
-    if (more) load(g0 + kChainGroup);                  // in flight while this group goes through the chain
-    NKA_CHAIN_STAMP(0)
-    const int glen = (int)(n - g0 < kChainGroup ? n - g0 : kChainGroup);
-    // every wavefront summarises its block under the sign and exponent the group starts with ...
-    const double a0 = sh_a;
-    const double *blk = prod + wave * kChainBlockLds;
-    const bool full = (wave + 1) * kChainBlock <= glen;
-    if (full && !walk) {
-      const ChainSummary sm = chain_block_summary(a0, blk);
-      if ((t & 63) == 0) summ[wave] = sm;
-    }
-    NKA_CHAIN_STAMP(1)
-    __syncthreads();
-    NKA_CHAIN_STAMP(2)
-    // ... and wavefront 0 takes the running sum through them
-    if (wave == 0) {
-      a = a0;
-      ChainRun run;
-      chain_run_enter(run, a);
-      for (int k = 0; k * kChainBlock < glen; k++) {
-        const double *bk = prod + k * kChainBlockLds;
-        const int len = glen - k * kChainBlock < kChainBlock ? glen - k * kChainBlock : kChainBlock;
-        bool done = false;
-        if (len == kChainBlock && !walk) {
-          ChainSummary sm = summ[k];
-          done = chain_block_apply(run, sm);
-          if (!done && run.hi != 0 && run.hi != sm.hi) {           // another binade by now: summarise under the present one
-            sm = chain_block_summary(run.S * run.unscale, bk);
-            done = chain_block_apply(run, sm);
-          }
-        }
-        if (!done) {
-          if (run.hi != 0) a = run.S * run.unscale;
-          a = chain_block_serial(a, bk, len);
-          chain_run_enter(run, a);
-        }
-      }
-      if (run.hi != 0) a = run.S * run.unscale;
-      if (t == 0) sh_a = a;
-    }
-    NKA_CHAIN_STAMP(3)
-    __syncthreads();
-    NKA_CHAIN_STAMP(4)
-    if (more) store();
-    NKA_CHAIN_STAMP(5)
-    __syncthreads();
-    NKA_CHAIN_STAMP(6)
-  }
+  ChainStamps stamps;
+  const double a = chain_drive(red[dst], n, prod, summ, &sh_a, walk, stamps, load, store);
   if (t == 0) red[dst] = a;
 #ifdef NKA_CHAIN_STAMPS
   if (t == 0 && set == kChainProbe)
-    for (int i = 0; i < 8; i++) ctl.stamps()[i] = (double)st[i];   // 10 ns ticks: load issue, summary, wait, apply, wait, store, wait
+    for (int i = 0; i < 8; i++) { ctl.stamps()[i] = (double)stamps.st[i]; ctl.stamps()[8 + i] = (double)stamps.cnt[i]; }
+  // (10 ns ticks: load issue, summary, wait, apply, wait, store; then the block counts)
 #endif
-#undef NKA_CHAIN_STAMP
 }
 
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------

@@ -150,6 +150,62 @@ static __global__ __launch_bounds__(kBlock) void k_dot_ordered(int64_t n, const 
   if (threadIdx.x == 0) partials[0] = acc;
 }
 
+// The same sum for LONG vectors (round 5): the per-sum machinery of the array flavour's reference-order pass (nka_kernels.hpp,
+// chain_drive) -- the products of a group are rounded into LDS by eight wavefronts, whole blocks of 1024 go through the chain
+// in exact integer arithmetic wherever that is provably the walk's result, the walk elsewhere.  Same bits as k_dot_ordered
+// (tests/test_chain_sums_gpu.py holds the machinery to numpy's sequential sum), 10-20 x its speed from n ~ 1e5 on.
+static __global__ __launch_bounds__(kChainThreads) void k_dot_chain(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                                    double *__restrict__ partials) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double chain_prod[];   // kChainLdsBytes
+  __shared__ ChainSummary summ[kChainGroupBlocks];
+  __shared__ double sh_a;
+  using V2 = typename VecT<2>::type;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const bool vec16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  constexpr int kPairs = kChainLaneElems / 2;
+  static_assert(kPairs == 8, "the pair mapping below assumes 16 elements per lane");
+  V2 vx[kPairs], vy[kPairs];
+  auto ldpair = [&](const double *p, int64_t i, bool full) -> V2 {
+    V2 v;
+    if (full && vec16) v = *reinterpret_cast<const V2 *>(p + i);
+    else if (full) { v.x = p[i]; v.y = p[i + 1]; }
+    else { v.x = i < n ? p[i] : 0.0; v.y = i + 1 < n ? p[i + 1] : 0.0; }
+    return v;
+  };
+  auto load = [&](int64_t g0) {
+    const bool full = g0 + kChainGroup <= n;
+    const int64_t i0 = g0 + wave * kChainBlock + 2 * lane;
+#pragma unroll
+    for (int j = 0; j < kPairs; j++) { vx[j] = ldpair(x, i0 + j * 128, full); vy[j] = ldpair(y, i0 + j * 128, full); }
+  };
+  double *myblk = chain_prod + wave * kChainBlockLds;
+  auto store = [&]() {
+#pragma unroll
+    for (int j = 0; j < kPairs; j++) {
+      V2 p;
+      p.x = vx[j].x * vy[j].x;
+      p.y = vx[j].y * vy[j].y;
+      *reinterpret_cast<V2 *>(myblk + (lane % kPairs) * kChainRow + 2 * (j * (64 / kPairs) + lane / kPairs)) = p;
+    }
+  };
+  ChainStamps stamps;
+  const double a = chain_drive(0.0, n, chain_prod, summ, &sh_a, 0, stamps, load, store);
+  if (t == 0) partials[0] = a;
+}
+static int launch_dot_ordered(hipStream_t s, int64_t n, const double *x, const double *y, double *partials) {
+  if (n <= 4 * kDotOrdChunk) {
+    hipLaunchKernelGGL(k_dot_ordered, dim3(1), dim3(kBlock), 0, s, n, x, y, partials);
+    return 0;
+  }
+  static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dot_chain),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);
+  if (raised != hipSuccess)
+    return nka_detail::set_error(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+  hipLaunchKernelGGL(k_dot_chain, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, n, x, y, partials);
+  return 0;
+}
+
 // ---- batched hooks: one pass for many dots / many axpys -----------
 constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24; window kernels: every width 1..24); longer lists run several launches
 // ... of BALANCED widths (round 5; 25 = 13 + 12, not 24 + 1: a launch that is nearly all padding costs as much as a full one --
@@ -1065,7 +1121,7 @@ static int nka_hip_vec_dot_entry(nka_hip_vec_ws_t ws, int64_t n, const double *x
     const bool v2 = al16(x) && al16(y);
     g = ws->sum_order == 1 ? 1 : grid_for(ws, n, v2 ? 2 : 1);
     if (ws->sum_order == 1)
-      hipLaunchKernelGGL(k_dot_ordered, dim3(1), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
+      { if (int rc = launch_dot_ordered(ws->stream, n, x, y, ws->partials)) return rc; }
     else if (v2)
       hipLaunchKernelGGL((k_dot<2>), dim3(g), dim3(kBlock), 0, ws->stream, n, x, y, ws->partials);
     else

@@ -127,6 +127,21 @@ def test_magnitudes_over_the_whole_range(bench):
     check(bench, rare, np.ones(n), 0.0, "rare giants")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_giants_that_turn_the_sign_inside_a_block(bench, seed):
+    """A product larger than the running sum itself, of the other sign, somewhere inside a block whose earlier lanes go
+    in as they stand: the lane that holds it is walked, the prefix before it must be exact (the prefix sums AT that
+    lane are beyond 2^53 and rounded), and the rest is taken again under the new sign and exponent."""
+    rng = np.random.default_rng(500 + seed)
+    n = 1024 * 6
+    p = rng.uniform(-1, 1, n)
+    for pos in rng.integers(0, n, 5):
+        p[pos] = rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(11.5, 12.5)
+    for start in (-5.2e11, 5.2e11, 3e11, -7.7e11, 1e12):
+        check(bench, p, np.ones(n), start, f"giants seed {seed} from {start}")
+    check(bench, p * 2.0 ** -300, np.ones(n), -5.2e11 * 2.0 ** -300, f"giants seed {seed}, scaled down")
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_regimes_stitched_together(bench, seed):
     """Segments of random length, each with its own magnitude, sign bias and grid (multiples of a power of two: halfway

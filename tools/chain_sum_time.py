@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import nka_amd  # noqa: E402
 
 acc = nka_amd.nka(diagnostic=True).init(64, 3)
-stamps = "stamps" in os.environ.get("NKA_HIP_DIAG_LIB", "")
+stamps = "chain_stamps" in os.environ.get("NKA_HIP_DIAG_LIB", "")
 sizes = [int(float(a)) for a in sys.argv[1:]] or [10**6, 10**7, 10**8]
 for n in sizes:
     g = torch.Generator(device="cuda")
@@ -33,4 +33,6 @@ for n in sizes:
                 acc._L.nka_hip_get_stamps(acc._handle(), out)
                 names = ("load", "summary", "wait", "apply", "wait", "store", "wait")
                 line += "  phases us: " + " ".join(f"{nm}={out[i] * 0.01:.0f}" for i, nm in enumerate(names))
+                cn = ("blocks in runs", "on their own", "summarised again", "lane by lane", "lanes walked singly", "lanes walked as a rest")
+                line += "\n      " + ", ".join(f"{nm} {int(out[8 + i])}" for i, nm in enumerate(cn))
             print(line, flush=True)
