@@ -136,11 +136,13 @@ def host_mem_available_gb():
     return None
 
 
-def cpu_baseline(mvec: int, n: int, timed: int = 6, gen=None, note: str = ""):
+def cpu_baseline(mvec: int, n: int, timed: int = 6, gen=None, note: str = "", after_update=None):
     """Time the reference's own accel_update (compiled from /root/reference into
     oracle/_ref, if it travelled with the repo) or else the oracle port, serial,
     on the same workload: same generator (gen(t) -> the t-th input as a host array;
-    default: the numpy twin of the device generator), same mvec, steady state."""
+    default: the numpy twin of the device generator), same mvec, steady state.
+    after_update(t, f, kind), if given, sees every output (the device's reference-order
+    twin of the run compares itself with it there, bit for bit)."""
     import numpy as np
     from nka_amd import synth
     from oracle import oracle_py as O
@@ -164,6 +166,8 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6, gen=None, note: str = ""):
         t0 = time.perf_counter()
         acc.accel_update(f)
         t_cpu += time.perf_counter() - t0
+        if after_update is not None:
+            after_update(t, f, kind)
     assert acc.num_vec() == mvec
     dt = []
     for t in range(mvec + 2, mvec + 2 + timed):
@@ -171,6 +175,8 @@ def cpu_baseline(mvec: int, n: int, timed: int = 6, gen=None, note: str = ""):
         t0 = time.perf_counter()
         acc.accel_update(f)
         dt.append(time.perf_counter() - t0)
+        if after_update is not None:
+            after_update(t, f, kind)
     per = float(np.median(dt))
     return {
         "value": 1.0 / per, "unit": "updates/s", "cores": 1, "kind": kind,
@@ -1112,8 +1118,53 @@ def main(argv=None):
                         synth.fill_torch(dbuf, SEED, t, 0, n_global)
                         hbuf.copy_(dbuf)
                         return hbuf.numpy()
-                out["cpu_baseline"] = cpu_baseline(m, cpu_n, timed, gen, why)
+                # The device's bit-identical mode beside it (nka_hip_set_sum_order(NKA_HIP_SUMS_REFERENCE_ORDER), src-F08
+                # flavour): the same inputs through a second handle, every output compared with the compiled reference's
+                # -- torch.equal, at the full size -- and the steady-state updates timed.
+                twin = {"acc": None, "equal": 0, "compared": 0, "ms": [], "error": None}
+                if headline and cpu_n == n_local and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
+                    try:
+                        twin["acc"] = nka_amd.nka().init(n_local, m, flavor=FLAVORS["f08"]).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+                        twin["in"] = torch.empty(n_local, dtype=torch.float64, device=dev)
+                        twin["ref"] = torch.empty(n_local, dtype=torch.float64, device=dev)
+                    except Exception as exc:
+                        twin["acc"], twin["error"] = None, repr(exc)
+
+                def after_update(t, f_host, kind):
+                    if twin["acc"] is None or kind != "reference":
+                        return
+                    try:
+                        synth.fill_torch(twin["in"], SEED, t, 0, n_global)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        twin["acc"].accel_update(twin["in"])
+                        e1.record()
+                        twin["ref"].copy_(torch.from_numpy(f_host))
+                        torch.cuda.synchronize(dev)
+                        twin["compared"] += 1
+                        twin["equal"] += int(torch.equal(twin["in"], twin["ref"]))
+                        if t >= m + 2:
+                            twin["ms"].append(e0.elapsed_time(e1))
+                    except Exception as exc:
+                        twin["error"] = repr(exc)
+                        twin["acc"] = None
+
+                out["cpu_baseline"] = cpu_baseline(m, cpu_n, timed, gen, why, after_update)
                 out["cpu_baseline"]["updates_per_s_scaled_to_n_global"] = out["cpu_baseline"]["value"] * cpu_n / n_global
+                if twin["compared"] or twin["error"]:
+                    ms = sorted(twin["ms"])
+                    med = ms[len(ms) // 2] if ms else None
+                    out["cpu_baseline"]["device_reference_order"] = {
+                        "what": "the same inputs through nka_hip_set_sum_order(NKA_HIP_SUMS_REFERENCE_ORDER), src-F08 flavour: every "
+                                "sum formed in the reference's order (k_chain_sums); every output compared with the compiled "
+                                "reference's on the host run beside it, torch.equal",
+                        "outputs_compared": twin["compared"], "outputs_bit_identical": twin["equal"],
+                        "ms_per_step": med, "value": (1e3 / med) if med else None, "unit": "updates/s",
+                        "times_the_cpu_reference": (1e3 / med) / out["cpu_baseline"]["value"] if med else None,
+                        "error": twin["error"]}
+                if twin["acc"] is not None:
+                    twin["acc"].delete()
+                twin.clear()
                 dbuf = hbuf = None
             except Exception as exc:  # the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
@@ -1129,6 +1180,11 @@ def main(argv=None):
                 out["roofline"].update(flat)
             if rounded is not None and rounded.get("value"):
                 out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]
+            dro = (out.get("cpu_baseline") or {}).get("device_reference_order")
+            if dro and dro.get("value"):                        # (flat, like the others)
+                out["roofline"]["reference_order_updates_per_s"] = dro["value"]
+                out["roofline"]["reference_order_outputs_compared_with_cpu_reference"] = dro["outputs_compared"]
+                out["roofline"]["reference_order_outputs_bit_identical"] = dro["outputs_bit_identical"]
             if host_arr is not None:
                 out["host_array_entry"] = host_arr
                 for kind in ("pageable", "pinned"):

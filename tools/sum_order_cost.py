@@ -14,17 +14,22 @@ from nka_amd import synth  # noqa: E402
 
 
 def us_per_update(n, m, order, reps):
+    """Every input is a fresh vector of the generator (repeating a pool would make the differences dependent: the subspace
+    would shrink to the pool's size and both modes would look cheaper than they are at mvec vectors)."""
     acc = nka_amd.nka().init(n, m).set_sum_order(order)
-    fs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(8)]
-    for j, f in enumerate(fs):
-        synth.fill_torch(f, 4321, j, 0, n)
+    buf = torch.empty(n, dtype=torch.float64, device="cuda")
     for t in range(m + 4):
-        acc.accel_update(fs[t % 8].clone())
-    work = [f.clone() for f in fs]
+        synth.fill_torch(buf, 4321, t, 0, n)
+        acc.accel_update(buf)
+    work = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(reps)]
+    for r, w in enumerate(work):
+        synth.fill_torch(w, 4321, m + 4 + r, 0, n)
     torch.cuda.synchronize()
+    if acc.num_vec() != m:
+        print(f"# n={n} m={m}: the subspace holds {acc.num_vec()} vectors", flush=True)
     t0 = time.perf_counter()
     for r in range(reps):
-        acc.accel_update(work[r % 8])
+        acc.accel_update(work[r])
     torch.cuda.synchronize()
     return 1e6 * (time.perf_counter() - t0) / reps
 
