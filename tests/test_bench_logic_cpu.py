@@ -162,3 +162,17 @@ def test_roofline_block_at_a_shrunk_subspace(bench):
     assert r["kernels"]["PB_k_combine"]["words_per_element"] == D + 2 + 5
     assert r["whole_update"]["bytes_moved"] == 8.0 * n * (9 + 2 * D)
     assert r["traffic"] is None                      # the committed full-subspace PMC summary does not apply
+
+
+def test_cpu_baseline_hands_every_output_to_the_twin(bench):
+    """The CPU leg shows every output of the compiled reference (or of the port) to `after_update` -- that is where the
+    device's reference-order twin compares itself with it, bit for bit, in the headline run."""
+    import numpy as np
+    seen = []
+    out = bench.cpu_baseline(3, 200, timed=2, after_update=lambda t, f, kind: seen.append((t, kind, np.array(f, copy=True))))
+    assert [t for t, _, _ in seen] == list(range(3 + 2 + 2))
+    assert all(kind == out["kind"] for _, kind, _ in seen) and out["kind"] in ("reference", "port")
+    assert all(f.shape == (200,) and np.isfinite(f).all() for _, _, f in seen)
+    # (and the outputs are the accelerated ones, not the inputs: once the subspace is there they differ from the generator's vectors)
+    from nka_amd import synth
+    assert not np.array_equal(seen[-1][2], synth.fill_numpy(bench.SEED, seen[-1][0], 0, 200, 200))

@@ -86,6 +86,8 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
     # Gram row on the rounded w1').  `sums` overrides the rotation (the regression test replays recorded seeds in another mode).
     names = {nka_amd.SUMS_BLOCKED: "blocked", nka_amd.SUMS_AUTO: "auto", nka_amd.SUMS_REFERENCE_ORDER: "reference",
              nka_amd.SUMS_BLOCKED_ROUNDED: "rounded"}
+    if sums is None and os.environ.get("NKA_FUZZ_SUMS") == "reference":     # (a soak of the bit-identical mode alone)
+        sums = nka_amd.SUMS_REFERENCE_ORDER
     if sums is None:
         sums = (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER)[seed % 3] if seed < 300_000 else \
             (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER, nka_amd.SUMS_BLOCKED_ROUNDED)[seed % 4]
