@@ -1021,7 +1021,7 @@ __device__ __forceinline__ double wave_scan_add_f64(double x) {
 // exponent the group starts with; wavefront 0 then walks the summaries (chain_block_apply): a block is accepted iff it
 // was summarised under the sum's present sign and exponent, every prefix provably stays inside the binade and every
 // lane's sum of |r| < 2^51 (r exact, lane sums exact; NaN and Inf fail the comparison).  The prefix bounds are kept in SINGLE precision,
-// rounded to nearest: they are off by < 2^31 units, and the acceptance window leaves 2^34 units (2^-18 of the binade)
+// rounded to nearest: they are off by < 2^33 units, and the acceptance window leaves 2^34 units (2^-18 of the binade)
 // at either end -- which also covers the corrections (<= 1024) and the one inexact case (sums beyond 2^53 are only ever
 // formed in blocks that leave the window by far more than their error).  Otherwise the block is summarised again under
 // the present exponent or, failing that, walked (chain_block_serial).  Same bits as the walk by construction;
@@ -1033,7 +1033,7 @@ struct ChainLane {
   int par, differ;           // parity of the lane's sum if it starts even; whether starting odd still flips it (no halfway case met)
   int adj0, adj1;            // corrections the halfway cases owe if the lane starts even / odd
 };
-__device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLaneElems], double scale, bool active) {
+__device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLaneElems], double scale) {
 #pragma clang fp contract(off)
   constexpr double M = 6755399441055744.0;                         // 1.5 * 2^52
   ChainLane ln;
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLa
   bool halfway = false;
 #pragma unroll
   for (int j = 0; j < kChainLaneElems; j++) {
-    const double t = (active ? pl[j] : 0.0) * scale;               // exact (a power of two), |t| tiny if it underflows
+    const double t = pl[j] * scale;                                // exact (a power of two), |t| tiny if it underflows
     const double tm = t + M;                                       // rounds t to an integer, halves to even
     const double r = tm - M;
     const double diff = t - r;                                     // exact
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLa
     parw = 0;
 #pragma unroll
     for (int j = 0; j < kChainLaneElems; j++) {
-      const double t = (active ? pl[j] : 0.0) * scale;
+      const double t = pl[j] * scale;
       const double tm = t + M;
       const double diff = t - (tm - M);
       if (fabs(diff) == 0.5) {                                     // halfway: r is the EVEN neighbour of t, r + 2 diff the odd one
@@ -1093,7 +1093,6 @@ struct ChainSummary {
   int hi;                    // sign and exponent word the summary assumed; 0: none, or a product out of range
 };
 constexpr int kChainAdjBias = 64 * kChainLaneElems;
-constexpr int kChainRoundWorth = 14;                              // lanes a round of chain_block_by_lanes must gain to be worth another
 __device__ __forceinline__ bool chain_scalable(double a) {
   const int ef = (__double2hiint(a) >> 20) & 0x7ff;
   return ef >= 1023 - 900 && ef <= 1023 + 900;                    // not zero, subnormal, Inf, NaN; scale factors in range
@@ -1109,7 +1108,7 @@ __device__ __forceinline__ ChainSummary chain_block_summary(double a, const doub
   const double scale = __hiloint2double((hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);    // +-2^(52-e): S > 0
   double pl[kChainLaneElems];
   chain_lane_read(pl, blk, lane);
-  const ChainLane ln = chain_lane_pass(pl, scale, true);
+  const ChainLane ln = chain_lane_pass(pl, scale);
   const bool bad = !(ln.absl < 0x1p51);                            // some |t| >= 2^51 / Inf / NaN: r = rne(t) and the lane's sums are exact below that
   // where the lane's excursion lies: the prefix before it +- its own absolute sum, in single precision
   const float basef = (float)ln.base, abslf = (float)ln.absl;
@@ -1157,63 +1156,13 @@ __device__ __forceinline__ bool chain_block_apply(ChainRun &run, const ChainSumm
   return true;
 }
 
-// A block that does not go in whole (the sum meets an end of its binade inside it): lane by lane.  Under the sum's
-// present exponent and parity the lanes before the first one whose excursion may leave the binade are accepted as they
-// stand (their prefix sums, corrections included, are exact), that lane's 16 products are walked, and the rest is taken
-// again under the exponent the walk ends in -- as long as rounds pay (a round costs what walking ~14 lanes costs), then
-// the rest is walked.  One wavefront, the running sum known: nothing here is speculative.
-__device__ __forceinline__ double chain_block_by_lanes(double a, const double *blk, unsigned long long *cnt = nullptr) {
-#pragma clang fp contract(off)
-  const int lane = threadIdx.x & 63;
-  constexpr double kEdge = 0x1p34;
-  double pl[kChainLaneElems];
-  chain_lane_read(pl, blk, lane);
-  int first = 0, poor = 0;
-  for (int round = 0; round < 4 && 64 - first >= kChainRoundWorth && poor < 2; round++) {
-    ChainRun run;
-    chain_run_enter(run, a);
-    if (run.hi == 0) break;
-    const int e = ((run.hi >> 20) & 0x7ff) - 1023;
-    const double scale = __hiloint2double((run.hi & (int)0x80000000) | ((1023 + 52 - e) << 20), 0);
-    const ChainLane ln = chain_lane_pass(pl, scale, lane >= first);
-    int q;
-    bool flips;
-    chain_lane_parity(ln, lane, q, flips);
-    if (flips) q ^= __double2loint(run.S) & 1;                     // the parity the block really starts from
-    const int adj = q ? ln.adj1 : ln.adj0;
-    const int adji = wave_scan_add_i32(adj);
-    const double incl = wave_scan_add_f64(ln.base);
-    const double excl = incl - ln.base;
-    const bool viol = !(ln.absl < 0x1p51) || !(run.S + (excl - ln.absl) >= 0x1p52 + kEdge) ||
-                      !(run.S + (excl + ln.absl) <= 0x1p53 - kEdge);
-    const unsigned long long m = __ballot(viol) & ~((1ull << first) - 1ull);   // (first < 64)
-    const int L = m ? __ffsll((long long)m) - 1 : 64;
-    if (L > first) {                                               // lanes first .. L-1: the inclusive sums AT lane L-1 (what
-      const double sum = readlane_f64(incl, L - 1);                //  lane L holds may be beyond 2^53 and inexact: its own
-      const int corr = __builtin_amdgcn_readlane(adji, L - 1);     //  `excl` is not to be trusted)
-      a = (run.S + (sum + (double)corr)) * run.unscale;
-    }
-    const int gained = L - first;
-    first = L;
-    if (L == 64) break;
-    poor = gained < kChainRoundWorth ? poor + 1 : 0;               // a round costs what walking ~14 lanes costs: two poor rounds
-                                                                   // in a row = the sum hovers at an end of its binade (or is small)
-    a = chain_block_serial(a, blk, (L + 1) * kChainLaneElems, L);  // lane L, element after element
-    first = L + 1;
-    if (cnt) { cnt[4] += 1; }                                      // (lanes walked one at a time)
-  }
-  if (cnt) { cnt[5] += 64 - first; }                               // (lanes walked as the rest of a block)
-  if (first < 64) a = chain_block_serial(a, blk, kChainBlock, first);
-  return a;
-}
-
 // The loop of one sum: `load(g0)` brings the operands of the group that starts at element g0 into the caller's registers
 // (wavefront w: block w of the group), `store()` rounds their products into the wavefront's block of `prod`.  Returns the
 // sum (valid in thread 0).  The whole workgroup calls it.
 struct ChainStamps {
 #ifdef NKA_CHAIN_STAMPS
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // 10 ns ticks of wavefront 0: load issue, summary, wait, apply, wait, store
-  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks: in a run / on their own / summarised again / lane by lane; lanes walked singly / as a rest
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks: in a run / on their own / summarised again / walked
 #endif
 };
 template <class Load, class Store>
@@ -1229,11 +1178,9 @@ __device__ __forceinline__ double chain_drive(double a, int64_t n, double *prod,
   unsigned long long tk = wall_clock64(), tn;
 #define NKA_CHAIN_STAMP(i) tn = wall_clock64(); stamps.st[i] += tn - tk; tk = tn;
 #define NKA_CHAIN_COUNT(i, v) stamps.cnt[i] += (v);
-#define NKA_CHAIN_CNT stamps.cnt
 #else
 #define NKA_CHAIN_STAMP(i)
 #define NKA_CHAIN_COUNT(i, v)
-#define NKA_CHAIN_CNT nullptr
 #endif
   for (int64_t g0 = 0; g0 < n; g0 += kChainGroup) {
     const bool more = g0 + kChainGroup < n;
@@ -1311,7 +1258,9 @@ __device__ __forceinline__ double chain_drive(double a, int64_t n, double *prod,
         if (!done) {
           if (run.hi != 0) a = run.S * run.unscale;
           if (len == kChainBlock && !walk) { NKA_CHAIN_COUNT(3, 1) }
-          a = (len == kChainBlock && !walk) ? chain_block_by_lanes(a, bk, NKA_CHAIN_CNT) : chain_block_serial(a, bk, len);
+          // (walked whole: accepting its first lanes and taking the rest again under the next exponent was measured -- a
+          //  sum that meets an end of its binade hovers there, a round costs what walking 14 lanes costs and gained 5: a loss)
+          a = chain_block_serial(a, bk, len);
           chain_run_enter(run, a);
         }
         k++;
@@ -1328,7 +1277,6 @@ __device__ __forceinline__ double chain_drive(double a, int64_t n, double *prod,
   return a;
 #undef NKA_CHAIN_STAMP
 #undef NKA_CHAIN_COUNT
-#undef NKA_CHAIN_CNT
 }
 
 static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_sums(Ctl ctl, Vecs vs,

@@ -1,6 +1,6 @@
-"""The reference-order sums of LONG vectors (k_chain_sums, round 5): one workgroup per sum, whole blocks of 512 products
-taken through the chain in integer arithmetic wherever that is provably the walk's result (chain_block_fast), the walk
-itself elsewhere.  A sequential sum  ((start + p0) + p1) + ...  has exactly one right answer per input, so every
+"""The reference-order sums of LONG vectors (k_chain_sums, round 5): one workgroup per sum, whole blocks of 1024 products
+taken through the chain in integer arithmetic wherever that is provably the walk's result (chain_block_summary /
+chain_block_apply), the walk itself elsewhere.  A sequential sum  ((start + p0) + p1) + ...  has exactly one right answer per input, so every
 comparison here is on the BITS: the kernel against numpy's strictly sequential `add.accumulate`, and against its own
 element-after-element walk (`walk=True`), on inputs built to sit on the algorithm's edges -- halfway cases under both
 parities, binade crossings in both directions, cancellation to zero, sign changes, products far larger and far smaller
@@ -129,9 +129,10 @@ def test_magnitudes_over_the_whole_range(bench):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_giants_that_turn_the_sign_inside_a_block(bench, seed):
-    """A product larger than the running sum itself, of the other sign, somewhere inside a block whose earlier lanes go
-    in as they stand: the lane that holds it is walked, the prefix before it must be exact (the prefix sums AT that
-    lane are beyond 2^53 and rounded), and the rest is taken again under the new sign and exponent."""
+    """A product larger than the running sum itself, of the other sign, somewhere inside a block: the sum changes sign and
+    exponent in one step, the prefix sums at that lane are beyond 2^53 (rounded), the block must not go in as summarised --
+    and the blocks behind it were summarised under a sign that no longer holds.  (This case caught a real bug in a
+    lane-by-lane variant of the fallback: the exclusive prefix AT the lane of the giant is not exact.)"""
     rng = np.random.default_rng(500 + seed)
     n = 1024 * 6
     p = rng.uniform(-1, 1, n)

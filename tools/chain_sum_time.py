@@ -33,6 +33,6 @@ for n in sizes:
                 acc._L.nka_hip_get_stamps(acc._handle(), out)
                 names = ("load", "summary", "wait", "apply", "wait", "store", "wait")
                 line += "  phases us: " + " ".join(f"{nm}={out[i] * 0.01:.0f}" for i, nm in enumerate(names))
-                cn = ("blocks in runs", "on their own", "summarised again", "lane by lane", "lanes walked singly", "lanes walked as a rest")
+                cn = ("blocks in runs", "on their own", "summarised again", "walked")
                 line += "\n      " + ", ".join(f"{nm} {int(out[8 + i])}" for i, nm in enumerate(cn))
             print(line, flush=True)
