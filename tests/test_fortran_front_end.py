@@ -178,7 +178,8 @@ def test_abstract_vector_flavour_on_device_grid_vector_with_ghost_ring(fortran_b
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45), (2, 4099, 30, 50)])
+@pytest.mark.parametrize("nfield,nper,mvec,ncalls", [(4, 2503, 6, 24), (1, 64, 3, 12), (3, 1, 2, 8), (4, 2503, 20, 45), (2, 4099, 30, 50),
+                                                     (4, 25003, 5, 12)])   # (the last: a dozen groups of the per-sum machinery per dot)
 def test_abstract_vector_flavour_with_reference_order_sums_returns_the_reference_bits(fortran_build, oracle, tmp_path, nfield,
                                                                                       nper, mvec, ncalls):
     """hip_block_vector_set_sum_order(ws, NKA_HIP_SUMS_REFERENCE_ORDER) (driver: compact argument + 10): dot() sums element

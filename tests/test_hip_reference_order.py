@@ -107,6 +107,27 @@ def test_on_request_the_reference_bits_at_any_length(torch_cuda, oracle, flavor,
     _lockstep(torch_cuda, oracle, n, m, flavor, nka_amd.SUMS_REFERENCE_ORDER, calls=26, swap_every=4)
 
 
+@pytest.mark.parametrize("n,m", [(4099, 5), (2 * 8192 + 37, 7), (3 * 8192, 3)])
+def test_reference_bits_from_a_buffer_that_is_not_16_byte_aligned(torch_cuda, oracle, n, m):
+    """The per-sum kernel of long vectors loads 16 bytes per lane when f and the stored vectors allow it; a caller's f at
+    an odd multiple of 8 bytes takes the 8-byte loads: the same bits, beyond one group (8 192 elements) and at its edge."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(n + m)
+    acc = nka_amd.nka().init(n, m, flavor=0).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+    ora = oracle.OracleNKA(n, m, 0)
+    raw = torch.empty(n + 1, dtype=torch.float64, device="cuda")
+    view = raw[1:]
+    assert view.data_ptr() % 16 == 8
+    for t in range(m + 6):
+        x = rng.standard_normal(n)
+        f = x.copy()
+        ora.accel_update(f)
+        view.copy_(torch.from_numpy(x))
+        acc.accel_update(view)
+        assert np.array_equal(view.cpu().numpy(), f), (n, m, t)
+
+
 def test_medium_fixture_of_the_compiled_f08_reference_bit_for_bit(torch_cuda):
     """n = 1e5, m = 10, 25 calls: the sampled entries of the compiled src-F08 reference's outputs
     (tests/golden/medium_n100000_m10.npz) -- equal, not close.  (The fixture's norm and probe functional were formed by
