@@ -98,9 +98,10 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  *     i.e. within the stated tolerance wherever the reference is, and never further from the truth than F times the
  *     reference's own worst distance on the same calls (ill-conditioned sequences -- pivots down to vtol, a tiny difference
  *     norm s -- put the REFERENCE 1e-10 ... 1e-6 from the truth; no fixed figure can hold there).  An EMPIRICAL bar with a
- *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 24 sequences in round 5 (39 834 sharded
- *     records, 3 735 other sequences) -- all but nine with n <= 9 elements; one with 510 (within one tile); the EIGHT beyond one
- *     tile have 595 ... 1660 elements (2.05 ... 3.5 x instead of 2 x) and, once, 8191 (2.7 x).  Each of the eight is a fixture
+ *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 28 sequences in round 5 (48 411 sharded
+ *     records, 4 678 other sequences) -- all but eleven with n <= 9 elements; one with 510 (within one tile); the TEN beyond one
+ *     tile have 595 ... 4097 elements (2.05 ... 3.5 x instead of 2 x; once 5.5 x: abstract-vector flavour, 4097 elements) and,
+ *     once, 8191 (2.7 x).  Each of the ten is a fixture
  *     (tests/golden/soak_cases.json: its generator call) replayed by the suite with a cap on its ratio, and the soak tool exits
  *     non-zero on an exceedance beyond one tile that the file does not list.  DIRECTLY against the reference: wherever err(f_reference) <= base / 2,
  *     ||f_device - f_reference|| / ||f_in|| <= 2 * base is asserted; at n = 2e7, m = 20 (independent and dependent inputs)

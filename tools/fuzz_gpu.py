@@ -166,6 +166,8 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True)
     n = nfield * nper
     m = int(rng.integers(1, 41))
     compact, fuse, defer = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    if os.environ.get("NKA_FUZZ_VECTOR_FUSE") in ("0", "1"):       # (replays of recorded seeds with the norm stage fused / on its own)
+        fuse = int(os.environ["NKA_FUZZ_VECTOR_FUSE"])
     if fuse:
         defer = 1                                           # fusing needs the deferral
     # every third seed on one rank: sums in the reference's order (hip_block_vector_set_sum_order; the driver's compact
