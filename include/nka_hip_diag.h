@@ -37,6 +37,8 @@ extern "C" {
  * at the next width with one dead ring slot; 0 = exact widths everywhere (profiles/r05/multipass.txt).  Same bits.
  * "fail_after_solve" = 1: the NEXT update returns NKA_HIP_EHIP right behind its enqueued scalar step, as a failing HIP call
  * there would: the handle must then be poisoned (every later call but destroy: NKA_HIP_ESTATE).
+ * "chain_many" = -1/0/1: reference-order sums of the longest vectors by the whole device (k_chain_blocks / _predict / _apply): -1 automatic
+ * (from 2^19 elements on), 0 never (one compute unit per sum: k_chain_sums), 1 wherever a vector has a full block.  Same bits.
  * "chain_walk" = 0/1: reference-order sums of long vectors (k_chain_sums) walk every block element after element instead of
  * taking whole blocks through the chain in integer arithmetic (chain_block_fast).  Same bits. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
@@ -51,7 +53,8 @@ int nka_hip_debug_time_pa(nka_hip_t a, const double *f_dev, int32_t reps, float 
 /* Test bench of the reference-order sums of long vectors: start + x[0]*y[0] + x[1]*y[1] + ... (one rounding per product and
  * per addition, in that order) over any two device arrays of n doubles, formed by the kernel the update uses (k_chain_sums, one
  * workgroup).  walk = 1: every block element after element; 0: whole blocks through the chain where that is provably the same
- * (chain_block_fast).  *ms (optional) = the kernel's device time.  The handle's state is not touched (scratch only). */
+ * (chain_block_summary / _apply); walk | 2: the same sum through the many-compute-unit form (k_chain_blocks / k_chain_predict /
+ * k_chain_apply: needs n >= 1024).  *ms (optional) = the kernels' device time.  The handle's state is not touched (scratch only). */
 int nka_hip_debug_chain_sum(nka_hip_t a, const double *x_dev, const double *y_dev, int64_t n, double start, int32_t walk,
                             double *sum, float *ms);
 

@@ -225,6 +225,10 @@ struct nka_hip_state {
                               // when the tickets apply), 1 = 512 elements, 2 = 1024 elements
   int pb_tickets = -1;        // tile tickets of the rolling-window PB: -1 automatic, 0 static tile mapping,
                               // 1, 2, 4, 8 = that many ticket counters (see k_combine_win)
+  double *chain_pred = nullptr;   // reference-order sums of the longest vectors (k_chain_blocks ...): per sum and block of 1024, the block
+  void *chain_summ = nullptr;     // sum / the predicted running sum, and the block's summary; allocated at the first such update
+  long long chain_cap = 0;        // (sums x blocks the two arrays hold)
+  int chain_many = -1;            // diagnostic switch "chain_many": -1 automatic (from kChainManyMin elements on), 0 never, 1 whenever blocks exist
   int chain_walk = 0;         // diagnostic switch "chain_walk": k_chain_sums walks every block element after element (A/B of chain_block_fast)
   int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
   int fail_after_solve = 0;   // diagnostic switch "fail_after_solve": the next update fails as if a HIP call behind its scalar step had
@@ -668,9 +672,12 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
     }
   }
 
-  {   // ... and, for long vectors, a group of products per sum (k_chain_sums)
+  {   // ... and, for long vectors, a group of products per sum (k_chain_sums) / a block per wavefront (k_chain_blocks)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_sums), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kChainLdsBytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_blocks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kChainLdsBytes);
     if (e != hipSuccess) {
       delete a;
       return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(e));
@@ -798,6 +805,8 @@ int nka_hip_destroy(nka_hip_t a) {
   hipFree(a->ctl.ic);
   hipFree(a->ctl.dc);
   hipFree(a->partials);
+  hipFree(a->chain_pred);
+  hipFree(a->chain_summ);
   hipFree(a->tickets);
   hipFree(a->ctl.pc);
   for (void *p : a->extra_allocs) hipFree(p);
@@ -887,6 +896,8 @@ int nka_hip_clone(nka_hip_t src, nka_hip_t *out) {
   b->pb_tickets = src->pb_tickets;
   b->prime_pad = src->prime_pad;
   b->chain_walk = src->chain_walk;
+  b->chain_many = src->chain_many;      // (the copy allocates its own block arrays when it needs them)
+  b->chain_pred = nullptr; b->chain_summ = nullptr; b->chain_cap = 0;
   b->serial_solve = src->serial_solve;
   b->sum_order = src->sum_order;
   b->shard_rank = src->shard_rank;
@@ -1237,6 +1248,51 @@ static bool held_by_library(const nka_hip_state *a, const double *p) {
 // order, so ANY hook that sums serves as the chain's transport.  N rounds for the norm (the Gram row needs the GLOBAL s
 // before w1' = d/s can be rounded), N rounds for the rows: 2N small exchanges and the serial walk of the whole global
 // vector per update -- validation speed, bits of the single-rank compiled reference.
+// The longest vectors: the block summaries of every sum by the whole device, then one wavefront per sum applies them
+// (k_chain_blocks / k_chain_predict / k_chain_apply, nka_kernels.hpp).  false: not this way (short vectors, no memory for the
+// block arrays, a capture in progress before they exist) -- the caller takes one compute unit per sum.
+constexpr long long kChainManyMin = 1 << 19;
+static bool chain_many_ready(nka_hip_t a, int nsum_max, long long n = -1) {
+  if (n < 0) n = a->n;
+  const long long nfull = n / kChainBlock;
+  if (a->chain_many == 0 || nfull < 1 || (a->chain_many < 0 && n < kChainManyMin)) return false;
+  const long long need = nfull * nsum_max;
+  if (a->chain_cap >= need) return true;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(a->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (cs != hipStreamCaptureStatusNone) return false;                 // (no allocation inside a capture)
+  hipFree(a->chain_pred); hipFree(a->chain_summ);
+  a->chain_pred = nullptr; a->chain_summ = nullptr; a->chain_cap = 0;
+  void *p = nullptr, *q = nullptr;
+  if (hipMalloc(&p, sizeof(double) * (size_t)need) != hipSuccess || hipMalloc(&q, sizeof(ChainSummary) * (size_t)need) != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(p); hipFree(q);
+    return false;
+  }
+  a->chain_pred = static_cast<double *>(p); a->chain_summ = q; a->chain_cap = need;
+  return true;
+}
+static int chain_many_stage(nka_hip_t a, const double *f, int rcp, int set, int with_f, int ub, int nsum, const double *probe = nullptr,
+                            long long n_probe = -1) {
+  hipStream_t s = a->stream;
+  Vecs vs = a->vs;
+  if (n_probe >= 0) vs.n = n_probe;                    // (the diagnostic entry sums arrays of its own length)
+  const long long nfull = vs.n / kChainBlock;
+  const long long items = nfull * nsum;
+  const unsigned grid = (unsigned)((items + kChainWaves - 1) / kChainWaves);
+  ChainSummary *summ = static_cast<ChainSummary *>(a->chain_summ);
+  hipLaunchKernelGGL(k_chain_blocks, dim3(grid), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, vs, f, rcp, set, with_f, ub, nsum, nfull,
+                     a->chain_pred, summ, 0, probe);
+  hipLaunchKernelGGL(k_chain_predict, dim3(nsum), dim3(kChainPredictThreads), 0, s, a->ctl, vs, f, rcp, set, with_f, ub, nfull, a->chain_pred,
+                     probe);
+  hipLaunchKernelGGL(k_chain_blocks, dim3(grid), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, vs, f, rcp, set, with_f, ub, nsum, nfull,
+                     a->chain_pred, summ, 1, probe);
+  hipLaunchKernelGGL(k_chain_apply, dim3(nsum), dim3(64), 0, s, a->ctl, vs, f, rcp, set, with_f, ub, nfull,
+                     static_cast<const ChainSummary *>(summ), a->chain_walk, probe);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // (beyond one chunk of k_dots_ordered: one workgroup per sum, k_chain_sums)
 static bool chain_per_sum(const nka_hip_state *a, int rows) { return a->n > ord_chunk(rows); }
 
@@ -1351,11 +1407,18 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
         // long vectors: one workgroup per sum; the norm alone first (one chain: every other sum of the update would wait
         // for it on idle compute units if it shared a launch with sums twice as long), then everything else side by side
         HIP_TRY(hipMemsetAsync(a->ctl.red(), 0, sizeof(double) * (size_t)a->ctl.red_count(), s));
-        if (a->pending)
-          hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                             (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
-        hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                           (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
+        if (chain_many_ready(a, 1 + 2 * a->mvec)) {
+          // the longest vectors: every block of every sum summarised by the whole device, one wavefront per sum applies
+          if (a->pending)
+            if (int rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, 1)) return rc;
+          if (int rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainRows, 1, older_ub, 1 + 2 * older_ub)) return rc;
+        } else {
+          if (a->pending)
+            hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                               (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
+          hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                             (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
+        }
       } else {
         hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
                            ord_chunk(rows), (int)kOrdAll, 0);
@@ -1986,8 +2049,24 @@ int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipMemcpyAsync(slot, &start, sizeof(double), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
+  const bool many = (walk & 2) != 0;                    // (bit 1: through k_chain_blocks / _predict / _apply)
+  if (many) {
+    const int keep = a->chain_many;
+    a->chain_many = 1;
+    const bool ready = chain_many_ready(a, 1, n);
+    a->chain_many = keep;
+    if (!ready) return fail(NKA_HIP_EINVAL, "debug_chain_sum: no full block, or no memory for the block arrays");
+  }
   HIP_TRY(hipEventRecord(e0, a->stream));
-  hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, a->stream, a->ctl, vs, x, 0, (int)kChainProbe, 1, 0, (int)walk, y);
+  if (many) {
+    const int keepw = a->chain_walk;
+    a->chain_walk = walk & 1;
+    const int rc = chain_many_stage(a, x, 0, (int)kChainProbe, 1, 0, 1, y, n);
+    a->chain_walk = keepw;
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, a->stream, a->ctl, vs, x, 0, (int)kChainProbe, 1, 0, (int)(walk & 1), y);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e1, a->stream));
   HIP_TRY(hipMemcpyAsync(sum, slot, sizeof(double), hipMemcpyDeviceToHost, a->stream));
@@ -2043,6 +2122,9 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   } else if (k == "prime_pad") {      // -1 automatic = 1: list lengths 23 / 29 / 31 run the next width (one dead ring slot); 0: exact widths
     if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "prime_pad: -1, 0, 1");
     a->prime_pad = value;
+  } else if (k == "chain_many") {     // -1 automatic, 0: one compute unit per reference-order sum at every length, 1: many wherever blocks exist
+    if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "chain_many: -1, 0, 1");
+    a->chain_many = value;
   } else if (k == "chain_walk") {     // 1: the per-sum reference-order kernel walks every block (no chain_block_fast): same bits, for A/B
     a->chain_walk = value != 0;
   } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)

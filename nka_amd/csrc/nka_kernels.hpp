@@ -1279,113 +1279,308 @@ __device__ __forceinline__ double chain_drive(double a, int64_t n, double *prod,
 #undef NKA_CHAIN_COUNT
 }
 
-static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_sums(Ctl ctl, Vecs vs,
-                                                                                              const double *__restrict__ f,
-                                                                                              int rcp, int set, int with_f, int ub,
-                                                                                              int walk, const double *probe) {
-#pragma clang fp contract(off)      // products and additions stay separate roundings whatever the build's flags
-  extern __shared__ __attribute__((aligned(16))) double prod[];   // kChainLdsBytes
-  __shared__ ChainSummary summ[kChainGroupBlocks];
-  __shared__ double sh_a;
-  const int t = threadIdx.x, b = blockIdx.x, wave = t >> 6;
+// One sum of an update as the chain kernels see it: which vectors, which rounding of their product, where the sum goes.
+struct ChainSum {
+  int kind, dst;             // kChainKind...; index into red[].  kind < 0: this sum does not exist in this update
+  const double *f, *w1, *wk; // f; the pending w (d = w1 - f); the older w of the sum (kinds W1W, FW)
+  double s, rs;              // the norm of d and its reciprocal (kinds FW1, W1W)
+  int rcp;                   // w1' = (1/s) * d (vector flavour) instead of d / s
+  int64_t n;
+  bool vec16;                // every base address allows 16-byte loads
+};
+// sum number b of a launch: set kChainNorm = the norm (b = 0) and, with `with_f`, the sums on f alone (b = 1..ub);
+// set kChainRows = <f,w1'> (b = 0), the Gram row on the rounded w1' (b = 1..ub) and, with `with_f`, the sums on f alone
+// (b = ub+1..2ub), s from red[0]; set kChainProbe = <f, probe> into red[2 + mvec] (diagnostic entry)
+__device__ __forceinline__ ChainSum chain_decode(const Ctl &ctl, const Vecs &vs, const double *f, int rcp, int set, int with_f,
+                                                 int ub, int b, const double *probe) {
+  ChainSum cs;
   const int pending = ctl.ic[IC_PLAN_PENDING];
   const int nolder = ctl.ic[IC_PLAN_NOLDER];
   const int mvec = ctl.mvec;
-  const int64_t n = vs.n;
   const long long *pw = ctl.plan_w();
-  double *red = ctl.red();
-  const double *w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f;
-  const double *wk = f;                               // the older w of this sum (kinds W1W, FW)
-  int kind, dst;
-  double s = 0.0;
+  cs.kind = -1; cs.dst = 0;
+  cs.f = f; cs.w1 = pending ? vs.w + ctl.pc[PC_FIRST_W] : f; cs.wk = f;
+  cs.s = 0.0; cs.rcp = rcp; cs.n = vs.n;
   if (set == kChainProbe) {
-    kind = kChainKindFW; dst = 2 + mvec; wk = probe;
+    cs.kind = kChainKindFW; cs.dst = 2 + mvec; cs.wk = probe;
   } else if (set == kChainNorm) {
     if (b == 0) {
-      if (!pending) return;
-      kind = kChainKindNorm; dst = 0;
+      if (pending) { cs.kind = kChainKindNorm; cs.dst = 0; }
     } else {
       const int p = b - 1;
-      if (!with_f || p >= nolder) return;
-      kind = kChainKindFW; dst = 2 + mvec + p; wk = vs.w + pw[p];
+      if (with_f && p < nolder) { cs.kind = kChainKindFW; cs.dst = 2 + mvec + p; cs.wk = vs.w + pw[p]; }
     }
   } else {
-    if (pending) s = sqrt(red[0]);                    // the GLOBAL sum d^2 (F08:267)
-    const bool normed = pending && s != 0.0;          // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
+    if (pending) cs.s = sqrt(ctl.red()[0]);           // the GLOBAL sum d^2 (F08:267)
+    const bool normed = pending && cs.s != 0.0;       // (s == 0: the scalar step relaxes, F08:268-275; the w1' sums are dead)
     if (b == 0) {
-      if (!normed) return;
-      kind = kChainKindFW1; dst = 1;
+      if (normed) { cs.kind = kChainKindFW1; cs.dst = 1; }
     } else if (b <= ub) {
       const int k = b - 1;
-      if (!normed || k >= nolder) return;
-      kind = kChainKindW1W; dst = 2 + k; wk = vs.w + pw[k];
+      if (normed && k < nolder) { cs.kind = kChainKindW1W; cs.dst = 2 + k; cs.wk = vs.w + pw[k]; }
     } else {
       const int p = b - 1 - ub;
-      if (!with_f || p >= nolder) return;
-      kind = kChainKindFW; dst = 2 + mvec + p; wk = vs.w + pw[p];
+      if (with_f && p < nolder) { cs.kind = kChainKindFW; cs.dst = 2 + mvec + p; cs.wk = vs.w + pw[p]; }
     }
   }
-  const double rs = 1.0 / s;
+  cs.rs = 1.0 / cs.s;
+  cs.vec16 = ((reinterpret_cast<uintptr_t>(cs.f) | reinterpret_cast<uintptr_t>(cs.w1) | reinterpret_cast<uintptr_t>(cs.wk)) & 15) == 0;
+  return cs;
+}
+// The operands of one block (1024 elements from e0 on) in a wavefront's registers: pair j*64 + lane of the block per load,
+// i.e. 1 KiB per wave instruction ...
+constexpr int kChainPairs = kChainLaneElems / 2;       // 16-byte loads per thread and vector
+static_assert(kChainPairs == 8, "the pair mapping of chain_load_block / chain_store_block assumes 16 elements per lane");
+struct ChainBlockRegs {
+  typename VecT<2>::type xf[kChainPairs], xw1[kChainPairs], xw[kChainPairs];
+};
+__device__ __forceinline__ void chain_load_block(const ChainSum &cs, ChainBlockRegs &r, int64_t e0, int lane, bool full) {
   using V2 = typename VecT<2>::type;
-  const int lane = t & 63;
-  const bool vec16 = ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(wk)) & 15) == 0;
-
-  // Wavefront w loads, multiplies and summarises block w of a group (elements [1024 w, 1024 w + 1024)): pair j*64 + lane
-  // of the block per load, i.e. 1 KiB per wave instruction; the pair lands in LDS where the lane that owns it reads it.
-  constexpr int kPairs = kChainLaneElems / 2;          // 16-byte loads per thread and vector
-  V2 xf[kPairs], xw1[kPairs], xw[kPairs];
-  auto ldpair = [&](const double *p, int64_t i, bool full) -> V2 {
+  const int64_t n = cs.n;
+  const bool vec16 = cs.vec16;
+  auto ldpair = [&](const double *p, int64_t i) -> V2 {
     V2 v;
     if (full && vec16) v = *reinterpret_cast<const V2 *>(p + i);
     else if (full) { v.x = p[i]; v.y = p[i + 1]; }
     else { v.x = i < n ? p[i] : 0.0; v.y = i + 1 < n ? p[i + 1] : 0.0; }
     return v;
   };
-  auto load = [&](int64_t g0) {
-    const bool full = g0 + kChainGroup <= n;
-    const int64_t i0 = g0 + wave * kChainBlock + 2 * lane;
-    if (kind == kChainKindFW) {
+  const int64_t i0 = e0 + 2 * lane;
+  if (cs.kind == kChainKindFW) {
 #pragma unroll
-      for (int j = 0; j < kPairs; j++) { xf[j] = ldpair(f, i0 + j * 128, full); xw[j] = ldpair(wk, i0 + j * 128, full); }
-    } else if (kind == kChainKindW1W) {
+    for (int j = 0; j < kChainPairs; j++) { r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw[j] = ldpair(cs.wk, i0 + j * 128); }
+  } else if (cs.kind == kChainKindW1W) {
 #pragma unroll
-      for (int j = 0; j < kPairs; j++) {
-        xf[j] = ldpair(f, i0 + j * 128, full); xw1[j] = ldpair(w1, i0 + j * 128, full); xw[j] = ldpair(wk, i0 + j * 128, full);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < kPairs; j++) { xf[j] = ldpair(f, i0 + j * 128, full); xw1[j] = ldpair(w1, i0 + j * 128, full); }
+    for (int j = 0; j < kChainPairs; j++) {
+      r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw1[j] = ldpair(cs.w1, i0 + j * 128); r.xw[j] = ldpair(cs.wk, i0 + j * 128);
     }
-  };
-  double *myblk = prod + wave * kChainBlockLds;
-  auto store = [&]() {
+  } else {
 #pragma unroll
-    for (int j = 0; j < kPairs; j++) {
-      V2 p;
-      if (kind == kChainKindFW) { p.x = xf[j].x * xw[j].x; p.y = xf[j].y * xw[j].y; }
+    for (int j = 0; j < kChainPairs; j++) { r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw1[j] = ldpair(cs.w1, i0 + j * 128); }
+  }
+}
+// ... and their rounded products where the lane that owns them reads them (blk: the block's kChainBlockLds doubles of LDS)
+__device__ __forceinline__ void chain_store_block(const ChainSum &cs, const ChainBlockRegs &r, double *blk, int lane) {
+#pragma clang fp contract(off)      // products and additions stay separate roundings whatever the build's flags
+  using V2 = typename VecT<2>::type;
+  const double s = cs.s, rs = cs.rs;
+#pragma unroll
+  for (int j = 0; j < kChainPairs; j++) {
+    V2 p;
+    if (cs.kind == kChainKindFW) { p.x = r.xf[j].x * r.xw[j].x; p.y = r.xf[j].y * r.xw[j].y; }
+    else {
+      const double d0 = r.xw1[j].x - r.xf[j].x, d1 = r.xw1[j].y - r.xf[j].y;   // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+      if (cs.kind == kChainKindNorm) { p.x = d0 * d0; p.y = d1 * d1; }
       else {
-        const double d0 = xw1[j].x - xf[j].x, d1 = xw1[j].y - xf[j].y;   // F08:266 ((-1)*f + w1 in F08V:237: same bits)
-        if (kind == kChainKindNorm) { p.x = d0 * d0; p.y = d1 * d1; }
-        else {
-          const double n0 = rcp ? rs * d0 : d0 / s, n1 = rcp ? rs * d1 : d1 / s;   // the value PB stores as w1' (F08:283; F08V:256)
-          if (kind == kChainKindFW1) { p.x = xf[j].x * n0; p.y = xf[j].y * n1; }
-          else { p.x = n0 * xw[j].x; p.y = n1 * xw[j].y; }
-        }
+        const double n0 = cs.rcp ? rs * d0 : d0 / s, n1 = cs.rcp ? rs * d1 : d1 / s;   // the value PB stores as w1' (F08:283; F08V:256)
+        if (cs.kind == kChainKindFW1) { p.x = r.xf[j].x * n0; p.y = r.xf[j].y * n1; }
+        else { p.x = n0 * r.xw[j].x; p.y = n1 * r.xw[j].y; }
       }
-      // pair j*64 + lane of the block = elements 2 (j*64 + lane), +1: lane (j*64 + lane) / 8 of the chain, pair row lane % 8
-      *reinterpret_cast<V2 *>(myblk + (lane % kPairs) * kChainRow + 2 * (j * (64 / kPairs) + lane / kPairs)) = p;
     }
-  };
-  static_assert(kPairs == 8, "the pair mapping of load / store assumes 16 elements per lane");
+    // pair j*64 + lane of the block = elements 2 (j*64 + lane), +1: lane (j*64 + lane) / 8 of the chain, pair row lane % 8
+    *reinterpret_cast<V2 *>(blk + (lane % kChainPairs) * kChainRow + 2 * (j * (64 / kChainPairs) + lane / kChainPairs)) = p;
+  }
+}
 
+static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_sums(Ctl ctl, Vecs vs,
+                                                                                              const double *__restrict__ f,
+                                                                                              int rcp, int set, int with_f, int ub,
+                                                                                              int walk, const double *probe) {
+  extern __shared__ __attribute__((aligned(16))) double prod[];   // kChainLdsBytes
+  __shared__ ChainSummary summ[kChainGroupBlocks];
+  __shared__ double sh_a;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const ChainSum cs = chain_decode(ctl, vs, f, rcp, set, with_f, ub, blockIdx.x, probe);
+  if (cs.kind < 0) return;
+  // wavefront w loads, multiplies and summarises block w of a group (elements [1024 w, 1024 w + 1024))
+  ChainBlockRegs regs;
+  double *myblk = prod + wave * kChainBlockLds;
+  auto load = [&](int64_t g0) { chain_load_block(cs, regs, g0 + wave * kChainBlock, lane, g0 + kChainGroup <= cs.n); };
+  auto store = [&]() { chain_store_block(cs, regs, myblk, lane); };
+  double *red = ctl.red();
   ChainStamps stamps;
-  const double a = chain_drive(red[dst], n, prod, summ, &sh_a, walk, stamps, load, store);
-  if (t == 0) red[dst] = a;
+  const double a = chain_drive(red[cs.dst], cs.n, prod, summ, &sh_a, walk, stamps, load, store);
+  if (t == 0) red[cs.dst] = a;
 #ifdef NKA_CHAIN_STAMPS
   if (t == 0 && set == kChainProbe)
     for (int i = 0; i < 8; i++) { ctl.stamps()[i] = (double)stamps.st[i]; ctl.stamps()[8 + i] = (double)stamps.cnt[i]; }
   // (10 ns ticks: load issue, summary, wait, apply, wait, store; then the block counts)
 #endif
+}
+
+// ---- The same sums, MANY compute units per sum (round 5, the longest vectors) ------------------------------------
+// k_chain_sums gives a sum one compute unit: its blocks are summarised eight at a time and the summaries applied in
+// between.  But a block's summary needs only the SIGN AND EXPONENT of the running sum at its start -- and those follow from
+// an ordinary blocked prefix sum (off by rounding noise, i.e. wrong only when the sum is within ~1e-13 of a power of two,
+// which the apply step notices).  So the summaries of ALL blocks of ALL sums are made by the whole device:
+//   k_chain_blocks(mode 0)   one wavefront per (block, sum): the block's products, summed any way -> pred[sum][block]
+//   k_chain_predict          per sum: exclusive prefix of those, from red[dst] -> the predicted running sum at each block
+//   k_chain_blocks(mode 1)   one wavefront per (block, sum): the summary under the predicted sign and exponent
+//   k_chain_apply            per sum, ONE wavefront: 64 summaries at a time -- one scalar parity chain, one prefix sum, each
+//                            block checked against the sum it would start from, the longest run of acceptable blocks goes
+//                            in at once; a block that does not is loaded, summarised again if the exponent was
+//                            mispredicted, else walked (chain_block_serial), and the run goes on behind it.
+// Same functions, same acceptance rule, same bits as k_chain_sums; what remains sequential is ~10 ns per accepted block and
+// the walk of the blocks that meet an end of their binade.
+static __global__ __launch_bounds__(kChainThreads) __attribute__((unused)) void k_chain_blocks(Ctl ctl, Vecs vs,
+                                                                                                const double *__restrict__ f,
+                                                                                                int rcp, int set, int with_f, int ub,
+                                                                                                int nsum, long long nfull,
+                                                                                                double *__restrict__ pred,
+                                                                                                ChainSummary *__restrict__ summ,
+                                                                                                int mode, const double *probe) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double prod[];   // kChainLdsBytes: one block per wavefront
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const long long item = (long long)blockIdx.x * kChainWaves + wave;      // (no barrier in this kernel: wavefronts are on their own)
+  if (item >= nfull * nsum) return;
+  const int b = (int)(item % nsum);                                        // the sums of one block side by side: f and w1 come from L2
+  const long long blk = item / nsum;
+  const ChainSum cs = chain_decode(ctl, vs, f, rcp, set, with_f, ub, b, probe);
+  if (cs.kind < 0) return;
+  ChainBlockRegs regs;
+  double *myblk = prod + wave * kChainBlockLds;
+  chain_load_block(cs, regs, blk * kChainBlock, lane, true);
+  chain_store_block(cs, regs, myblk, lane);
+  if (mode == 0) {
+    double pl[kChainLaneElems];
+    chain_lane_read(pl, myblk, lane);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < kChainLaneElems; j++) acc = acc + pl[j];
+    const double tot = wave_scan_add_f64(acc);
+    if (lane == 63) pred[(long long)b * nfull + blk] = tot;
+  } else {
+    const ChainSummary sm = chain_block_summary(pred[(long long)b * nfull + blk], myblk);
+    if (lane == 0) summ[(long long)b * nfull + blk] = sm;
+  }
+}
+
+constexpr int kChainPredictThreads = 256;
+static __global__ __launch_bounds__(kChainPredictThreads) __attribute__((unused)) void k_chain_predict(Ctl ctl, Vecs vs,
+                                                                                                        const double *f, int rcp,
+                                                                                                        int set, int with_f, int ub,
+                                                                                                        long long nfull,
+                                                                                                        double *__restrict__ pred,
+                                                                                                        const double *probe) {
+  __shared__ double seg_sum[kChainPredictThreads];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const ChainSum cs = chain_decode(ctl, vs, f, rcp, set, with_f, ub, b, probe);
+  if (cs.kind < 0) return;
+  double *p = pred + (long long)b * nfull;
+  const long long seg = (nfull + kChainPredictThreads - 1) / kChainPredictThreads;
+  const long long lo = t * seg, hi = lo + seg < nfull ? lo + seg : nfull;
+  double acc = 0.0;
+  for (long long i = lo; i < hi; i++) acc += p[i];
+  seg_sum[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double run = ctl.red()[cs.dst];                    // the sum the chain starts from
+    for (int i = 0; i < kChainPredictThreads; i++) { const double v = seg_sum[i]; seg_sum[i] = run; run += v; }
+  }
+  __syncthreads();
+  double run = seg_sum[t];
+  for (long long i = lo; i < hi; i++) { const double v = p[i]; p[i] = run; run += v; }
+}
+
+static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_apply(Ctl ctl, Vecs vs, const double *__restrict__ f,
+                                                                                  int rcp, int set, int with_f, int ub,
+                                                                                  long long nfull,
+                                                                                  const ChainSummary *__restrict__ summ, int walk,
+                                                                                  const double *probe) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) double blk_lds[kChainBlockLds];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const ChainSum cs = chain_decode(ctl, vs, f, rcp, set, with_f, ub, b, probe);
+  if (cs.kind < 0) return;
+  double *red = ctl.red();
+  double a = red[cs.dst];
+  ChainRun run;
+  chain_run_enter(run, a);
+  ChainBlockRegs regs, ahead;                          // the operands of the block in hand; of the block behind it (see below)
+  long long ahead_of = -1;                             // which block `ahead` holds
+  const ChainSummary *mysum = summ + (long long)b * nfull;
+  ChainSummary none;
+  none.hi = 0; none.total = 0.0; none.gmin = none.gmax = 0.f; none.adj = 0;
+  ChainSummary next = (lane < nfull && !walk) ? mysum[lane] : none;       // (the summaries of the batch after this one are in
+  for (long long k0 = 0; k0 < nfull; k0 += 64) {                          //  flight while this one is applied)
+    const int nb = (int)(nfull - k0 < 64 ? nfull - k0 : 64);
+    const ChainSummary mine = next;
+    next = (k0 + 64 + lane < nfull && !walk) ? mysum[k0 + 64 + lane] : none;
+    int k = 0;
+    bool try_run = true;                               // (right behind a block that did not go in, its successor is tried alone first)
+    while (k < nb) {
+      if (run.hi != 0 && !walk && !try_run) {
+        ChainSummary one;
+        one.total = readlane_f64(mine.total, k);
+        one.gmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.gmin), k));
+        one.gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.gmax), k));
+        one.adj = __builtin_amdgcn_readlane(mine.adj, k);
+        one.hi = __builtin_amdgcn_readlane(mine.hi, k);
+        if (chain_block_apply(run, one)) { k++; try_run = true; continue; }
+      }
+      if (run.hi != 0 && !walk && try_run) {
+        const bool cand = lane >= k && lane < nb;
+        const int ae = (mine.adj & 0xffff) - kChainAdjBias, ao = ((mine.adj >> 16) & 0xffff) - kChainAdjBias;
+        const bool usable = cand && mine.hi == run.hi;
+        // the parity each block starts from, if every block before it goes in (a scalar chain over two ballot masks)
+        const int tpar = __double2loint(fabs(mine.total) + 0x1p52) & 1;     // (|total| < 2^52 in any block that goes in)
+        const unsigned long long pe = __ballot(usable && ((tpar ^ ae) & 1)), po = __ballot(usable && ((tpar ^ ao) & 1));
+        unsigned long long odd = 0;
+        if ((pe | po) == 0) {                          // (no block changes the parity: everyone starts from the sum's)
+          odd = (__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1) ? ~0ull : 0ull;
+        } else {
+          unsigned long long p = (unsigned long long)(__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1);
+          for (int i = k; i < nb; i++) {
+            odd |= p << i;
+            p ^= ((p ? po : pe) >> i) & 1ull;
+          }
+        }
+        const double tk_ = usable ? mine.total + (double)(((odd >> lane) & 1ull) ? ao : ae) : 0.0;
+        const double incl = wave_scan_add_f64(tk_);
+        const double Sk = run.S + (incl - tk_);
+        constexpr double kEdge = 0x1p34;
+        const bool ok = usable && (Sk + (double)mine.gmin >= 0x1p52 + kEdge) && (Sk + (double)mine.gmax <= 0x1p53 - kEdge);
+        const unsigned long long need = (nb == 64 ? ~0ull : (1ull << nb) - 1ull) & ~((1ull << k) - 1ull);
+        const unsigned long long failm = need & ~__ballot(ok);
+        const int F = failm ? __ffsll((long long)failm) - 1 : nb;
+        if (F > k) {
+          run.S = run.S + readlane_f64(incl, F - 1);
+          k = F;
+          continue;
+        }
+      }
+      // block k0 + k on its own: its products into LDS; summarised under the sum's present exponent if the prediction
+      // missed it, else (or failing that) walked.  A sum that meets an end of its binade stays there for a while: the
+      // operands of the NEXT block are requested before this one is walked, so that its walk, if it comes to that, finds them.
+      const long long kb = k0 + k;
+      if (ahead_of == kb) regs = ahead;
+      else chain_load_block(cs, regs, kb * kChainBlock, lane, true);
+      if (kb + 1 < nfull) { chain_load_block(cs, ahead, (kb + 1) * kChainBlock, lane, true); ahead_of = kb + 1; }
+      chain_store_block(cs, regs, blk_lds, lane);
+      bool done = false;
+      const int hi_k = __builtin_amdgcn_readlane(mine.hi, k);
+      if (!walk && run.hi != 0 && run.hi != hi_k) {
+        const ChainSummary sm = chain_block_summary(run.S * run.unscale, blk_lds);
+        done = chain_block_apply(run, sm);
+      }
+      if (!done) {
+        if (run.hi != 0) a = run.S * run.unscale;
+        a = chain_block_serial(a, blk_lds, kChainBlock);
+        chain_run_enter(run, a);
+      }
+      k++;
+      try_run = false;
+    }
+  }
+  if (run.hi != 0) a = run.S * run.unscale;
+  const long long e0 = nfull * kChainBlock;
+  if (e0 < cs.n) {                                     // the last, partial block
+    chain_load_block(cs, regs, e0, lane, false);
+    chain_store_block(cs, regs, blk_lds, lane);
+    a = chain_block_serial(a, blk_lds, (int)(cs.n - e0));
+  }
+  if (lane == 0) red[cs.dst] = a;
 }
 
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------

@@ -429,14 +429,15 @@ class nka:  # noqa: N801  (the reference's type name)
         self._need_diag("set_tuning")
         _check(self._L.nka_hip_set_tuning(self._handle(), key.encode(), int(value)), "set_tuning", self._L)
 
-    def debug_chain_sum(self, x, y, start: float = 0.0, walk: bool = False):
+    def debug_chain_sum(self, x, y, start: float = 0.0, walk: bool = False, many: bool = False):
         """start + x[0]*y[0] + x[1]*y[1] + ... formed by the reference-order kernel of long vectors over two device
-        tensors (nka_hip_debug_chain_sum, include/nka_hip_diag.h).  Returns (sum, kernel milliseconds)."""
+        tensors (nka_hip_debug_chain_sum, include/nka_hip_diag.h); many: through the many-compute-unit kernels.  Returns
+        (sum, kernel milliseconds)."""
         self._need_diag("debug_chain_sum")
         assert x.dtype == y.dtype and x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
         out, ms = C.c_double(), C.c_float()
         _check(self._L.nka_hip_debug_chain_sum(self._handle(), x.data_ptr(), y.data_ptr(), x.numel(), float(start),
-                                               int(bool(walk)), C.byref(out), C.byref(ms)), "debug_chain_sum", self._L)
+                                               int(bool(walk)) | (2 if many else 0), C.byref(out), C.byref(ms)), "debug_chain_sum", self._L)
         return out.value, ms.value
 
     def device_info(self):

@@ -26,9 +26,10 @@ def bench():
         tx, ty = torch.from_numpy(np.ascontiguousarray(x)).cuda(), torch.from_numpy(np.ascontiguousarray(y)).cuda()
         fast, _ = acc.debug_chain_sum(tx, ty, start, walk=False)
         walk, _ = acc.debug_chain_sum(tx, ty, start, walk=True)
+        many = acc.debug_chain_sum(tx, ty, start, many=True)[0] if len(x) >= 1024 else fast   # (the whole-device form needs a full block)
         with np.errstate(all="ignore"):
             want = float(np.add.accumulate(np.concatenate([[start], x * y]))[-1]) if len(x) else float(start)
-        return fast, walk, want
+        return fast, walk, want, many
 
     return run
 
@@ -42,9 +43,10 @@ def same(a, b):
 
 
 def check(bench, x, y, start=0.0, what=""):
-    fast, walk, want = bench(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), float(start))
+    fast, walk, want, many = bench(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), float(start))
     assert same(walk, want), (what, "walk", walk.hex() if walk == walk else walk, want.hex() if want == want else want)
     assert same(fast, want), (what, "blocks", fast.hex() if fast == fast else fast, want.hex() if want == want else want)
+    assert same(many, want), (what, "whole device", many.hex() if many == many else many, want.hex() if want == want else want)
 
 
 LENGTHS = [0, 1, 7, 8, 9, 511, 512, 513, 1024, 2047, 2048, 2049, 4096 + 37, 10 * 2048, 100_003]

@@ -128,6 +128,43 @@ def test_reference_bits_from_a_buffer_that_is_not_16_byte_aligned(torch_cuda, or
         assert np.array_equal(view.cpu().numpy(), f), (n, m, t)
 
 
+@pytest.mark.parametrize("flavor", [0, 1])
+@pytest.mark.parametrize("n,m", [(1024, 3), (5000, 5), (70001, 20), (2 ** 19 + 3, 6)])
+def test_many_compute_units_per_sum_return_the_same_bits(torch_cuda, oracle, flavor, n, m):
+    """The longest vectors have the block summaries of every sum made by the whole device and applied by one wavefront per
+    sum (k_chain_blocks / k_chain_predict / k_chain_apply; automatic from 2^19 elements on): forced on (`chain_many` = 1) and
+    off (0) on the same sequence -- dependent and repeated inputs, relax, set_vec_tol, restart -- both return the oracle's
+    bits (= the compiled reference's) in every output."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(31 * n + m + flavor)
+    accs = []
+    for many in (1, 0):
+        a = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+        a.set_tuning("chain_many", many)
+        accs.append(a)
+    ora = oracle.OracleNKA(n, m, flavor)
+    basis = rng.standard_normal((3, n))
+    prev = rng.standard_normal(n)
+    for t in range(m + 12):
+        kind = t % 7
+        x = rng.standard_normal(3) @ basis if kind in (3, 5) else prev.copy() if kind == 6 else rng.standard_normal(n)
+        prev = x
+        f = x.copy()
+        ora.accel_update(f)
+        for a in accs:
+            assert np.array_equal(_update(torch, a, x), f), (n, m, flavor, t)
+        if t == 9:
+            for a in accs:
+                a.relax()
+            ora.relax()
+        if t == m + 6:
+            for a in accs:
+                a.restart()
+            ora.restart()
+    assert all(a.defined() for a in accs)
+
+
 def test_medium_fixture_of_the_compiled_f08_reference_bit_for_bit(torch_cuda):
     """n = 1e5, m = 10, 25 calls: the sampled entries of the compiled src-F08 reference's outputs
     (tests/golden/medium_n100000_m10.npz) -- equal, not close.  (The fixture's norm and probe functional were formed by
