@@ -1502,6 +1502,12 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
   const ChainSummary *mysum = summ + (long long)b * nfull;
   ChainSummary none;
   none.hi = 0; none.total = 0.0; none.gmin = none.gmax = 0.f; none.adj = 0;
+#ifdef NKA_CHAIN_STAMPS
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tw = 0, t0_;   // blocks: in runs / singly / summarised again / walked
+#define NKA_APPLY_COUNT(i, v) cnt[i] += (v);
+#else
+#define NKA_APPLY_COUNT(i, v)
+#endif
   ChainSummary next = (lane < nfull && !walk) ? mysum[lane] : none;       // (the summaries of the batch after this one are in
   for (long long k0 = 0; k0 < nfull; k0 += 64) {                          //  flight while this one is applied)
     const int nb = (int)(nfull - k0 < 64 ? nfull - k0 : 64);
@@ -1517,7 +1523,7 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
         one.gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.gmax), k));
         one.adj = __builtin_amdgcn_readlane(mine.adj, k);
         one.hi = __builtin_amdgcn_readlane(mine.hi, k);
-        if (chain_block_apply(run, one)) { k++; try_run = true; continue; }
+        if (chain_block_apply(run, one)) { k++; try_run = true; NKA_APPLY_COUNT(1, 1) continue; }
       }
       if (run.hi != 0 && !walk && try_run) {
         const bool cand = lane >= k && lane < nb;
@@ -1527,8 +1533,10 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
         const int tpar = __double2loint(fabs(mine.total) + 0x1p52) & 1;     // (|total| < 2^52 in any block that goes in)
         const unsigned long long pe = __ballot(usable && ((tpar ^ ae) & 1)), po = __ballot(usable && ((tpar ^ ao) & 1));
         unsigned long long odd = 0;
-        if ((pe | po) == 0) {                          // (no block changes the parity: everyone starts from the sum's)
-          odd = (__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1) ? ~0ull : 0ull;
+        if (pe == po) {                                // (no block's flip depends on the parity it meets: a prefix XOR)
+          unsigned long long x = pe;
+          x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+          odd = ((__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1) ? ~0ull : 0ull) ^ (x << 1);
         } else {
           unsigned long long p = (unsigned long long)(__builtin_amdgcn_readfirstlane(__double2loint(run.S)) & 1);
           for (int i = k; i < nb; i++) {
@@ -1546,6 +1554,7 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
         const int F = failm ? __ffsll((long long)failm) - 1 : nb;
         if (F > k) {
           run.S = run.S + readlane_f64(incl, F - 1);
+          NKA_APPLY_COUNT(0, F - k)
           k = F;
           continue;
         }
@@ -1563,11 +1572,19 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
       if (!walk && run.hi != 0 && run.hi != hi_k) {
         const ChainSummary sm = chain_block_summary(run.S * run.unscale, blk_lds);
         done = chain_block_apply(run, sm);
+        if (done) { NKA_APPLY_COUNT(2, 1) }
       }
       if (!done) {
+        NKA_APPLY_COUNT(3, 1)
+#ifdef NKA_CHAIN_STAMPS
+        t0_ = wall_clock64();
+#endif
         if (run.hi != 0) a = run.S * run.unscale;
         a = chain_block_serial(a, blk_lds, kChainBlock);
         chain_run_enter(run, a);
+#ifdef NKA_CHAIN_STAMPS
+        tw += wall_clock64() - t0_;
+#endif
       }
       k++;
       try_run = false;
@@ -1581,6 +1598,13 @@ static __global__ __launch_bounds__(64) __attribute__((unused)) void k_chain_app
     a = chain_block_serial(a, blk_lds, (int)(cs.n - e0));
   }
   if (lane == 0) red[cs.dst] = a;
+#ifdef NKA_CHAIN_STAMPS
+  if (lane == 0 && set == kChainProbe) {
+    for (int i = 0; i < 8; i++) ctl.stamps()[8 + i] = (double)cnt[i];
+    ctl.stamps()[3] = (double)tw;                       // (10 ns ticks spent walking)
+  }
+#endif
+#undef NKA_APPLY_COUNT
 }
 
 // ---- PB: normalise the pending pair, combine, and all five stores -----------------

@@ -21,18 +21,22 @@ for n in sizes:
     g.manual_seed(1)
     x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
-    for walk in (False, True):
+    for walk, many in ((False, False), (False, True), (True, False)):
         if walk and n > 10**7:
             continue
         for what, (a, b) in (("signed", (x, y)), ("squares", (x, x))):
-            acc.debug_chain_sum(a, b, 0.0, walk)
-            s, ms = acc.debug_chain_sum(a, b, 0.0, walk)
-            line = f"n={n:>10d} {what:8s} walk={int(walk)} {ms:10.3f} ms  {1e6 * ms / n:7.3f} ns/element  sum={s!r}"
+            acc.debug_chain_sum(a, b, 0.0, walk, many)
+            s, ms = acc.debug_chain_sum(a, b, 0.0, walk, many)
+            line = f"n={n:>10d} {what:8s} walk={int(walk)} many={int(many)} {ms:10.3f} ms  {1e6 * ms / n:7.3f} ns/element  sum={s!r}"
             if stamps:
                 out = (C.c_double * 16)()
                 acc._L.nka_hip_get_stamps(acc._handle(), out)
                 names = ("load", "summary", "wait", "apply", "wait", "store", "wait")
-                line += "  phases us: " + " ".join(f"{nm}={out[i] * 0.01:.0f}" for i, nm in enumerate(names))
-                cn = ("blocks in runs", "on their own", "summarised again", "walked")
+                if many:
+                    line += f"  walking us: {out[3] * 0.01:.0f}"
+                else:
+                    line += "  phases us: " + " ".join(f"{nm}={out[i] * 0.01:.0f}" for i, nm in enumerate(names))
+                cn = ("blocks in runs", "singly", "summarised again", "walked") if many else \
+                    ("blocks in runs", "on their own", "summarised again", "walked")
                 line += "\n      " + ", ".join(f"{nm} {int(out[8 + i])}" for i, nm in enumerate(cn))
             print(line, flush=True)
