@@ -202,9 +202,12 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
  *       does) at ANY n: a validation mode for callers moving over from the reference.  Cost: two chains of n dependent
  *       roundings per update -- on par with the fast passes up to n = 64, +12-18 us at n = 512; beyond one chunk (~ 700
- *       elements at mvec = 20) every sum has a compute unit to itself and goes through its chain 1024 products at a time
- *       wherever that is provably the element-after-element result (k_chain_sums): 0.16 ms at n = 1e4, 6 ms at n = 1e6,
- *       0.27-0.29 s at n = 1e8, mvec = 20 -- 10-13 x the compiled reference on its core, every output torch.equal to it in
+ *       elements at mvec = 20) the sums go through their chains 1024 products at a time wherever that is provably the
+ *       element-after-element result -- one compute unit per sum (k_chain_sums), from 2^19 elements on the block summaries of
+ *       every sum by the whole device and one wavefront per sum to apply them (k_chain_blocks / k_chain_apply; 25 bytes of
+ *       scratch per block and sum, allocated at the first such update): 0.16 ms at n = 1e4, 6 ms at n = 1e6, 0.16 s at
+ *       n = 1e8, mvec = 20 on uniform random vectors (0.02 s on correlated ones) -- 19 x the compiled reference on its
+ *       core, every output torch.equal to it in
  *       the same bench run (profiles/r05/reference_order_chain.txt).  SHARDED (an all-reduce installed): the reference's sum over
  *       the global vector is one chain of additions through the slices in rank order, so the ranks take turns -- rank r
  *       continues the running sums of ranks 0..r-1, the others contribute zeros, and the installed hook (any hook that

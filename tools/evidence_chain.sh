@@ -17,5 +17,10 @@ cd "$ROOT"
   timeout -k 10 300 python tools/sum_order_cost.py 2>&1 | grep -v amdgpu.ids
   timeout -k 10 300 python tools/sum_order_cost.py 1e7 20 8 2>&1 | grep -v amdgpu.ids | tail -1
   timeout -k 10 300 python tools/sum_order_cost.py 1e8 20 4 2>&1 | grep -v amdgpu.ids | tail -1
+  echo
+  echo "# 4. the same with CORRELATED inputs (every input in the span of 12 fixed vectors: the inner products are sums that drift"
+  echo "#    instead of zero-mean random walks, so hardly a block meets an end of its binade; a dependence drop per update)"
+  timeout -k 10 300 python tools/sum_order_cost.py 1e7 20 8 12 2>&1 | grep -v amdgpu.ids | tail -2
+  timeout -k 10 300 python tools/sum_order_cost.py 1e8 20 4 12 2>&1 | grep -v amdgpu.ids | tail -1
 } > "$OUT" 2>&1
 tail -50 "$OUT"
