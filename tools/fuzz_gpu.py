@@ -93,7 +93,11 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
             (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER, nka_amd.SUMS_BLOCKED_ROUNDED)[seed % 4]
     same_bits = not hostdot and (sums == nka_amd.SUMS_REFERENCE_ORDER or (sums == nka_amd.SUMS_AUTO and n <= 64))
     key = f"fuzz{' hostdot' if hostdot else ''} seed {seed} n={n} m={m} flavor {flavor}" + ("" if hostdot else f" sums {names[sums]}")
-    acc = nka_amd.nka().init(n, m, flavor=flavor).set_sum_order(sums)
+    if os.environ.get("NKA_FUZZ_CHAIN_MANY") == "1":      # (reference-order sums through the whole-device kernels wherever a vector has a
+        acc = nka_amd.nka(diagnostic=True).init(n, m, flavor=flavor).set_sum_order(sums)   # full block: automatic only from 2^19 elements on)
+        acc.set_tuning("chain_many", 1)
+    else:
+        acc = nka_amd.nka().init(n, m, flavor=flavor).set_sum_order(sums)
     ora = oracle.OracleNKA(n, m, flavor)
     spread = P.Spread(oracle, n, m)
     calls = [0, 0]
