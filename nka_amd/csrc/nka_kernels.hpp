@@ -1029,7 +1029,8 @@ __device__ __forceinline__ double wave_scan_add_f64(double x) {
 // (halfway cases under both parities, binade crossings, cancellation, zeros, subnormals, overflow, NaN).
 // what one lane makes of its 16 consecutive products under the scale of the sum's binade
 struct ChainLane {
-  double base, absl;         // sum of the r's; sum of their magnitudes (bounds every prefix inside the lane)
+  double base, absl;         // sum of the r's; sum of their magnitudes (< 2^51: every r and every partial sum exact)
+  double pmin, pmax;         // least / greatest prefix sum inside the lane, the empty one (0) included
   int par, differ;           // parity of the lane's sum if it starts even; whether starting odd still flips it (no halfway case met)
   int adj0, adj1;            // corrections the halfway cases owe if the lane starts even / odd
 };
@@ -1037,7 +1038,7 @@ __device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLa
 #pragma clang fp contract(off)
   constexpr double M = 6755399441055744.0;                         // 1.5 * 2^52
   ChainLane ln;
-  ln.base = ln.absl = 0.0;
+  ln.base = ln.absl = ln.pmin = ln.pmax = 0.0;
   ln.differ = 1; ln.adj0 = ln.adj1 = 0;
   int parw = 0;
   bool halfway = false;
@@ -1051,6 +1052,8 @@ __device__ __forceinline__ ChainLane chain_lane_pass(const double (&pl)[kChainLa
     parw ^= __double2loint(tm);
     ln.base = ln.base + r;
     ln.absl = ln.absl + fabs(r);
+    ln.pmin = fmin(ln.pmin, ln.base);
+    ln.pmax = fmax(ln.pmax, ln.base);
   }
   if (__any(halfway)) {                                            // the parity bookkeeping in its own pass
     parw = 0;
@@ -1110,11 +1113,11 @@ __device__ __forceinline__ ChainSummary chain_block_summary(double a, const doub
   chain_lane_read(pl, blk, lane);
   const ChainLane ln = chain_lane_pass(pl, scale);
   const bool bad = !(ln.absl < 0x1p51);                            // some |t| >= 2^51 / Inf / NaN: r = rne(t) and the lane's sums are exact below that
-  // where the lane's excursion lies: the prefix before it +- its own absolute sum, in single precision
-  const float basef = (float)ln.base, abslf = (float)ln.absl;
+  // where the lane's excursion lies: the prefix before it + its own least / greatest prefix, in single precision
+  const float basef = (float)ln.base;
   const float exclf = wave_scan_f32<0>(basef, 0.f) - basef;
-  const float lo = wave_scan_f32<1>(exclf - abslf, __builtin_inff());
-  const float up = wave_scan_f32<2>(exclf + abslf, -__builtin_inff());
+  const float lo = wave_scan_f32<1>(exclf + (float)ln.pmin, __builtin_inff());
+  const float up = wave_scan_f32<2>(exclf + (float)ln.pmax, -__builtin_inff());
   int q;
   bool flips;
   chain_lane_parity(ln, lane, q, flips);
