@@ -176,3 +176,17 @@ def test_cpu_baseline_hands_every_output_to_the_twin(bench):
     # (and the outputs are the accelerated ones, not the inputs: once the subspace is there they differ from the generator's vectors)
     from nka_amd import synth
     assert not np.array_equal(seen[-1][2], synth.fill_numpy(bench.SEED, seen[-1][0], 0, 200, 200))
+
+
+def test_a_rank_group_launch_that_finds_its_port_taken_is_repeated_with_another():
+    """tests/launch_util.py: between probing a free port and the launcher's bind another process can take it (seen on a GPU
+    box: EADDRINUSE in the static rendezvous failed a test that had nothing to do with ports)."""
+    import sys
+    from launch_util import run_ranks
+    script = ("import sys; p = sys.argv[sys.argv.index('--master-port') + 1]; "
+              "sys.exit(0) if p != '1234' else (sys.stderr.write('... code: -98, name: EADDRINUSE, message: address already in use'), sys.exit(1))")
+    p = run_ranks([sys.executable, "-c", script, "--master-port", "1234"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0
+    other = run_ranks([sys.executable, "-c", "import sys; sys.stderr.write('boom'); sys.exit(3)", "--master-port", "1234"],
+                      capture_output=True, text=True, timeout=60)
+    assert other.returncode == 3 and other.stderr == "boom"        # (any other failure comes back as it is, once)

@@ -15,6 +15,8 @@ import os
 import numpy as np
 import pytest
 
+from launch_util import run_ranks  # noqa: E402
+
 import parity_util as P
 import scenarios as S
 
@@ -421,7 +423,7 @@ def test_bench_multi_gpu_plumbing_rehearsal_single_rank(torch_cuda, hook):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--vlen", "2e6",
            "--mvec", "6", "--steps", "5", "--no-cpu-baseline", "--allreduce", hook]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
@@ -516,7 +518,7 @@ def test_sharded_hip_path_two_ranks_one_gpu(torch_cuda):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_sharded_gpu_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-5000:]
     assert p.stdout.count(" OK") == 2
 

@@ -5,6 +5,8 @@ import math
 import os
 import socket
 import subprocess
+
+from launch_util import run_ranks  # noqa: E402
 import sys
 
 import numpy as np
@@ -241,7 +243,7 @@ def test_two_gpu_rccl_sharded_run(torch_cuda):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NKA_TEST_RCCL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_gpu_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-5000:]
     assert p.stdout.count(" OK") == 2
     assert "hook=rccl" in p.stdout
@@ -256,7 +258,7 @@ def test_bench_two_gpus(torch_cuda):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--vlen",
            "4e6", "--mvec", "6", "--steps", "5"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["steady_state"]
@@ -276,7 +278,7 @@ def test_bench_multi_rank_logic_rehearsed_with_ranks_sharing_the_gpu(torch_cuda,
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--vlen",
            "3000001", "--mvec", "6", "--steps", "6", "--backend", "gloo", "--allreduce", "staged", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == world and d["config"]["steady_state"] and d["scaling"] == "strong"
@@ -301,7 +303,7 @@ def test_bench_plain_form_launches_its_own_ranks(torch_cuda):
     env.update(NKA_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allreduce", "staged",
            "--vlen", "3000001", "--mvec", "6", "--steps", "6", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                                      # stdout carries the one JSON line and nothing else
@@ -326,7 +328,7 @@ def test_bench_plain_form_falls_back_to_the_staged_hook_when_rccl_cannot_work(to
     env.update(NKA_BENCH_SHARE_GPU="1", NKA_BENCH_WATCHDOG_S="90")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--vlen", "2000001", "--mvec", "5", "--steps", "5",
            "--no-cpu-baseline", "--launch-timeout", "150"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["steady_state"]

@@ -4,6 +4,8 @@ here with 2, 3 and 4 processes sharing the box's one GPU (hipIpc between process
 import os
 import socket
 import subprocess
+
+from launch_util import run_ranks  # noqa: E402
 import sys
 
 import pytest
@@ -23,12 +25,12 @@ def test_peer_to_peer_exchange_equals_the_rank_ordered_staged_hook_bit_for_bit(w
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_p2p_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=600)
     if p.returncode != 0:
         # one more attempt, LOUDLY (see tests/test_soak_regressions_gpu.py): several processes that rendezvous over a local port
         # and share one GPU can fail for reasons outside the library; a defect of the exchange fails twice
         print("FIRST ATTEMPT FAILED (rc %d); its last words:\n%s" % (p.returncode, p.stdout[-1500:] + p.stderr[-3000:]), flush=True)
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
     assert p.stdout.count("p2p OK") == world
 
@@ -41,7 +43,7 @@ def test_bench_rehearsal_with_the_peer_to_peer_exchange():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--vlen", "3000001", "--mvec", "6",
            "--steps", "6", "--backend", "gloo", "--allreduce", "p2p", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["steady_state"] and "all-reduce=p2p" in d["config"]["parallelism"]

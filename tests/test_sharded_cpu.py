@@ -4,6 +4,8 @@ the 8-GPU RCCL run is the driver's."""
 import os
 import socket
 import subprocess
+
+from launch_util import run_ranks  # noqa: E402
 import sys
 
 import pytest
@@ -41,7 +43,7 @@ def test_sharded_contract_world_size_n_gloo(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_sharded_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert p.stdout.count(" OK") == world
 

@@ -9,6 +9,8 @@ the global error norm are executed for real; only the transport differs."""
 import os
 import socket
 import subprocess
+
+from launch_util import run_ranks  # noqa: E402
 import sys
 
 import pytest
@@ -29,7 +31,7 @@ def _run(world, env_extra, timeout, worker=WORKER):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), worker]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    p = run_ranks(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
     assert p.stdout.count(" OK") == world, p.stdout[-3000:]
     return p.stdout
