@@ -455,6 +455,20 @@ def _free_port():
 
 
 def run_rank_group(nproc, script, script_args, timeout_s, env=None):
+    """One attempt (run_rank_group_once) -- repeated, at once and at most twice, if the launcher found the port it was given
+    taken (EADDRINUSE in the static rendezvous: the port is probed by binding port 0 and released again before the launcher
+    binds it; another process of the box can get in between).  That is no failure of the communication path and must not
+    push the run onto the staged fallback."""
+    t0 = time.perf_counter()
+    for attempt in range(3):
+        rc, line, err, timed_out = run_rank_group_once(nproc, script, script_args, max(30, timeout_s - (time.perf_counter() - t0)), env)
+        if line is not None or timed_out or rc == 0 or "EADDRINUSE" not in err or attempt == 2:
+            return rc, line, err, timed_out
+        sys.stderr.write("[bench] the rendezvous port was taken between the probe and the launcher's bind: launching again\n")
+    return rc, line, err, timed_out
+
+
+def run_rank_group_once(nproc, script, script_args, timeout_s, env=None):
     """ONE attempt: `python -m torch.distributed.run --nproc-per-node nproc script args` as a child in a process group
     of its own (start_new_session; a subprocess, never an exec: this process has touched no GPU and stays alive to
     supervise).  stdout is read line by line (the last line that parses as a JSON object is the result), stderr is
