@@ -205,8 +205,8 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
  *       elements at mvec = 20) the sums go through their chains 1024 products at a time wherever that is provably the
  *       element-after-element result -- one compute unit per sum (k_chain_sums), from 2^19 elements on the block summaries of
  *       every sum by the whole device and one wavefront per sum to apply them (k_chain_blocks / k_chain_apply; 25 bytes of
- *       scratch per block and sum, allocated at the first such update): 0.16 ms at n = 1e4, 6 ms at n = 1e6, 0.16 s at
- *       n = 1e8, mvec = 20 on uniform random vectors (0.02 s on correlated ones) -- 19 x the compiled reference on its
+ *       scratch per block and sum, allocated at the first such update): 0.16 ms at n = 1e4, 5 ms at n = 1e6, 0.13 s at
+ *       n = 1e8, mvec = 20 on uniform random vectors (0.02 s on correlated ones) -- 22 x the compiled reference on its
  *       core, every output torch.equal to it in
  *       the same bench run (profiles/r05/reference_order_chain.txt).  SHARDED (an all-reduce installed): the reference's sum over
  *       the global vector is one chain of additions through the slices in rank order, so the ranks take turns -- rank r
