@@ -40,7 +40,7 @@ extern "C" {
  * "chain_many" = -1/0/1: reference-order sums of the longest vectors by the whole device (k_chain_blocks / _predict / _apply): -1 automatic
  * (from 2^19 elements on), 0 never (one compute unit per sum: k_chain_sums), 1 wherever a vector has a full block.  Same bits.
  * "chain_walk" = 0/1: reference-order sums of long vectors (k_chain_sums) walk every block element after element instead of
- * taking whole blocks through the chain in integer arithmetic (chain_block_fast).  Same bits. */
+ * taking whole blocks through the chain in integer arithmetic (chain_block_summary / chain_block_apply).  Same bits. */
 int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value);
 
 /* Launch geometry knobs for tuning: blocks per CU of PA and PB (0 = automatic). */

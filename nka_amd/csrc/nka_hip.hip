@@ -229,7 +229,7 @@ struct nka_hip_state {
   void *chain_summ = nullptr;     // sum / the predicted running sum, and the block's summary; allocated at the first such update
   long long chain_cap = 0;        // (sums x blocks the two arrays hold)
   int chain_many = -1;            // diagnostic switch "chain_many": -1 automatic (from kChainManyMin elements on), 0 never, 1 whenever blocks exist
-  int chain_walk = 0;         // diagnostic switch "chain_walk": k_chain_sums walks every block element after element (A/B of chain_block_fast)
+  int chain_walk = 0;         // diagnostic switch "chain_walk": k_chain_sums walks every block element after element (A/B of chain_block_summary / _apply)
   int pb_reverse = 0;         // diagnostic switch "pb_reverse": the rolling-window PB walks its tiles from the end (kPbReverse)
   int fail_after_solve = 0;   // diagnostic switch "fail_after_solve": the next update fails as if a HIP call behind its scalar step had
                               // (the test of the poisoned-handle path: the failure itself cannot be provoked from outside)
@@ -2036,7 +2036,7 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
 // handle's stream, timed with HIP events (mean ms per repetition).  PA only writes
 // scratch (partials, red[]), so the state is unchanged.
 // start + x[0]*y[0] + x[1]*y[1] + ... as the per-sum reference-order kernel forms it (k_chain_sums on one workgroup),
-// over ANY two device arrays: the test bench of chain_block_fast (walk = 1: every block element after element).
+// over ANY two device arrays: the test bench of chain_block_summary / _apply (walk = 1: every block element after element).
 int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64_t n, double start, int32_t walk, double *sum,
                             float *ms) {
   if (!a || !sum || n < 0 || (n > 0 && (!x || !y))) return fail(NKA_HIP_EINVAL, "bad argument");
@@ -2125,7 +2125,7 @@ int nka_hip_set_tuning(nka_hip_t a, const char *key, int32_t value) {
   } else if (k == "chain_many") {     // -1 automatic, 0: one compute unit per reference-order sum at every length, 1: many wherever blocks exist
     if (value < -1 || value > 1) return fail(NKA_HIP_EINVAL, "chain_many: -1, 0, 1");
     a->chain_many = value;
-  } else if (k == "chain_walk") {     // 1: the per-sum reference-order kernel walks every block (no chain_block_fast): same bits, for A/B
+  } else if (k == "chain_walk") {     // 1: the per-sum reference-order kernel walks every block (no summaries): same bits, for A/B
     a->chain_walk = value != 0;
   } else if (k == "pb_reverse") {     // 1: the rolling-window PB walks its tiles in the reverse of PA's order (round-5 A/B)
     a->pb_reverse = value != 0;

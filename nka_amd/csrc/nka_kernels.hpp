@@ -899,11 +899,11 @@ static __global__ __launch_bounds__(kOrdThreads) __attribute__((unused)) void k_
 // ---- The same sums, ONE WORKGROUP PER SUM (round 5, long vectors) ----------------------------------
 // k_dots_ordered walks every sum on one compute unit and waits for each chunk's loads before it adds: 40 ns per element.
 // A sequential sum is a chain of n dependent roundings whatever is done, but (1) the 2 + 2L sums of an update are
-// independent chains once the norm is known, (2) the products are not part of any chain and (3) -- see chain_block_fast --
+// independent chains once the norm is known, (2) the products are not part of any chain and (3) -- see chain_block_summary --
 // while the running sum stays inside one binade its roundings are roundings to a FIXED grid, which is integer
-// arithmetic and therefore associative.  Here sum c has workgroup c to itself: all 256 threads load the next group of
-// elements and round the products into LDS while wavefront 0 takes the previous group through the chain, 512 elements
-// per step.  Two launches per update: set kChainNorm = the norm (block 0) and, with `with_f`, the sums on f alone (blocks
+// arithmetic and therefore associative.  Here sum c has workgroup c to itself: its eight wavefronts load the next group of
+// 8 192 elements, round the products into LDS and summarise one block of 1 024 each, and wavefront 0 takes the group
+// through the chain.  Two launches per update: set kChainNorm = the norm (block 0) and, with `with_f`, the sums on f alone (blocks
 // 1..ub); set kChainRows = with s from red[0], <f,w1'> (block 0), the Gram row on the ROUNDED w1' (blocks 1..ub) and,
 // with `with_f`, the sums on f alone (blocks ub+1..2ub) -- the sharded rounds of ordered_chain take the second form (their
 // norm rounds hold red[0] only).  EVERY chain starts from the value red[] holds: the host zeroes red[] where no prefix of
