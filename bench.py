@@ -950,7 +950,30 @@ def main(argv=None):
             e3, mean3, nv3, nv3_end, _, stats3 = measure(a3, "drops")
             fl3 = FLAVOR_NAMES[a3.flavor()]
             lb = a3.list_bound()
-            return {"workload": f"every input in a {D}-dimensional span: one dependence drop per update, num_vec = {nv3} "
+            # ... and the same accelerator in the BIT-IDENTICAL mode on these correlated inputs (sums that drift: hardly a
+            # block of a sum meets an end of its binade), beside the full workload's figure on uniform random vectors
+            # (cpu_baseline.device_reference_order, where the outputs are compared with the compiled reference's)
+            try:
+                a3.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
+                t_in, R = W_all + K, 4
+                for s_ in range(2):                                   # (the first such update allocates the block arrays)
+                    fill(0, t_in, "drops")
+                    a3.accel_update(pool[0])
+                    t_in += 1
+                for s_ in range(R):
+                    fill(s_ % P, t_in + s_, "drops")
+                torch.cuda.synchronize(dev)
+                t_ref = time.perf_counter()
+                for s_ in range(R):
+                    a3.accel_update(pool[s_ % P])
+                    torch.cuda.synchronize(dev)
+                dt_ref = (time.perf_counter() - t_ref) / R
+                ref3 = {"mode": "nka_hip_set_sum_order(NKA_HIP_SUMS_REFERENCE_ORDER) on the same inputs", "value": 1.0 / dt_ref,
+                        "unit": "updates/s", "ms_per_step": 1e3 * dt_ref, "num_vec": a3.num_vec(), "updates_timed": R}
+            except Exception as exc:                                  # an extra, never the measured path
+                ref3 = {"value": None, "error": repr(exc)}
+            return {"reference_order": ref3,
+                    "workload": f"every input in a {D}-dimensional span: one dependence drop per update, num_vec = {nv3} "
                                 f"of mvec = {m}; torch.cuda.synchronize() after every update (inside the timed region)",
                     "flavor": FLAVOR_TEXT[fl3], "value": K / e3, "unit": "updates/s", "ms_per_step": 1e3 * e3 / K,
                     "mean_k": float(nv3 + nv3_end) / 2.0, "steady_state": bool(nv3 == D and nv3_end == D),
@@ -1194,6 +1217,8 @@ def main(argv=None):
                 out["roofline"].update(flat)
             if rounded is not None and rounded.get("value"):
                 out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]
+            if drops is not None and (drops.get("reference_order") or {}).get("value"):
+                out["roofline"]["reference_order_with_drops_updates_per_s"] = drops["reference_order"]["value"]
             dro = (out.get("cpu_baseline") or {}).get("device_reference_order")
             if dro and dro.get("value"):                        # (flat, like the others)
                 out["roofline"]["reference_order_updates_per_s"] = dro["value"]
