@@ -1311,11 +1311,16 @@ static int ordered_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
       // every chain continues from what red[] holds: the prefix of the ranks before this one, or zeros on the first rank
       // (the norm rounds exchange red[0] alone; the rows rounds everything behind it)
       if (r == 0) HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)cnt, s));
-      if (phase == kOrdNorm)
+      if (chain_many_ready(a, 1 + 2 * a->mvec)) {        // (the longest slices: the whole device summarises, one wavefront per sum applies)
+        if (int rc = phase == kOrdNorm ? chain_many_stage(a, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, 1)
+                                       : chain_many_stage(a, f, mode & kSolveRcp, (int)kChainRows, 1, older_ub, 1 + 2 * older_ub))
+          return rc;
+      } else if (phase == kOrdNorm) {
         hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
-      else
+      } else {
         hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
                            (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
+      }
       HIP_TRY(hipGetLastError());
     } else if (r == me) {
       hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,

@@ -38,7 +38,10 @@ def main():
 
     def make(n, m, flavor):
         lo, hi = nd.slice_bounds(n, world, rank)
-        acc = nka_amd.nka().init(hi - lo, m, flavor=flavor, device=local)
+        many = os.environ.get("NKA_TEST_CHAIN_MANY") == "1"          # the whole-device form of the sums wherever a slice has a full block
+        acc = nka_amd.nka(diagnostic=many).init(hi - lo, m, flavor=flavor, device=local)
+        if many:
+            acc.set_tuning("chain_many", 1)
         nd.attach_allreduce(acc, rank, world, prefer=ladder[0], ladder=ladder)      # (tells the handle its slice: set_shard)
         acc.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
         return acc, lo, hi

@@ -75,6 +75,14 @@ def test_sharded_reference_order_sums_return_the_single_rank_reference_bits(worl
     assert "every bit equal" in out, out[-2000:]
 
 
+def test_sharded_reference_order_sums_with_the_whole_device_form_of_the_longest_slices():
+    """The same with every rank taking its slice through k_chain_blocks / k_chain_predict / k_chain_apply (automatic from 2^19
+    elements per slice on; forced here wherever a slice has a full block of 1 024): each rank's sums START from the prefix
+    the ranks before it left in red[], exactly as in the one-compute-unit form."""
+    out = _run(3, {"NKA_NGPU_MODE": "share", "NKA_TEST_CHAIN_MANY": "1"}, 900, worker=REFORDER_WORKER)
+    assert "every bit equal" in out, out[-2000:]
+
+
 def test_sharded_reference_order_sums_over_rccl():
     """The same through the library's own RCCL communicator, one GPU per rank (skips on the one-GPU boxes)."""
     import torch
