@@ -328,6 +328,15 @@ int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
 int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64);
 int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank);
 int nka_hip_p2p_detach(nka_hip_t a);
+/* The same exchange between several handles of ONE process (one per slice, each on its own stream, driven by host threads):
+ * after nka_hip_p2p_export on every handle, nka_hip_p2p_mailbox returns the device address of a handle's mailbox and
+ * nka_hip_p2p_attach_local takes the nranks addresses in rank order (entry `rank` must be the handle's own).  Nothing is
+ * mapped, so detach frees only the handle's own mailbox: synchronise every handle before the first detach.  The scalar
+ * step of a slice WAITS on the device for the sums of the others: every handle's stream must own a hardware queue
+ * (GPU_MAX_HW_QUEUES >= nranks in the environment before HIP starts; the default of 4 makes streams share queues and a
+ * wait then sits in front of the kernel it waits for until the timeout). */
+int nka_hip_p2p_mailbox(nka_hip_t a, void **mailbox);
+int nka_hip_p2p_attach_local(nka_hip_t a, void *const *mailboxes, int32_t nranks, int32_t rank);
 
 /* Run the installed all-reduce hook once on `count` doubles at device address
  * buf_dev, on the handle's stream (no-op without a hook): lets a launcher check

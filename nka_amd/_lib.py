@@ -48,6 +48,8 @@ SIGNATURES = {
     "nka_hip_p2p_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "nka_hip_p2p_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "nka_hip_p2p_detach": (C.c_int, [C.c_void_p]),
+    "nka_hip_p2p_mailbox": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "nka_hip_p2p_attach_local": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]),
     "nka_hip_state_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nka_hip_set_host_dot": (C.c_int, [C.c_void_p, HOST_DOT_FN, C.c_void_p]),
     "nka_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -1783,28 +1783,36 @@ int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64) {
   return 0;
 }
 
-int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank) {
-  if (!a || !handles) return fail(NKA_HIP_EINVAL, "null argument");
+// `local` != nullptr: the peers live in THIS process (several handles, one per slice, driven by threads: hipIpc does not map a
+// handle into the process that exported it) -- their mailboxes are given as plain device addresses in rank order.
+static int p2p_attach_impl(nka_hip_t a, const void *handles, void *const *local, int32_t nranks, int32_t rank) {
+  if (!a || (!handles && !local)) return fail(NKA_HIP_EINVAL, "null argument");
   if (!a->p2p_mail || nranks != a->p2p_ranks) return fail(NKA_HIP_ESTATE, "p2p_attach: call nka_hip_p2p_export(nranks) first");
   if (a->p2p.base || a->p2p_dev || !a->p2p_opened.empty())
     return fail(NKA_HIP_ESTATE, "p2p_attach: already attached (nka_hip_p2p_detach, then export and attach again, collectively)");
   if (rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "p2p_attach: bad rank");
+  if (local && local[rank] != a->p2p_mail) return fail(NKA_HIP_EINVAL, "p2p_attach_local: entry `rank` is not this handle's own mailbox");
   HIP_TRY(hipSetDevice(a->device));
   const int cap = std::max(a->ctl.red_count(), 64);
   std::vector<long long> off((size_t)nranks, 0);
   for (int q = 0; q < nranks; q++) {
     if (q == rank) continue;
-    hipIpcMemHandle_t h;
-    memcpy(&h, static_cast<const char *>(handles) + (size_t)q * sizeof h, sizeof h);
     void *p = nullptr;
-    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      for (void *o : a->p2p_opened) hipIpcCloseMemHandle(o);
-      a->p2p_opened.clear();
-      return fail(NKA_HIP_ECOMM, std::string("p2p_attach: hipIpcOpenMemHandle(rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+    if (local) {
+      p = local[q];
+      if (!p) return fail(NKA_HIP_EINVAL, "p2p_attach_local: null mailbox");
+    } else {
+      hipIpcMemHandle_t h;
+      memcpy(&h, static_cast<const char *>(handles) + (size_t)q * sizeof h, sizeof h);
+      hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *o : a->p2p_opened) hipIpcCloseMemHandle(o);
+        a->p2p_opened.clear();
+        return fail(NKA_HIP_ECOMM, std::string("p2p_attach: hipIpcOpenMemHandle(rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+      }
+      a->p2p_opened.push_back(p);
     }
-    a->p2p_opened.push_back(p);
     off[(size_t)q] = (long long)(reinterpret_cast<intptr_t>(p) - reinterpret_cast<intptr_t>(a->p2p_mail));
   }
   // offsets table | exchange counter | status word
@@ -1833,6 +1841,19 @@ int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t
   a->needs_comm = false;
   a->shard_rank = rank;
   a->shard_n = nranks;
+  return 0;
+}
+
+int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank) {
+  return p2p_attach_impl(a, handles, nullptr, nranks, rank);
+}
+int nka_hip_p2p_attach_local(nka_hip_t a, void *const *mailboxes, int32_t nranks, int32_t rank) {
+  return p2p_attach_impl(a, nullptr, mailboxes, nranks, rank);
+}
+int nka_hip_p2p_mailbox(nka_hip_t a, void **mailbox) {
+  if (!a || !mailbox) return fail(NKA_HIP_EINVAL, "null argument");
+  if (!a->p2p_mail) return fail(NKA_HIP_ESTATE, "p2p_mailbox: call nka_hip_p2p_export first");
+  *mailbox = a->p2p_mail;
   return 0;
 }
 

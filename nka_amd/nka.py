@@ -208,6 +208,19 @@ class nka:  # noqa: N801  (the reference's type name)
         buf = C.create_string_buffer(blob, len(blob))
         _check(self._L.nka_hip_p2p_attach(self._handle(), buf, int(nranks), int(rank)), "p2p_attach", self._L)
 
+    def p2p_mailbox(self) -> int:
+        """Device address of this handle's mailbox (after p2p_export): what handles of the SAME process exchange instead
+        of hipIpc handles (nka_hip_p2p_mailbox)."""
+        p = C.c_void_p()
+        _check(self._L.nka_hip_p2p_mailbox(self._handle(), C.byref(p)), "p2p_mailbox", self._L)
+        return int(p.value)
+
+    def p2p_attach_local(self, mailboxes, rank: int):
+        """Step 2 for handles that share a process (nka_hip_p2p_attach_local): `mailboxes` = every handle's p2p_mailbox()
+        in rank order."""
+        arr = (C.c_void_p * len(mailboxes))(*[C.c_void_p(int(m)) for m in mailboxes])
+        _check(self._L.nka_hip_p2p_attach_local(self._handle(), arr, len(mailboxes), int(rank)), "p2p_attach_local", self._L)
+
     def p2p_detach(self):
         _check(self._L.nka_hip_p2p_detach(self._handle()), "p2p_detach", self._L)
 
