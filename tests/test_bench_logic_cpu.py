@@ -190,3 +190,66 @@ def test_a_rank_group_launch_that_finds_its_port_taken_is_repeated_with_another(
     other = run_ranks([sys.executable, "-c", "import sys; sys.stderr.write('boom'); sys.exit(3)", "--master-port", "1234"],
                       capture_output=True, text=True, timeout=60)
     assert other.returncode == 3 and other.stderr == "boom"        # (any other failure comes back as it is, once)
+
+
+def _as_a_truncating_record_keeps_it(obj, keys=19, chars=120):
+    """What BENCH_r05.parsed kept of round 5's line: of `roofline` only scalar entries, the first `keys` of them, and of
+    every string its first `chars` characters."""
+    kept = {}
+    for k, v in obj.items():
+        if isinstance(v, (dict, list)):
+            continue
+        if len(kept) == keys:
+            break
+        kept[k] = v[:chars] if isinstance(v, str) else v
+    return kept
+
+
+def test_the_line_survives_a_record_that_keeps_19_scalars_and_120_characters(bench):
+    """the contract-comparable src-F08-rounding figures, the per-pass fractions and the same-run ceiling
+    must come BEFORE the prose and the per-kernel extras of `roofline`, and the config strings must say what they have to
+    say within 100 characters."""
+    n, m = 10**8, 20
+    probe = {"mix_22R_5W_GBps": 6300.0, "mix_42R_5W_GBps": 6100.0, "pure_read_22_streams_GBps": 7100.0}
+    pm = {"kernels": {"k_dots": {"read_bytes": 17.6e9, "write_bytes": 1e5}, "k_combine": {"read_bytes": 17.6e9, "write_bytes": 4.0e9}},
+          "hbm_bytes_per_update": 39.2e9}
+    rl = bench.roofline_block("c", n, m, [2.52, 0.017, 3.44, 5.98], probe, None, pm)
+    also = {"flavor": bench.FLAVOR_TEXT["f08"], "value": 116.9, "unit": "updates/s", "ms_per_step": 8.55, "steady_state": True,
+            "roofline": bench.roofline_block("f08", n, m, [2.53, 0.017, 5.98, 8.55])}
+    nested, flat = bench.reference_rounding_entry(also)
+    rl["reference_rounding"] = nested
+    rl.update(flat)
+    rl["sum_mode_blocked_rounded_updates_per_s"] = 151.0
+    out = {"value": 166.8, "config": {"workload": "BASELINE configs[2]: synthetic n=100000000 (global), mvec=20, fp64, subspace full (num_vec=20)",
+                                      "flavor": bench.FLAVOR_TEXT["c"],
+                                      "flavor_note": "the flavour `call a%init(vlen, mvec)` (Fortran), nka_init (F95) and nka().init "
+                                                     "(Python) run when the caller names none (include/nka_hip.h: NKA_HIP_FLAVOR_DEFAULT)",
+                                      "parallelism": "contiguous n-slices over 1 GPU(s); all-reduce=none"},
+           "roofline": rl}
+    out = bench.finish_line(out)
+    kept = _as_a_truncating_record_keeps_it(out["roofline"])
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_update_frac", "PA_k_dots_frac", "PB_k_combine_frac",
+                "frac_of_probe_ceiling", "reference_rounding_updates_per_s", "reference_rounding_contract_frac_of_peak",
+                "reference_rounding_PB_frac", "probe_ceiling_dominant_mix_GBps", "traffic_source"):
+        assert key in kept, (key, list(kept))
+    assert kept["reference_rounding_updates_per_s"] == 116.9
+    assert abs(kept["reference_rounding_contract_frac_of_peak"] - 56.8e9 / 8.55e-3 / 8e12) < 1e-3
+    assert abs(kept["frac_of_probe_ceiling"] - kept["achieved"] / 6300.0) < 1e-12
+    assert kept["traffic_source"] == out["roofline"]["traffic_source"] and kept["traffic_source"].startswith("same run")
+    # nothing is lost: the long texts live on under *_detail, every entry of the block is still there
+    assert set(rl) <= set(out["roofline"]) and "traffic_source_detail" in out["roofline"]
+    for key in ("workload", "flavor", "flavor_note", "parallelism"):
+        assert len(out["config"][key]) <= bench.SHORT, (key, len(out["config"][key]))
+    assert "configs[2]" in out["config"]["workload"] and "mvec=20" in out["config"]["workload"]
+    assert "compact" in out["config"]["flavor"]
+
+
+def test_a_committed_counter_figure_is_labelled_as_not_of_this_run(bench):
+    """N > 1 lines take `traffic` from profiles/ -- the line must say so in the first words."""
+    r = bench.roofline_block("c", 12_500_000, 20, [0.33, 0.017, 0.42, 0.78])
+    out = bench.finish_line({"roofline": r, "config": {}})
+    src = out["roofline"]["traffic_source"]
+    if out["roofline"]["traffic"] is None:
+        assert src is None
+    else:
+        assert src.startswith("committed file, not this run: profiles/"), src

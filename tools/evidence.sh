@@ -8,6 +8,7 @@
 #   suite                       pytest -m gpu, smoke(), default bench.py                       (tools/gpu_check.sh)
 #   rocprof TAG                 rocprofv3 kernel stats + PMC traffic of bench.py: compact, src-F08 rounding, drops workload
 #   soak MODE SECONDS SEED [W]  tools/fuzz_gpu.py: MODE = array | vector | hostdot | sharded | vector-sharded, W ranks
+#   soak-paired MODE "F:N ..." [W]  the same seeds once per fast sum mode (NKA_FUZZ_FORCE_SUMS)   (tools/soak_compare.py)
 #   soak-seeds SEEDS...         flagged seeds in place against out of place, bit for bit       (tools/swap_vs_inplace_seed.py)
 #   list-word                   tests of the list word + its in-process A/B, drops workload
 #   swap                        tests of the out-of-place entry + tools/ab_swap.py
@@ -44,6 +45,32 @@ soak)
   timeout -k 10 $((secs + 120)) python tools/fuzz_gpu.py --seconds $secs --first-seed $seed $flags --out $out > ${out%.txt}.log 2>&1
   rc=$?; tail -2 ${out%.txt}.log | cut -c1-900; grep -h -A12 "^FAIL" $out* 2>/dev/null | head -40
   exit $rc ;;   # (2 = a sequence of more than 512 elements beyond the allowance that tests/golden/soak_cases.json does not list)
+soak-paired)
+  # round 6: the SAME seeds once per fast sum mode -- raw-sum Gram row (blocked) / Gram row on the rounded
+  # w1' (rounded) -- for tools/soak_compare.py.  soak-paired MODE "FIRST:COUNT FIRST:COUNT ..." [W]; array and vector run the two
+  # modes side by side (two processes), sharded one after the other (3 ranks each).
+  mode=${1:-array}; spans=${2:-"0:100"}; world=${3:-3}
+  case "$mode" in
+    array) flags="" ;; vector) flags="--vector" ;; sharded) flags="--sharded $world" ;; vector-sharded) flags="--vector-sharded $world" ;;
+    *) echo "soak-paired: unknown mode $mode"; exit 2 ;;
+  esac
+  mkdir -p gpurun_out/paired
+  one() {   # one SUMS FIRST COUNT
+    out=gpurun_out/paired/fuzz_${mode}_$2_$1.txt
+    NKA_FUZZ_FORCE_SUMS=$1 timeout -k 10 1100 python tools/fuzz_gpu.py --seeds $3 --first-seed $2 $flags --out $out > ${out%.txt}.log 2>&1
+    rc=$?; echo "$mode $1 seeds $2+$3: rc $rc; $(tail -1 ${out%.txt}.log | cut -c1-300)"; return $rc
+  }
+  for span in $spans; do
+    first=${span%%:*}; count=${span##*:}
+    if [ "$mode" = sharded ] || [ "$mode" = vector-sharded ]; then
+      one blocked $first $count; pass_on $?
+      one rounded $first $count; pass_on $?
+    else
+      one blocked $first $count & p1=$!
+      one rounded $first $count & p2=$!
+      wait $p1; r1=$?; wait $p2; r2=$?; pass_on $r1; pass_on $r2
+    fi
+  done ;;
 soak-seeds)
   timeout -k 10 300 python tools/swap_vs_inplace_seed.py "$@" 2>&1 | tee gpurun_out/swap_vs_inplace_seed.txt | cut -c1-250 ;;
 list-word)

@@ -42,6 +42,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from fuzz_ops import SIZES, array_ops, array_shape  # noqa: E402,F401
 
+# NKA_FUZZ_FORCE_SUMS=blocked|rounded (round 6): every sequence of the array, sharded and abstract-vector
+# generators in ONE fast sum mode -- the raw-sum Gram row (NKA_HIP_SUMS_BLOCKED) or the Gram row on the rounded w1'
+# (NKA_HIP_SUMS_BLOCKED_ROUNDED) -- so that the same seeds can be run once per mode and compared (tools/soak_compare.py).
+FORCE_SUMS = os.environ.get("NKA_FUZZ_FORCE_SUMS", "")
+assert FORCE_SUMS in ("", "blocked", "rounded"), FORCE_SUMS
+
 BEYOND = []      # (key, err_dev, tol, err_ref) of sequences beyond the truth rule's allowance (soak runs: recorded, not fatal)
 
 
@@ -88,6 +94,8 @@ def one_seed(seed, torch, oracle, P, S, nka_amd, steps=120, hostdot=False, stric
              nka_amd.SUMS_BLOCKED_ROUNDED: "rounded"}
     if sums is None and os.environ.get("NKA_FUZZ_SUMS") == "reference":     # (a soak of the bit-identical mode alone)
         sums = nka_amd.SUMS_REFERENCE_ORDER
+    if sums is None and FORCE_SUMS:       # round 6, the paired soak: EVERY seed in one mode, the same seeds once per mode
+        sums = {"blocked": nka_amd.SUMS_BLOCKED, "rounded": nka_amd.SUMS_BLOCKED_ROUNDED}[FORCE_SUMS]
     if sums is None:
         sums = (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER)[seed % 3] if seed < 300_000 else \
             (nka_amd.SUMS_BLOCKED, nka_amd.SUMS_AUTO, nka_amd.SUMS_REFERENCE_ORDER, nka_amd.SUMS_BLOCKED_ROUNDED)[seed % 4]
@@ -176,11 +184,13 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True)
         defer = 1                                           # fusing needs the deferral
     # every third seed on one rank: sums in the reference's order (hip_block_vector_set_sum_order; the driver's compact
     # argument + 10) with the reference's own statements (compact = 0) -- the outputs must then be the oracle's BITS
-    same_bits = world == 1 and seed % 3 == 2
+    same_bits = world == 1 and seed % 3 == 2 and not FORCE_SUMS
     if same_bits:
         compact = 0
+    vrounded = FORCE_SUMS == "rounded"      # (the workspace's rounded mode = the norm stage a pass of its own; compact argument + 20)
     key = f"fuzz vector seed {seed} {nfield}x{nper} m={m} compact={compact} fuse={fuse} defer={defer}" + \
-          (f" world {world}" if world > 1 else "") + (" sums reference" if same_bits else "")
+          (f" world {world}" if world > 1 else "") + (" sums reference" if same_bits else "") + \
+          (f" sums {FORCE_SUMS}" if FORCE_SUMS else "")
     basis = rng.standard_normal((3, n))
     prev = rng.standard_normal(n)
     ops, script = [], []
@@ -211,7 +221,7 @@ def one_seed_vector(seed, oracle, P, S, tmpdir, steps=100, world=1, strict=True)
     exe = os.path.join(ROOT, "nka_amd", "fortran", "build", "nka_vector_driver")
     env = dict(os.environ, NKA_HIP_VEC_FUSE_NORM=str(fuse), NKA_HIP_VEC_DEFER_SCALE=str(defer))
     ofiles = [os.path.join(tmpdir, f"out{r}.bin") for r in range(world)]
-    cmds = [[exe, "script", str(nfield), str(nper), str(m), str(steps), ofiles[r], str(compact + (10 if same_bits else 0)), sfile]
+    cmds = [[exe, "script", str(nfield), str(nper), str(m), str(steps), ofiles[r], str(compact + (10 if same_bits else 20 if vrounded else 0)), sfile]
             for r in range(world)]
     if world > 1:                                           # ranks sharing the GPU, host all-reduce through a mapped file
         shm = os.path.join(tmpdir, "allreduce.shm")
@@ -308,6 +318,8 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
     rounded = seed >= 300_000 and same_bits and (seed // 4) % 2 == 1
     if os.environ.get("NKA_FUZZ_FORCE_ROUNDED") == "1" and not same_bits:
         rounded = True           # (the regression test replays recorded blocked-mode seeds with the Gram row on the rounded w1')
+    if FORCE_SUMS:               # the paired soak: every seed in one fast mode, transports rotating as before
+        same_bits, rounded = False, FORCE_SUMS == "rounded"
     if rounded:
         same_bits = False
     key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}" + \
