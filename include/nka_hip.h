@@ -1,38 +1,21 @@
 /*
- * nka_hip.h -- C ABI of the MI355X-native NKA accelerator (libnka_hip.so).
+ * nka_hip.h -- CORE C ABI of the MI355X-native NKA accelerator (libnka_hip.so): what a caller needs to replace the
+ * accelerator object of nncarlson/nka and its accel_update hot path, one entry per reference interface:
+ *   F08  = /root/reference/src-F08/nka_type.F90          (type nka, F08:154-181)
+ *   F08V = /root/reference/src-F08-vector/nka_type.F90
+ *   C    = /root/reference/src-C/nonlinear_krylov_accelerator.{h,c}   (C .h:3-12)
+ * Optional entry points live in two other headers and never change what the core returns:
+ *   nka_hip_ext.h   state read-back for parity tests, the out-of-place update, hipGraph capture, the list word, timing,
+ *                   the peer-to-peer exchange, the long note on the sum orders and the table of supported combinations
+ *   nka_hip_vec.h   device hooks of the reference's abstract vector class (src-F08-vector/vector_class.F90)
  *
- * Drop-in boundary for ONE path of nncarlson/nka: the accelerator object and
- * its accel_update hot path.  Every entry point names the reference interface
- * it replaces:
- *   F08  = /root/reference/src-F08/nka_type.F90
- *   F08V = /root/reference/src-F08-vector/nka_type.F90, vector_class.F90
- *   C    = /root/reference/src-C/nonlinear_krylov_accelerator.{h,c}
- *
- * Plain C types only: opaque handle, raw DEVICE pointers (memory on the HIP
- * device the handle was created for), int64 lengths, a hipStream_t passed as
- * void*.  No status codes exist in the reference (its precondition checks are
- * ASSERTs, F08:190-191,205,212,257-258); here every call returns 0 on success
- * or a negative NKA_HIP_E* code, and nka_hip_last_error() gives the text.
- *
- * All state-changing calls are ASYNCHRONOUS on the handle's stream (no host
- * synchronisation inside accel_update); the query calls (num_vec, get_state)
- * synchronise that stream.  In a multi-rank run every call is collective, like
- * the reference (F08:58-64).
- *
- * Slot numbering, list links and the H matrix layout visible through
- * nka_hip_get_state are the Fortran ones: slots 1..mvec+1, 0 = end of list.
- *
- * MAP OF THIS HEADER.  A caller who only replaces the reference needs the CORE, which mirrors the reference's surface one to
- * one (C .h:3-12, F08:169-181); everything else is optional and never changes what the core returns:
- *   core           create / destroy / clone, accel_update (+ _host), restart, relax, set_vec_tol, num_vec, max_vec, vec_len,
- *                  vec_tol, defined, set_host_dot (the reference's dp), last_error
- *   distribution   set_allreduce | comm_unique_id / comm_init_rank / comm_destroy / comm_info / comm_library |
- *                  p2p_export / p2p_attach / p2p_detach (opt-in prototype) | set_shard, allreduce_now, state_digest
- *   validation     set_sum_order (the reference's bits), get_state / get_reductions / get_w / get_v, flavor
- *   performance    accel_update_swap (opt-in: buffers change hands -- read its ownership rules before use), list_bound,
- *                  capture_safe, set_stream, set_timing / get_timing / set_timing_stride, device_info
- *   vector hooks   nka_hip_vec_*: device implementations of the deferred procedures of the abstract vector class, their
- *                  batched / fused forms and parallel-aware reductions (used by nka_amd/fortran/vector/)
+ * Plain C types only: an opaque handle, raw DEVICE pointers (memory of the HIP device the handle was created for), int64
+ * lengths, a hipStream_t passed as void*.  The reference has no status codes (its precondition checks are ASSERTs,
+ * F08:190-191,205,212,257-258); here every call returns 0 or a negative NKA_HIP_E* code and nka_hip_last_error() has the
+ * text.  State-changing calls are ASYNCHRONOUS on the handle's stream (no host synchronisation inside accel_update); the
+ * queries synchronise it.  Not thread-safe per handle; distinct handles are independent (also from different threads).  In
+ * a multi-rank run every call is collective, like the reference (F08:58-64).  Slots are numbered as in Fortran: 1..mvec+1,
+ * 0 = end of list.  There is no CPU path: without a HIP device nka_hip_create fails.
  */
 #ifndef NKA_HIP_H
 #define NKA_HIP_H
@@ -47,201 +30,103 @@ typedef struct nka_hip_state *nka_hip_t;
 
 enum {
   NKA_HIP_OK = 0,
-  NKA_HIP_EINVAL = -1,  /* bad argument (the reference would ASSERT)        */
+  NKA_HIP_EINVAL = -1,  /* bad argument, or a combination that is not supported (the reference would ASSERT) */
   NKA_HIP_EHIP = -2,    /* a HIP runtime call failed                        */
   NKA_HIP_ENOMEM = -3,  /* device allocation failed                         */
   NKA_HIP_ECOMM = -4,   /* RCCL / user all-reduce failed                    */
-  NKA_HIP_ESTATE = -5   /* device state failed the defined() invariants     */
+  NKA_HIP_ESTATE = -5   /* device state failed the defined() invariants, or the call order is wrong */
 };
 
-/* Which of the reference's three roundings of the elementwise statements is
- * mirrored:
+/* Which of the reference's three roundings of the elementwise statements is mirrored:
  *   F08        w1-f ; x/s          ; (f - c*w) + c*v        F08:266,282-283,397
  *   F08_VECTOR (-1)*f+w ; (1/s)*x  ; ((-c)*w + c*v) + f     F08V:237,255-256,374
  *   C          w1-f ; x/s          ; f + c*(v - w)          C .c:299-300,317-320,423
- * The C flavour uses COMPACT storage: its combine only ever needs the difference
- * v_k - w_k of a normalised pair, so that difference is formed once, when the
- * pair is normalised, and kept in the v array in place of v_k.  f + c*(v-w) is
- * then evaluated with bit-identical operands while the combine pass reads one
- * vector per pair instead of two.  (nka_hip_get_v on a normalised slot returns
- * v_k - w_k in this flavour; the pending slot holds the raw update.) */
+ * The C flavour uses COMPACT storage: its combine only needs the difference v_k - w_k of a normalised pair, so that
+ * difference is formed once and kept in the v array in place of v_k; f + c*(v-w) is then evaluated with bit-identical
+ * operands while the combine pass reads one vector per pair instead of two (8n(9+L+k) bytes per update instead of
+ * 8n(8+L+2k)).  NKA_HIP_FLAVOR_DEFAULT -- what every front end passes unless the caller names a flavour -- resolves to the
+ * environment variable NKA_HIP_FLAVOR ("f08" | "f08vec" | "c") if set, else to NKA_HIP_FLAVOR_C; it differs from
+ * NKA_HIP_FLAVOR_F08 only in the association of the combine (last bits).  nka_hip_flavor() reports what a handle runs. */
 enum { NKA_HIP_FLAVOR_F08 = 0, NKA_HIP_FLAVOR_F08_VECTOR = 1, NKA_HIP_FLAVOR_C = 2 };
-/* NKA_HIP_FLAVOR_DEFAULT: what every front end of this build passes unless the caller
- * names a flavour (Fortran `call a%init(vlen, mvec)`, F95 nka_init, Python init, the C
- * compatibility header).  It resolves to the environment variable NKA_HIP_FLAVOR
- * ("f08" | "f08vec" | "c", or 0 | 1 | 2) if set, else to NKA_HIP_FLAVOR_C: compact
- * storage moves 8n(9+L+k) bytes per update instead of 8n(8+L+2k) and is held to the
- * compiled src-F08 reference in tests/ at the stated tolerance with exact decisions;
- * it differs from NKA_HIP_FLAVOR_F08 only in the association of the combine
- * (f + c*(v-w) against (f - c*w) + c*v: last-bit differences).  A caller that wants
- * the F08 statement bit for bit passes NKA_HIP_FLAVOR_F08 (or sets NKA_HIP_FLAVOR=f08).
- * nka_hip_flavor() reports the flavour a handle runs. */
 enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
 
 /* ---- NUMERICAL CONTRACT ----------------------------------------------------------------------------------------------
  * What nka_hip_accel_update returns, held against the COMPILED reference (oracle/_ref: /root/reference built here without
  * floating-point contraction) on the same call sequence.  err(x) = ||x - f_exact||_2 / ||f_in||_2, f_exact = the same calls
  * in extended precision (oracle/nka_oracle_exact.c, itself held to a 60-digit restatement, oracle/oracle_mp.py);
- * tests/parity_util.py is the executable form of every line below.
+ * tests/parity_util.py is the executable form of every line below; the record behind the counts is
+ * profiles/r06/soak_paired.txt (round 6) and profiles/r04, r05/fuzz_soak.txt.
  *  1. DECISIONS.  s == 0 (relax, F08:275), the capacity and dependence drops (F08:301-345), slot numbers, list order,
- *     free-list order and num_vec equal the reference's after EVERY call: compared with == in every test and in every soak
- *     sequence (about 19 000 random call sequences in round 4; none differed).  With reference-order sums that holds by
- *     construction; with the fast passes a pivot within rounding distance of vtol^2 could in principle fall the other way.
- *  2. REFERENCE-ORDER SUMS (nka_hip_set_sum_order(NKA_HIP_SUMS_REFERENCE_ORDER); the default up to n = 64): the returned f
- *     -- and h, c, every stored vector -- carry the BITS of the reference flavour the handle runs, at any n, on one rank or
- *     sharded (the ranks continue one another's running sums).  Validation speed beyond a few thousand elements.
- *  3. FAST PASSES (the default beyond n = 64): sums in blocks with fma, the Gram row of the normalised difference from raw
- *     sums -- other last bits than the reference's sequential sums, and closer to f_exact than those from n ~ 1e3 up.  Over a
- *     call sequence
- *           max err(f_device) <= max(base, F * max err(f_reference)),   base = 1e-12 (1e-10 for n >= 1e7),
- *           F = 2 for n > 512, 4 within one tile of the kernels (n <= 512),
- *     i.e. within the stated tolerance wherever the reference is, and never further from the truth than F times the
- *     reference's own worst distance on the same calls (ill-conditioned sequences -- pivots down to vtol, a tiny difference
- *     norm s -- put the REFERENCE 1e-10 ... 1e-6 from the truth; no fixed figure can hold there).  An EMPIRICAL bar with a
- *     counted exceedance rate: 25 of 18 916 soak records + 15 in later runs of round 4 + 28 sequences in round 5 (48 411 sharded
- *     records, 4 678 other sequences) -- all but eleven with n <= 9 elements; one with 510 (within one tile); the TEN beyond one
- *     tile have 595 ... 4097 elements (2.05 ... 3.5 x instead of 2 x; once 5.5 x: abstract-vector flavour, 4097 elements) and,
- *     once, 8191 (2.7 x).  Each of the ten is a fixture
- *     (tests/golden/soak_cases.json: its generator call) replayed by the suite with a cap on its ratio, and the soak tool exits
- *     non-zero on an exceedance beyond one tile that the file does not list.  DIRECTLY against the reference: wherever err(f_reference) <= base / 2,
- *     ||f_device - f_reference|| / ||f_in|| <= 2 * base is asserted; at n = 2e7, m = 20 (independent and dependent inputs)
- *     <= 1e-10 on every call, unscaled (tests/test_hip_fullsize.py).
+ *     free-list order and num_vec equal the reference's after EVERY call: compared with == in every test and every soak
+ *     sequence (none has ever differed).  With reference-order sums that holds by construction; with the fast passes a
+ *     pivot within rounding distance of vtol^2 could in principle fall the other way.
+ *  2. REFERENCE-ORDER SUMS (NKA_HIP_SUMS_REFERENCE_ORDER; the default up to n = 64): the returned f -- and h, c, every
+ *     stored vector -- carry the BITS of the reference flavour the handle runs, at any n, on one rank or sharded.
+ *  3. FAST PASSES (the default beyond n = 64): sums in blocks with fma -- other last bits than the reference's sequential
+ *     sums, and closer to f_exact than those from n ~ 1e3 up.  Over a call sequence
+ *         TYPICAL  max err(f_device) <= max(base, F * max err(f_reference)),  base = 1e-12 (1e-10 for n >= 1e7),
+ *                  F = 2 for n > 512, 4 within one tile of the kernels (n <= 512): within the stated tolerance wherever
+ *                  the reference is, else within F times the reference's own worst distance from the truth on the same
+ *                  calls (ill-conditioned sequences put the REFERENCE 1e-10 ... 1e-6 from it: no fixed figure can hold).
+ *                  An empirical bar with a counted exceedance rate -- see item 6.
+ *         HARD     the same with F = 8 for n > 512 and F = 32, base 1e-11 for n <= 512 has NEVER been exceeded by any
+ *                  recorded sequence in either sum mode (item 6); every test also stops a call that exceeds it.
+ *     DIRECTLY against the reference: wherever err(f_reference) <= base / 2, ||f_device - f_reference|| / ||f_in|| <= 2 base
+ *     is asserted; at n = 2e7, m = 20 <= 1e-10 on every call, unscaled (tests/test_hip_fullsize.py).
  *  4. FLAVOURS.  The default flavour evaluates the combine as the C reference does, f + c*(v - w), against src-F08's
  *     (f - c*w) + c*v: last-bit differences, inside every bound above; NKA_HIP_FLAVOR_F08 gives the src-F08 statement.
- *  5. Sharded runs return the same bits on every rank (one reduction result, added in one order), and -- fast passes -- bits
- *     that depend on the number of ranks like any blocked sum; the bounds of 3 hold unchanged (soak: 3 ranks, 5 600 sequences).
+ *  5. Sharded runs return the same bits on every rank (one reduction result, added in one order), and -- fast passes --
+ *     bits that depend on the number of ranks like any blocked sum; the bounds of 3 hold unchanged.
+ *  6. THE RECORD.  See profiles/r06/soak_paired.txt for the two fast sum modes on the same seeds, side by side.
  */
 
 /* ---- lifecycle --------------------------------------------------------- */
 
-/* Replaces  call a%init(vlen, mvec)  (F08:185-200)  /  nka_init(vlen, mvec,
- * vtol, dp)  (C .h:4, .c:211-258).  vlen_local is THIS rank's slice length
- * (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).
- * `device` is the HIP device ordinal; `stream` is a hipStream_t (NULL = HIP's
- * default stream).  Allocates 2*(mvec+1) slot vectors on the device.
- * Any mvec, like the reference (F08:185-200): up to 140 the scalar step keeps the
- * (mvec+2)^2 matrix in the 160 KiB LDS of one CU (one wavefront up to mvec = 62, one
- * lane beyond); above 140 the same one-lane loops work on the control block in global
- * memory -- correct and slow (practical subspaces are 5..20 vectors). */
+/* Replaces  call a%init(vlen, mvec)  (F08:185-200)  /  nka_init(vlen, mvec, vtol, dp)  (C .h:4, .c:211-258).
+ * vlen_local is THIS rank's slice length (>= 0), mvec > 0, vtol > 0 (the Fortran default is 0.01, F08:160).  `device` is
+ * the HIP device ordinal; `stream` a hipStream_t (NULL = HIP's default stream).  Allocates 2*(mvec+1) slot vectors on the
+ * device.  Any mvec, like the reference: the scalar step runs on one wavefront up to mvec = 62, on one lane in LDS up to
+ * 140, beyond that on one lane in global memory (correct and slow; practical subspaces are 5..20 vectors). */
 int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol,
                    int32_t flavor, int32_t device, void *stream);
-
-/* hipGraph capture.  nka_hip_accel_update only enqueues kernels (no allocation,
- * no synchronisation), so a caller may capture it into a graph and replay it.
- * A replay re-issues the kernel instances chosen at capture time; they stay
- * valid as long as the unroll widths chosen then cover the list, which is
- * guaranteed once nka_hip_capture_safe() returns 1: a pair is pending and the
- * host-side bound on the list length (nka_hip_list_bound) is mvec+1 -- from the
- * mvec+1-th update after init/restart on, unless the device has reported a list made
- * shorter by dependence drops.  restart()/relax() end that state.  A handle whose stream
- * was seen capturing stops using (and publishing) the list word for good: replays change
- * the list behind it.  Never 1 in the
- * debug mode (NKA_HIP_DEBUG=1 reads the state back after every update), with a user dot
- * product (nka_hip_set_host_dot: it runs on the host) or with a caller's all-reduce hook
- * (nka_hip_set_allreduce: a host callback a replay would not call again; the built-in
- * RCCL hook only enqueues on the stream and can be captured). */
-int nka_hip_capture_safe(nka_hip_t a);
-
-/* Upper bound on the list length (pending pair included) at the entry of the next update, as the HOST knows it
- * without synchronising: its own count (+1 per update up to mvec+1, -1 per relax, 0 after restart) tightened by the
- * LIST WORD -- a 64-bit word in pinned host memory that the combine pass of every update overwrites with (update
- * number, list length at its exit).  After a dependence drop (F08:326-345) the list is shorter than the host's
- * count; PA and PB are launched at the width of this bound, so a caller that synchronises once per iteration (every
- * solver reads its residual norm) runs both passes at exactly the list length, never at the padded full width.
- * A caller that never synchronises gets the plain count.  Results do not depend on the width (same bits). */
-int nka_hip_list_bound(nka_hip_t a);
-
-/* Rebind the handle to another hipStream_t (NULL = default stream).  Work already
- * enqueued on the old stream is ordered before anything enqueued on the new one. */
-int nka_hip_set_stream(nka_hip_t a, void *stream);
-
 /* Replaces nka_delete (C .h:5, .c:261-282) / automatic deallocation (F08). */
 int nka_hip_destroy(nka_hip_t a);
-
-/* Replaces the intrinsic assignment  b = a  of the reference's type, whose allocatable
- * components make it a DEEP copy (F08:154-168): *out becomes an independent accelerator
- * with the same vectors (device-to-device copies of v and w), the same lists, factor and
- * flags, vtol, flavour, device and stream; afterwards the two objects evolve separately.
- * The copy is ordered on src's stream.  User hooks (set_allreduce, set_host_dot) are
- * carried over -- like the procedure pointer component dp of the reference, F08:161 --
- * but NOT the built-in RCCL communicator, which belongs to src: call
- * nka_hip_comm_init_rank on the copy.  Timing rings are not copied. */
+/* Replaces the intrinsic assignment  b = a  of the reference's type, a DEEP copy (allocatable components, F08:154-168):
+ * *out becomes an independent accelerator with the same vectors, lists, factor, flags, vtol, flavour, device and stream.
+ * User hooks (set_allreduce, set_host_dot) are carried over like the procedure pointer dp (F08:161); the built-in RCCL
+ * communicator and peer-to-peer mailboxes are NOT (they belong to src): the copy refuses to update until it has its own. */
 int nka_hip_clone(nka_hip_t src, nka_hip_t *out);
+/* Rebind the handle to another hipStream_t (NULL = default stream); work already enqueued stays ordered before. */
+int nka_hip_set_stream(nka_hip_t a, void *stream);
 
 /* ---- the hot path ------------------------------------------------------ */
 
-/* Replaces  call a%accel_update(f)  (F08:249-419; F08V:219-397; C .h:6,
- * .c:285-447).  f_dev: vlen_local doubles in device memory, updated in place.
- * The object keeps copies, never a reference (F08:361,404). */
+/* Replaces  call a%accel_update(f)  (F08:249-419; F08V:219-397; C .h:6, .c:285-447).  f_dev: vlen_local doubles in
+ * device memory, updated in place.  The object keeps copies, never a reference (F08:361,404).  If the all-reduce of a
+ * sharded handle fails the call returns NKA_HIP_ECOMM with the update NOT done (only scratch sums were written). */
 int nka_hip_accel_update(nka_hip_t a, double *f_dev);
-
-/* OUT-OF-PLACE form of accel_update, opt-in: two of PB's five store streams less (8n(7+L+k) bytes per update with
- * compact storage instead of 8n(9+L+k); 8n(6+L+2k) against 8n(8+L+2k) in the src-F08 rounding).  The reference keeps
- * COPIES of f_in and f_out (F08:361, 404) and returns f_out in the caller's array; here the buffers themselves change
- * hands instead of being copied:
- *   in   *f_io  : device buffer with f (vlen_local doubles, 16-byte aligned).  The library KEEPS it -- it becomes the
- *                 storage of w of the new pair, which is f_in itself -- until the handle is destroyed: do not write it,
- *                 free it only after nka_hip_destroy.
- *   out  *f_io  : a free device buffer of the library (>= vlen_local doubles, contents undefined) for the caller's NEXT
- *                 input; it dies with the handle.
- *   out  *f_acc : the accelerated f -- the v of the new pair, stored once -- to be READ only (solution update, next
- *                 residual), valid until the next accel_update* / restart / destroy on this handle.  Handing it to either
- *                 update entry as the next f is refused (NKA_HIP_EINVAL): it is the stored v of the pending pair.
- * Same arithmetic, same bits, same state as nka_hip_accel_update on the same inputs; the two entries can be mixed.  The
- * buffers an update displaces are known on the device only; they reach the host with the list word's record (no
- * synchronisation if the caller has synchronised since the previous out-of-place update, else this call waits for the
- * stream).  Not with nka_hip_set_host_dot; not capturable into a graph. */
-int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc);
-
-/* HOW THE INNER PRODUCTS ARE SUMMED.  The reference's sums are sequential (its default dot product: C .c:200-208;
- * `dot_product` in F08:216-219); the fast passes sum in blocks, fused, and take the Gram row of the normalised
- * difference from raw sums -- closer to the exact result than the reference from n ~ 1e3 up, but other bits.
- *   NKA_HIP_SUMS_REFERENCE_ORDER  every sum of an update exactly as the reference forms it -- the norm first, then
- *       <w1',w_k>, <f,w_k>, <f,w1'> on the ROUNDED w1' = d/s, element after element, one rounding per product and per
- *       addition -- on one workgroup.  Everything else of an update being bit-exact given its sums, accel_update then
- *       returns the bits of the reference flavour the handle runs (compiled without contraction, as oracle/Makefile
- *       does) at ANY n: a validation mode for callers moving over from the reference.  Cost: two chains of n dependent
- *       roundings per update -- on par with the fast passes up to n = 64, +12-18 us at n = 512; beyond one chunk (~ 700
- *       elements at mvec = 20) the sums go through their chains 1024 products at a time wherever that is provably the
- *       element-after-element result -- one compute unit per sum (k_chain_sums), from 2^19 elements on the block summaries of
- *       every sum by the whole device and one wavefront per sum to apply them (k_chain_blocks / k_chain_apply; 25 bytes of
- *       scratch per block and sum, allocated at the first such update): 0.16 ms at n = 1e4, 5 ms at n = 1e6, 0.13 s at
- *       n = 1e8, mvec = 20 on uniform random vectors (0.02 s on correlated ones) -- 22 x the compiled reference on its
- *       core, every output torch.equal to it in
- *       the same bench run (profiles/r05/reference_order_chain.txt).  SHARDED (an all-reduce installed): the reference's sum over
- *       the global vector is one chain of additions through the slices in rank order, so the ranks take turns -- rank r
- *       continues the running sums of ranks 0..r-1, the others contribute zeros, and the installed hook (any hook that
- *       sums) hands the prefix on: N rounds for the norm (w1' = d/s needs the GLOBAL s before it can be rounded), N for the
- *       rows, 2N small exchanges per update.  An N-rank run then returns the bits of the SINGLE-rank compiled reference.
- *       The handle must know where its slice lies: nka_hip_set_shard (nka_hip_comm_init_rank does it), else NKA_HIP_ESTATE.
- *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
- *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden
- *       scenario of the reference among them) -- blocked otherwise.
- *   NKA_HIP_SUMS_BLOCKED_ROUNDED  (round 5) the fast passes, but the norm first, in a short pass of its own (two streams: 51 instead
- *       of 49 words per element, one more exchange when sharded), and PA then on the ROUNDED w1' = fl(d/s) -- the vector that is
- *       stored: <w1',w_k> and <f,w1'> are then inner products of the stored vectors, as the reference defines them (F08:283-290,
- *       371), instead of fl(<d,w_k>/s).  That removes the one deviation of the fast passes that is not "a more accurate sum":
- *       what remains is the blocked order and the fma.  For callers who put parity before 5-9 % of speed
- *       (profiles/r05/rounded_gram_row.txt); the bounds of the numerical contract are the same.
- * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates.  REFERENCE_ORDER is
- * offered up to mvec = 250 (NKA_HIP_EINVAL beyond). */
-enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2, NKA_HIP_SUMS_BLOCKED_ROUNDED = 3 };
-int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
-/* Position of this rank's slice in the global vector: slice `rank` of `nranks`, slices laid out in rank order (the
- * reference's parallel contract leaves the layout to the caller, F08:58-64; contiguous slices in rank order are what
- * nka_amd/dist.py and every front end of this build use).  Only the sharded reference-order sums read it. */
-int nka_hip_set_shard(nka_hip_t a, int32_t rank, int32_t nranks);
-
-/* Host-array compatibility entry (the reference signature takes host memory,
- * F08:252): H2D copy, update, D2H copy, stream synchronised on return. */
+/* Host-array compatibility entry (the reference signature takes host memory, F08:252): H2D copy, update, D2H copy,
+ * stream synchronised on return. */
 int nka_hip_accel_update_host(nka_hip_t a, double *f_host);
-
 /* Replaces  call a%restart()  (F08:422-436; C .h:7).  */
 int nka_hip_restart(nka_hip_t a);
 /* Replaces  call a%relax()    (F08:439-457; C .h:8).  */
 int nka_hip_relax(nka_hip_t a);
 /* Replaces  call a%set_vec_tol(vtol)  (F08:202-207). */
 int nka_hip_set_vec_tol(nka_hip_t a, double vtol);
+
+/* How the inner products are summed (part of the numerical contract; the long note is in nka_hip_ext.h):
+ *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing (one rank, n <= 64), the fast passes otherwise
+ *   NKA_HIP_SUMS_REFERENCE_ORDER  every sum as the reference forms it: accel_update returns the reference's BITS at any n,
+ *                                 sharded too (needs nka_hip_set_shard); validation speed beyond a few thousand elements
+ *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n: ONE pure-read pass forms every sum of an update; the Gram row
+ *                                 of the normalised difference is taken from raw sums, fl(<d,w_k>/s)
+ *   NKA_HIP_SUMS_BLOCKED_ROUNDED  the fast passes with the norm first (a short pass of its own, a second exchange when
+ *                                 sharded) and the Gram row as the inner product of the STORED fl(d/s), as the reference
+ *                                 defines it (F08:282-290): +5-9 % time
+ * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates. */
+enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2, NKA_HIP_SUMS_BLOCKED_ROUNDED = 3 };
+int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
 
 /* ---- queries (synchronise the stream) ---------------------------------- */
 
@@ -251,306 +136,52 @@ int64_t nka_hip_vec_len(nka_hip_t a);  /* F08:238-241, C .h:11 (local length) */
 double nka_hip_vec_tol(nka_hip_t a);   /* F08:243-246, C .h:12 ; -1 (and last_error) on a NULL handle */
 int nka_hip_defined(nka_hip_t a);      /* F08:460-524 ; 1 = well defined */
 int nka_hip_flavor(nka_hip_t a);       /* NKA_HIP_FLAVOR_* this handle runs (DEFAULT resolved) ; <0 on error */
+const char *nka_hip_last_error(void);  /* text of the last failure on this thread */
+/* "gfx950"-style name of the device the handle runs on, CU count. */
+int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
 
-/* List / factor state for parity tests (the reference keeps these private,
- * F08:155-168).  next, prev: mvec+1 ints (entry k-1 is slot k); h: (mvec+1)^2
- * doubles, column-major h(i,j) = h[(i-1)+(j-1)*(mvec+1)]; c: mvec+1 doubles,
- * the coefficients of the last update by slot.  Any pointer may be NULL. */
-int nka_hip_get_state(nka_hip_t a, int32_t *subspace, int32_t *pending, int32_t *first,
-                      int32_t *last, int32_t *free_, int32_t *next, int32_t *prev,
-                      double *h, double *c);
-/* The reduced inner products of the most recent update as the device solve saw
- * them, with d = w1 - f the new (not yet normalised) difference:
- * red[0] = <d,d>, red[1] = <f,d>, red[2+p] = <d,w_p>, red[2+mvec+p] = <f,w_p>
- * for the p-th older list entry (2+2*mvec doubles).  The solve divides the d
- * rows by s = sqrt(red[0]).  With these a CPU restatement of the scalar step
- * can be checked bit for bit.  With reference-order sums (nka_hip_set_sum_order) red[1] and red[2+p] are the sums on the
- * NORMALISED difference, <f,w1'> and <w1',w_p>, and the solve takes them as they are. */
-int nka_hip_get_reductions(nka_hip_t a, double *red_out);
-/* Copy stored vector w(:,slot) / v(:,slot) (1-based slot) to host memory. */
-int nka_hip_get_w(nka_hip_t a, int32_t slot, double *host_out);
-int nka_hip_get_v(nka_hip_t a, int32_t slot, double *host_out);
+/* ---- the user's dot product --------------------------------------------- */
 
-/* ---- distribution hook -------------------------------------------------- */
+/* Source compatibility with  call a%set_dot_prod(dot_prod)  (F08:209-219), the dp argument of nka_init (C .h:4,
+ * .c:196,227-231) and the optional dp dummy of the F95 nka_accel_update (src-F95/nka_type.F90:278-291): a user dot
+ * product over HOST arrays that returns the GLOBAL dot product (F08:58-64; no hook is applied on top).  With fn installed
+ * an update makes EXACTLY the reference's calls, in its order, on its operands (host copies of this rank's slices):
+ * fn(d,d) with d = w1 - f; if s != 0 the Gram row fn(w1', w_k) for every older list entry in list order (F08:286-290);
+ * then, after the device has taken the drop decisions, fn(f, w_j) for j = first ... last (F08:371) -- while the scalar
+ * step, the combine and the ring stores stay on the device.  Results are bit-identical to the reference with the same dp.
+ * 2+L vectors cross PCIe per update and the call synchronises: a compatibility path.  fn = NULL restores the device sums. */
+typedef double (*nka_hip_host_dot_fn)(void *ctx, int64_t n, const double *x, const double *y);
+int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx);
 
-/* Replaces  call a%set_dot_prod(dot_prod)  (F08:209-214) / the dp argument of
- * nka_init (C .c:211,227-231).  The reference asks the user for a GLOBAL dot
- * product; here the local partial sums already live on the device, so the
- * hook is the global SUM of `count` doubles at device address `buf`, in place,
- * enqueued on `stream` (hipStream_t).  Must return 0 on success, and must give
- * bit-identical results on every rank.  Called ONCE per accel_update (count
- * 2+2*mvec: the norm, and both Gram rows).  NULL restores the single-rank
- * default (no reduction). */
+/* ---- distribution (contiguous n-slices, one handle per rank; F08:58-64) --- */
+
+/* The device form of  set_dot_prod  for a sharded vector: the local partial sums already live on the device, so the hook
+ * is the global SUM of `count` doubles at device address `buf`, in place, enqueued on `stream` (hipStream_t).  Must return
+ * 0 on success and give bit-identical results on every rank.  Called ONCE per accel_update (count 2+2*mvec: the norm and
+ * both Gram rows; twice with NKA_HIP_SUMS_BLOCKED_ROUNDED).  NULL restores the single-rank default (no reduction). */
 typedef int (*nka_hip_allreduce_fn)(void *ctx, double *buf, int32_t count, void *stream);
 int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx);
-
-/* If the hook (or the built-in RCCL all-reduce) fails, nka_hip_accel_update
- * returns NKA_HIP_ECOMM with the update NOT done: only scratch sums were
- * written; f, the stored vectors, the lists and the host bookkeeping are as
- * before the call. */
-
-/* Built-in hook: RCCL all-reduce over xGMI on the handle's stream.
- * nka_hip_comm_unique_id fills 128 bytes (an ncclUniqueId) on one rank; the
- * caller broadcasts it by any means; every rank then calls comm_init_rank.
- * RCCL is bound at first use (dlopen): the librccl.so.1 already mapped into the
- * process if there is one (PyTorch brings its own), else the ROCm
- * installation's -- one copy per process either way; nka_hip_comm_library
- * reports the file.  nka_hip_comm_destroy drops the communicator and the hook. */
+/* Built-in hook: ONE RCCL all-reduce over xGMI on the handle's stream.  nka_hip_comm_unique_id fills 128 bytes (an
+ * ncclUniqueId) on one rank; the caller broadcasts it by any means; every rank then calls comm_init_rank (collective,
+ * blocking).  RCCL is bound at first use (dlopen): the librccl.so.1 already mapped into the process if there is one, else
+ * the ROCm installation's; nka_hip_comm_library reports the file.  comm_info: what the communicator itself reports
+ * (*nranks = 0, *rank = -1 without one).  nka_hip_comm_destroy drops the communicator and the hook. */
 int nka_hip_comm_unique_id(void *id128);
 int nka_hip_comm_init_rank(nka_hip_t a, const void *id128, int32_t nranks, int32_t rank);
 int nka_hip_comm_destroy(nka_hip_t a);
 int nka_hip_comm_library(char *path, int32_t len);
-/* What the handle's built-in communicator itself reports (ncclCommCount / ncclCommUserRank):
- * *nranks = 0, *rank = -1 without one.  A launcher prints it so that a multi-GPU record proves
- * how many ranks RCCL really connected. */
 int nka_hip_comm_info(nka_hip_t a, int32_t *nranks, int32_t *rank);
-
-/* PEER-TO-PEER EXCHANGE (opt-in, one node): the sums of an update without a communication kernel -- one more way to supply
- * the global reduction the reference leaves to its caller (F08:58-64, set_dot_prod F08:209-214).  Every rank owns a
- * mailbox in fine-grained device memory which its peers map through hipIpc; the final-sums kernel of an update writes
- * each sum straight into every rank's mailbox (value, then the exchange number released at system scope) and the scalar
- * step starts by waiting for the N rows and adding them IN RANK ORDER -- the same additions in the same order on every
- * rank, hence the same bits; two kernel boundaries fewer than with an all-reduce kernel in between.  Set-up, collective:
- *   nka_hip_p2p_export(a, nranks, handle64)   allocate this rank's mailbox, fill 64 bytes (a hipIpcMemHandle_t);
- *   the caller gathers the nranks handles in rank order by any means (as it broadcasts the RCCL unique id);
- *   nka_hip_p2p_attach(a, handles, nranks, rank)   map the peers' mailboxes, install the exchange as the reduction
- *                                                   (it also serves nka_hip_allreduce_now and the reference-order chain,
- *                                                   as one small send-and-gather kernel).
- * One process per GPU (hipIpc does not map a handle into the process that exported it).  A wait for a peer is BOUNDED
- * (NKA_HIP_P2P_TIMEOUT_MS, default 10000): if a rank's sums do not arrive the gather stores NaNs, raises a status word and
- * lets the grid drain; the next synchronising query (num_vec, get_state, state_digest ...) returns NKA_HIP_ECOMM.
- * Capturable into a graph (the exchange number lives on the device).  nka_hip_p2p_detach, collective too (a peer must not
- * write into a mailbox that has been freed: synchronise all ranks first), drops it; nka_hip_destroy calls it.
- * Where hipIpc is refused (export or attach returns NKA_HIP_ECOMM) the caller falls back to the RCCL hook:
- * nka_amd/dist.py attach_allreduce(ladder=("p2p", "rccl", ...)) decides that collectively.
- * STATUS: a prototype, proven with ranks sharing one GPU (tests/test_p2p_exchange.py); over xGMI it needs a measured win
- * over RCCL's 336-byte all-reduce before it is preferred. */
-int nka_hip_p2p_export(nka_hip_t a, int32_t nranks, void *handle64);
-int nka_hip_p2p_attach(nka_hip_t a, const void *handles, int32_t nranks, int32_t rank);
-int nka_hip_p2p_detach(nka_hip_t a);
-/* The same exchange between several handles of ONE process (one per slice, each on its own stream, driven by host threads):
- * after nka_hip_p2p_export on every handle, nka_hip_p2p_mailbox returns the device address of a handle's mailbox and
- * nka_hip_p2p_attach_local takes the nranks addresses in rank order (entry `rank` must be the handle's own).  Nothing is
- * mapped, so detach frees only the handle's own mailbox: synchronise every handle before the first detach.  The scalar
- * step of a slice WAITS on the device for the sums of the others: every handle's stream must own a hardware queue
- * (GPU_MAX_HW_QUEUES >= nranks in the environment before HIP starts; the default of 4 makes streams share queues and a
- * wait then sits in front of the kernel it waits for until the timeout). */
-int nka_hip_p2p_mailbox(nka_hip_t a, void **mailbox);
-int nka_hip_p2p_attach_local(nka_hip_t a, void *const *mailboxes, int32_t nranks, int32_t rank);
-
-/* Run the installed all-reduce hook once on `count` doubles at device address
- * buf_dev, on the handle's stream (no-op without a hook): lets a launcher check
- * the communicator before the first update. */
+/* Position of this rank's slice in the global vector: slice `rank` of `nranks`, slices laid out in rank order (what
+ * nka_amd/dist.py and every front end of this build use).  Only the sharded reference-order sums read it;
+ * nka_hip_comm_init_rank sets it by itself. */
+int nka_hip_set_shard(nka_hip_t a, int32_t rank, int32_t nranks);
+/* Run the installed all-reduce hook once on `count` doubles at device address buf_dev, on the handle's stream (no-op
+ * without a hook): lets a launcher prove the communicator before the first update. */
 int nka_hip_allreduce_now(nka_hip_t a, double *buf_dev, int32_t count);
-
-/* 64-bit FNV-1a digest of the device-resident scalar state (flags, lists, h, c,
- * the reduced sums of the last update).  In a sharded run that state is
- * replicated: every rank must report the same digest after the same call
- * sequence -- the check SURVEY.md 8(e) asks for, since s == 0, the drop
- * decisions and the slot choices are taken independently per rank (F08:58-64).
- * Synchronises the stream. */
+/* 64-bit FNV-1a digest of the device-resident scalar state (flags, lists, h, c, the reduced sums of the last update).  In
+ * a sharded run that state is replicated: every rank must report the same digest after the same call sequence -- the
+ * check SURVEY.md 8(e) asks for, since s == 0, the drops and the slot choices are taken independently per rank. */
 int nka_hip_state_digest(nka_hip_t a, uint64_t *digest);
-
-/* Source compatibility with  call a%set_dot_prod(dot_prod)  (F08:209-219), the dp
- * argument of nka_init (C .h:4, .c:196,227-231) and the optional dp dummy of the
- * F95 nka_accel_update (src-F95/nka_type.F90:278-291): a user dot product over
- * HOST arrays.  With fn installed, the inner products of every update are
- * evaluated by handing host copies of this rank's slices to fn in the
- * reference's own order and with its operands -- fn(d,d) with d = w1 - f, then
- * on w1' = d/s the Gram row fn(w1', w_k) and the projections fn(f, w_j) -- while
- * the scalar step, the combine and the ring stores stay on the device.  fn must
- * return the GLOBAL dot product (as in the reference, F08:58-64); the all-reduce
- * hook is not applied on top.  The calls an update makes are EXACTLY the reference's, in the
- * reference's order, on the reference's operands: fn(d,d); if s != 0 the Gram row
- * fn(w1', w_k) for every older list entry in list order (F08:286-290); then -- after the
- * device has taken the drop decisions and the host has read the list back -- the
- * projections fn(f, w_j) for j = first ... last of the list as it then stands (F08:371).
- * A dp with side effects cannot tell the two apart (tests compare the call sequences).
- * 2+L vectors cross PCIe per update and the call
- * synchronises: a compatibility path, orders of magnitude slower than the
- * device sums.  fn = NULL restores them. */
-typedef double (*nka_hip_host_dot_fn)(void *ctx, int64_t n, const double *x, const double *y);
-int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx);
-
-/* ---- instrumentation ---------------------------------------------------- */
-
-/* Per-phase device times from HIP events recorded on the handle's stream.
- * nka_hip_set_timing(a, capacity) keeps the events of the last `capacity`
- * updates in a ring (0 switches timing off); recording never synchronises.
- * nka_hip_get_timing(a, back, ms) synchronises and returns, for the update
- * `back` calls ago (0 = most recent):  ms[0] = PA k_dots (with its final sums
- * and the all-reduce), ms[1] = k_solve, ms[2] = PB k_combine, ms[3] = whole
- * update, first kernel start -> last kernel end. */
-int nka_hip_set_timing(nka_hip_t a, int32_t capacity);
-int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]);
-/* With timing on, record the events of every stride-th update only (1..1024; the first update after the call is a
- * recorded one): four event records widen the kernel boundaries of an update by ~15 us, which matters below
- * n ~ 1e7.  get_timing then counts recorded updates. */
-int nka_hip_set_timing_stride(nka_hip_t a, int32_t stride);
-
-/* The A/B switches and measurement aids of the builder's lab (kernel-variant selection, launch geometry, phase
- * stamps, a PA-only timer) are NOT part of this library: they exist only in the diagnostic build
- * libnka_hip_diag.so (-DNKA_DIAGNOSTIC) and are declared in include/nka_hip_diag.h. */
-
-
-
-
-const char *nka_hip_last_error(void);
-/* Device pointers that cross this ABI are checked against their allocation before any launch
- * (a kernel reading past a buffer faults the GPU): memory handed out by nka_hip_vec_alloc from a
- * registry of live allocations, any other pointer with hipMemGetAddressRange on every call.
- * NKA_HIP_CHECK_POINTERS=cached (opt-in) remembers foreign spans that passed for 100 ms per
- * thread; a caller that frees such a buffer itself calls this to drop what was remembered.
- * NKA_HIP_CHECK_POINTERS=0 switches the checks off. */
-void nka_hip_invalidate_pointer_cache(void);
-/* "gfx950"-style name of the device the handle runs on, CU count. */
-int nka_hip_device_info(nka_hip_t a, char *name64, int32_t *num_cu);
-
-/* ---- vector primitives for the abstract-vector hooks -------------------- */
-/* Device implementations of the deferred procedures a concrete `vector` must
- * supply (F08V vector_class.F90:92-108; model: grid_vector_type.F90:86-197).
- * x, y, z are device pointers to n doubles; `ws` is a workspace obtained from
- * nka_hip_vec_workspace_create (holds the reduction partials).  Elementwise
- * results are rounded exactly like the Fortran expressions they replace. */
-typedef struct nka_hip_vec_ws *nka_hip_vec_ws_t;
-int nka_hip_vec_workspace_create(nka_hip_vec_ws_t *out, int32_t device, void *stream);
-int nka_hip_vec_workspace_destroy(nka_hip_vec_ws_t ws);
-int nka_hip_vec_alloc(nka_hip_vec_ws_t ws, int64_t n, double **out_dev);      /* clone: allocate */
-int nka_hip_vec_free(nka_hip_vec_ws_t ws, double *dev);
-int nka_hip_vec_copy(nka_hip_vec_ws_t ws, int64_t n, double *dst, const double *src);          /* copy_   */
-int nka_hip_vec_setval(nka_hip_vec_ws_t ws, int64_t n, double *x, double val);                  /* setval  */
-int nka_hip_vec_scale(nka_hip_vec_ws_t ws, int64_t n, double *x, double a);                     /* scale: a*x */
-int nka_hip_vec_update1(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x);  /* a*x + z */
-int nka_hip_vec_update2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x, double b); /* a*x + b*z */
-int nka_hip_vec_update3(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
-                        double b, const double *y);                                             /* a*x + b*y + z */
-int nka_hip_vec_update4(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
-                        double b, const double *y, double c);                                   /* a*x + b*y + c*z */
-int nka_hip_vec_dot(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *y, double *host_result); /* dot_ */
-int nka_hip_vec_norm2(nka_hip_vec_ws_t ws, int64_t n, const double *x, double *host_result);    /* norm2   */
-/* Batched forms (optional overrides of vector%dot_many / vector%update_many,
- * nka_amd/fortran/vector/vector_class.F90): ys / xs are HOST arrays of `count`
- * device pointers.  dot_many: vals[j] = <x, ys[j]> with x read once per 24
- * vectors.  update_many: z <- (a[j]*xs[j] + b[j]*ys[j]) + z for j = 0..count-1
- * in order -- the rounding of `count` successive update3_ calls -- with z read
- * and written once per 24 pairs. */
-int nka_hip_vec_dot_many(nka_hip_vec_ws_t ws, int64_t n, const double *x, const double *const *ys,
-                         int32_t count, double *host_vals);
-/* Both rows of the Gram update in one pass: vals0[j] = <x0, ys[j]>,
- * vals1[j] = <x1, ys[j]>, *cross = <x0, x1> (override of vector%dot_pair_many). */
-int nka_hip_vec_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *x0, const double *x1,
-                              const double *const *ys, int32_t count, double *host_vals0,
-                              double *host_vals1, double *host_cross);
-int nka_hip_vec_update_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                            const double *const *xs, const double *b, const double *const *ys, int32_t count);
-/* z <- a[j]*xs[j] + z for j = 0..count-1 in order (override of vector%axpy_many). */
-int nka_hip_vec_axpy_many(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                          const double *const *xs, int32_t count);
-/* Fused stages of the vector-flavour update (optional overrides of
- * vector%update_norm2 / scale_dot_pair_many / update_many_keep / axpy_many_keep;
- * each default body is the reference's own hook sequence, F08V:237-238, 255-264 +
- * 347, 336 + 374 + 382).  Elementwise results are rounded like those hook calls.
- *   update_norm2:        *host_norm = ||a*x + z||_2 ; store != 0: z <- a*x + z, store == 0:
- *                        z untouched -- the update is then applied by the next stage
- *   scale_dot_pair_many: [pre != 0: w <- pre_a*f + w ;] w <- a*w ; v <- a*v (subtract:
- *                        v <- (-1)*w + v) ; then with the new w: vals_w[j] = <w,ys[j]>,
- *                        vals_f[j] = <f,ys[j]>, *cross = <f,w>
- *   update_many_keep:    keep_in <- z ; z <- (a[j]*xs[j] + b[j]*ys[j]) + z in order ;
- *                        keep_out <- z          (keep_in / keep_out may be NULL)
- *   axpy_many_keep:      the same with z <- a[j]*xs[j] + z
- * With the norm stage deferring its store an update of the abstract path moves
- * 8n(11+3m) bytes in 3 passes: exactly the contract's figure. */
-int nka_hip_vec_update_norm2(nka_hip_vec_ws_t ws, int64_t n, double *z, double a, const double *x,
-                             int32_t store, double *host_norm);
-int nka_hip_vec_scale_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, double *w, double *v, double a,
-                                    int32_t subtract, int32_t pre, double pre_a, const double *f,
-                                    const double *const *ys, int32_t count, double *host_vals_w,
-                                    double *host_vals_f, double *host_cross);
-int nka_hip_vec_update_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                                 const double *const *xs, const double *b, const double *const *ys,
-                                 int32_t count, double *keep_in, double *keep_out);
-int nka_hip_vec_axpy_many_keep(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                               const double *const *xs, int32_t count, double *keep_in, double *keep_out);
-/* The scale-and-dot stage as a PURE READ, and the combine stage normalising the new pair itself
- * ("pending pair": entry 0 of its lists is the raw pair the first call left untouched):
- *   dot_pair_many_scaled:   with w' = a*(pre_a*f + w) [pre != 0; else a*w] formed in registers only:
- *                           vals_w[j] = <w',ys[j]>, vals_f[j] = <f,ys[j]>, *cross = <f,w'> ; any count (balanced groups of <= 24)
- *   update_many_keep_pend:  update_many_keep with xs[0] = w, ys[0] = v rewritten on the way as
- *                           w <- a*(pre_a*z_in + w) [pre], v <- a*v [, subtract: v <- (-1)*w + v]
- *   axpy_many_keep_pend:    axpy_many_keep for compact storage: xs[0] = v, pend_w = w, subtract implied
- * Same expressions as scale_dot_pair_many, hence the same bits; the new pair is read raw once more by
- * the combine instead of being written and re-read normalised: 8n(10+3m) bytes (8n(8+3m) with the fused
- * norm stage nka_hip_vec_diff_norm_dot_pair_many), the scale-and-dot
- * stage without a store stream. */
-int nka_hip_vec_dot_pair_many_scaled(nka_hip_vec_ws_t ws, int64_t n, const double *w, double a, int32_t pre,
-                                     double pre_a, const double *f, const double *const *ys, int32_t count,
-                                     double *host_vals_w, double *host_vals_f, double *host_cross);
-/* The norm stage and the scale-and-dot stage as ONE pure-read pass (override of
- * vector%update_norm2_dots): with d = a*x + z formed in registers only,
- *   *host_dd = <d,d>, vals_z[j] = <d,ys[j]>, vals_x[j] = <x,ys[j]>, *cross = <x,d>     (RAW sums; any count: balanced groups of <= 24 vectors,
- *                           each forming d in registers again)
- * The accelerator takes s = sqrt(<d,d>) and scales the d-sums by 1/s itself -- the Gram row of the normalised
- * pair as fl(<d,w_k>/s) instead of the sum of fl(d_i/s)*w_k,i, like pass PA of the array flavours: last-bit
- * differences, decisions and tolerance unaffected -- and hands the whole pending normalisation to the combine
- * stage (update_many_keep_pend / axpy_many_keep_pend with pre): 8n(8+3m) bytes and TWO reductions per update. */
-int nka_hip_vec_diff_norm_dot_pair_many(nka_hip_vec_ws_t ws, int64_t n, const double *z, double a, const double *x,
-                                        const double *const *ys, int32_t count, double *host_dd, double *host_vals_z,
-                                        double *host_vals_x, double *host_cross);
-int nka_hip_vec_update_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                                      const double *const *xs, const double *b, const double *const *ys,
-                                      int32_t count, double *keep_in, double *keep_out, double pend_a,
-                                      int32_t pend_pre, double pend_pre_a, int32_t pend_subtract);
-int nka_hip_vec_axpy_many_keep_pend(nka_hip_vec_ws_t ws, int64_t n, double *z, const double *a,
-                                    const double *const *xs, int32_t count, double *keep_in, double *keep_out,
-                                    double *pend_w, double pend_a, int32_t pend_pre, double pend_pre_a);
-/* ---- parallel-aware reductions of the device vector types ----------------
- * The vector flavour of the reference is distributed THROUGH the vector class: "the
- * implementation of the vector base class reduction methods will necessarily be
- * parallel-aware" (src-F08-vector/README.md:16-22).  For the device vector types of this
- * build (hip_block_vector, hip_grid_vector) that means: every sum a reduction hands back
- * to the host -- dot_, norm2 (before its square root), dot_many, dot_pair_many and the 1
- * resp. 2L+1 sums of the fused stages update_norm2 / scale_dot_pair_many -- is first
- * summed over all ranks.  The hooks hang on the WORKSPACE the vectors share:
- *   nka_hip_vec_set_allreduce       fn sums `count` doubles at a DEVICE address in place,
- *                                   ordered on the given hipStream_t (the type of
- *                                   nka_hip_set_allreduce); the sums are written there in a
- *                                   layout that depends only on the list length, never on
- *                                   the kernel variant a rank happened to take
- *   nka_hip_vec_comm_init_rank      built-in: an RCCL all-reduce on the workspace stream
- *                                   (unique id from nka_hip_comm_unique_id)
- *   nka_hip_vec_set_host_allreduce  fn sums `count` doubles in HOST memory in place, after
- *                                   the stream has been synchronised -- the natural place
- *                                   for an MPI_Allreduce of a caller that has no device-
- *                                   aware communication library
- * Either kind, both, or none may be installed (device hook first, then the host hook).
- * The result must carry the same bits on every rank: the Gram/Cholesky matrix and the
- * lists of the vector flavour live on the host of each rank and take the drop decisions
- * independently (F08V:269-321).  A rank whose slice is empty (n = 0) still takes part in
- * every collective.  A failing hook makes the reduction return NKA_HIP_ECOMM.
- * nka_hip_vec_allreduce_now runs the installed hooks once on `count` host values
- * (count <= 50), so that a launcher can prove the communicator before the first update. */
-typedef int (*nka_hip_host_allreduce_fn)(void *ctx, double *host_vals, int32_t count);
-/* Sums of the vector hooks in the REFERENCE'S ORDER (the abstract-vector counterpart of nka_hip_set_sum_order).  With
- * NKA_HIP_SUMS_REFERENCE_ORDER nka_hip_vec_dot -- and nka_hip_vec_norm2, which is its square root -- sums element after
- * element, one rounding per product and per addition, as `sum(x*y)` over the elements does
- * (/root/reference/src-F08-vector/grid_vector_type.F90:170-197); the batched and stage reductions of this library sum in
- * blocks and return NKA_HIP_ESTATE then: a vector type that honours the switch (hip_block_vector, hip_grid_vector) runs
- * the default bodies of the batched / stage hooks, i.e. the reference's own sequence of deferred hook calls
- * (vector_class.F90), and the vector flavour of the accelerator returns the bits of the reference on the same vector
- * type.  Works with the parallel-aware reductions too (ordered partial sums per rank, summed by the hook -- the
- * reference's own parallel contract).  n sequential additions per dot product: a validation mode.
- * NKA_HIP_SUMS_BLOCKED (= _AUTO, the default): the fast reductions.  NKA_HIP_SUMS_BLOCKED_ROUNDED: the fast reductions, but the device
- * vector types keep the norm stage a pass of its own, so that the Gram row is summed on the ROUNDED pair (see nka_hip_set_sum_order). */
-int nka_hip_vec_set_sum_order(nka_hip_vec_ws_t ws, int32_t order);
-int nka_hip_vec_get_sum_order(nka_hip_vec_ws_t ws);      /* NKA_HIP_SUMS_REFERENCE_ORDER or NKA_HIP_SUMS_BLOCKED; <0 on error */
-int nka_hip_vec_set_allreduce(nka_hip_vec_ws_t ws, nka_hip_allreduce_fn fn, void *ctx);
-int nka_hip_vec_set_host_allreduce(nka_hip_vec_ws_t ws, nka_hip_host_allreduce_fn fn, void *ctx);
-int nka_hip_vec_comm_init_rank(nka_hip_vec_ws_t ws, const void *id128, int32_t nranks, int32_t rank);
-int nka_hip_vec_comm_destroy(nka_hip_vec_ws_t ws);
-int nka_hip_vec_allreduce_now(nka_hip_vec_ws_t ws, double *host_vals, int32_t count);
-
-int nka_hip_vec_h2d(nka_hip_vec_ws_t ws, int64_t n, double *dst_dev, const double *src_host);
-int nka_hip_vec_d2h(nka_hip_vec_ws_t ws, int64_t n, double *dst_host, const double *src_dev);
 
 #ifdef __cplusplus
 }

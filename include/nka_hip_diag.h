@@ -9,7 +9,8 @@
 #ifndef NKA_HIP_DIAG_H
 #define NKA_HIP_DIAG_H
 
-#include "nka_hip.h"
+#include "nka_hip_ext.h"
+#include "nka_hip_vec.h"
 
 #ifdef __cplusplus
 extern "C" {

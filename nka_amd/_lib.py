@@ -14,7 +14,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_
 HOST_DOT_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 
-# name -> (restype, argtypes): every symbol include/nka_hip.h declares
+# name -> (restype, argtypes): every symbol include/nka_hip.h (core), nka_hip_ext.h and nka_hip_vec.h declare
 SIGNATURES = {
     "nka_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_void_p]),
     "nka_hip_destroy": (C.c_int, [C.c_void_p]),

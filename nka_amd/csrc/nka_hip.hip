@@ -8,10 +8,13 @@
 // it can know without looking: whether a pair is pending, and an upper bound on
 // the list length (used to pick the unroll width of PA/PB).
 #include "../../include/nka_hip.h"
+#include "../../include/nka_hip_ext.h"
+#include "../../include/nka_hip_vec.h"
 #ifdef NKA_DIAGNOSTIC
 #include "../../include/nka_hip_diag.h"
 #endif
 #include "nka_kernels.hpp"
+#include "host_logic.hpp"
 
 #include <hip/hip_runtime.h>
 #include "rccl_dl.hpp"
@@ -208,9 +211,10 @@ struct nka_hip_state {
   // allocations that a table entry may name (callers' buffers handed in, the two extra allocations); `lent` = the free
   // buffers handed to the caller for its NEXT input (they may lie anywhere, the slot-major allocations included).  A
   // buffer may enter an update only if the library does not hold it: it is lent, or it is foreign to both.
-  std::set<const double *> taken, lent;
+  nka_host::BufferBook book;          // .taken / .lent (host_logic.hpp)
   bool captured = false;      // the handle's stream was seen capturing: replays re-issue the scalar step with the ARGUMENTS of
                               // the capture, so from then on it loads the slot -> buffer tables instead of computing them
+  bool solve63_raised = false;   // k_solve_rows<63> has its dynamic-LDS limit raised on this handle's device
   bool poisoned = false;      // a HIP call failed AFTER the scalar step of an update was enqueued: the lists on the device
                               // are ahead of the vectors; every later call but destroy returns NKA_HIP_ESTATE
   // launch geometry
@@ -501,28 +505,12 @@ int launch_combine_win(int flavor, int width, const nka_hip_state *a, double *f,
   }
 }
 
-// A list of `total` > kMaxPerPass entries in the fewest passes of BALANCED widths (33 -> 17 + 16, 70 -> 24 + 23 + 23): every
-// pass then runs the rolling-window kernel at (nearly) its exact width instead of one full pass of 32 and one that is mostly
-// padding (measured in round 5, profiles/r05/multipass.txt: mvec = 33 at 0.58 of the roofline against 0.76 at mvec = 32).
-static inline int balanced_passes(int total) { return (total + kMaxPerPass - 1) / kMaxPerPass; }
-// The widths whose only ring is the whole width (win_ring / win_ring_pairs: primes) AND large: 23, 29, 31.
-static inline bool heavy_prime(int w) { return w == 23 || w == 29 || w == 31; }
-// (22 and 26 -- twice a prime: no ring in win_ring's list either -- were tried the same way in round 5: padding to 24 / 28 makes PA
-//  3-4 % SLOWER and the update +1...2 % (compact), -1 % (src-F08): not kept, profiles/r05/multipass.txt)
-// widths[0..np): balanced, then one vector moved between two passes wherever that removes a heavy prime without making another
-static inline void balanced_widths(int total, int np, int *w) {
-  for (int p = 0; p < np; p++) w[p] = total / np + (p < total % np ? 1 : 0);
-  for (int i = 0; i < np; i++) {
-    if (!heavy_prime(w[i])) continue;
-    for (int j = 0; j < np; j++) {
-      if (j == i) continue;
-      if (w[i] + 1 <= kMaxPerPass && w[j] > 1 && !heavy_prime(w[j] - 1)) { w[i]++; w[j]--; break; }          // (w[i] + 1 is even)
-      if (w[j] + 1 <= kMaxPerPass && !heavy_prime(w[j] + 1) && !heavy_prime(w[i] - 1)) { w[i]--; w[j]++; break; }
-    }
-  }
-}
-
-int round_up4(int x) { return ((std::max(x, 1) + 3) / 4) * 4; }
+// balanced_passes / balanced_widths / heavy_prime / round_up4: host_logic.hpp (pure arithmetic, checked under sanitizers on the CPU)
+using nka_host::balanced_passes;
+using nka_host::balanced_widths;
+using nka_host::heavy_prime;
+using nka_host::round_up4;
+static_assert(nka_host::kMaxPerPass == kMaxPerPass && nka_host::kListWordLenBits == kListWordLenBits, "host_logic.hpp out of step with nka_kernels.hpp");
 
 // Optional ROCTx ranges around the phases of an update (NKA_HIP_ROCTX=1), for
 // rocprofv3 --marker-trace timelines.  The library is looked up at run time so
@@ -565,20 +553,9 @@ constexpr int kTimingEvents = 4;
 // Exact whenever the caller has synchronised with the previous update (u == seq): every solver does, once per
 // iteration, to read its residual norm.  A caller that never synchronises gets the old bound.
 int list_bound_now(nka_hip_state *a) {
-  int ub = a->list_ub;
-  if (a->word_off || !a->list_word) return ub;
+  if (a->word_off || !a->list_word) return a->list_ub;
   const unsigned long long w = __atomic_load_n(a->list_word, __ATOMIC_ACQUIRE);
-  const int64_t u = (int64_t)(w >> kListWordLenBits);
-  if (u <= a->word_valid_after || u > a->seq) return ub;
-  int64_t len = (int64_t)(w & ((1ull << kListWordLenBits) - 1)) + (a->seq - u);
-  size_t keep = 0;
-  for (int64_t r : a->relaxed_after)
-    if (r >= u) {
-      len--;
-      a->relaxed_after[keep++] = r;
-    }
-  a->relaxed_after.resize(keep);      // older relax calls are part of every word from now on
-  return (int)std::min<int64_t>(ub, std::max<int64_t>(len, 0));
+  return nka_host::list_bound_from_word(a->list_ub, w, a->seq, a->word_valid_after, a->relaxed_after);      // host_logic.hpp
 }
 
 constexpr size_t kMaxDynamicLds = 160 * 1024;   // gfx950: LDS per CU = per workgroup maximum
@@ -981,10 +958,14 @@ static int enqueue_solve(nka_hip_t a, int mode, long long swap_w = kNoBuffer, lo
     else if (nl <= 48) ROWS(48);
     else {
       // 49..63 list entries (mvec 48..62): the working arrays exceed the 64 KiB a kernel gets without asking
-      static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_rows<63>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           (int)solve_wave_smem_bytes(kSolveWaveMax - 1));
-      if (raised != hipSuccess) return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+      // (once per HANDLE, i.e. per device -- a process-wide static would serve only the first GPU of a process)
+      if (!a->solve63_raised) {
+        const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_rows<63>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)solve_wave_smem_bytes(kSolveWaveMax - 1));
+        if (raised != hipSuccess) return fail(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+        a->solve63_raised = true;
+      }
       ROWS(63);
     }
 #undef ROWS
@@ -1230,14 +1211,7 @@ static bool ordered_sums(const nka_hip_state *a) {
 // Does [p, p + n) touch memory the library holds -- the slot-major allocations or a buffer it has taken over -- that it
 // has NOT lent to the caller?  (Ordered sets: a caller that hands over a fresh buffer every iteration makes them long.)
 static bool held_by_library(const nka_hip_state *a, const double *p) {
-  if (a->lent.count(p)) return false;
-  const int64_t n = std::max<int64_t>(a->n, 1);
-  auto overlaps = [&](const double *q, int64_t len) { return p < q + len && q < p + n; };
-  const int64_t block = a->vs.stride * (int64_t)(a->mvec + 1);
-  if (overlaps(a->vs.w, block) || overlaps(a->vs.v, block)) return true;
-  // every taken buffer holds n doubles: one of them overlaps [p, p + n) iff its base lies in (p - n, p + n)
-  auto it = a->taken.upper_bound(p - n);
-  return it != a->taken.end() && *it < p + n;
+  return a->book.held(p, a->n, a->vs.w, a->vs.v, a->vs.stride * (int64_t)(a->mvec + 1));
 }
 
 // Reference-order sums of a SHARDED accelerator (validation mode).  The reference's sum over the global
@@ -1340,6 +1314,7 @@ static int ordered_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
 }
 
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
+static int p2p_status_after_sync(nka_hip_t a);
 
 int nka_hip_accel_update(nka_hip_t a, double *f) { return update_impl(a, f, kNoBuffer, kNoBuffer); }
 
@@ -1383,6 +1358,17 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
     else if (cs != hipStreamCaptureStatusNone) a->captured = a->word_off = true;
+  }
+  if (a->captured) {
+    // NOT SUPPORTED (nka_hip_ext.h, table of combinations): a capture of an update whose sums pass through the HOST -- a
+    // caller's all-reduce hook or dot product is a host callback that a replay would not call again, silently wrong results
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce && a->allreduce != p2p_allreduce;
+    if (cs != hipStreamCaptureStatusNone && (user_hook || a->host_dot))
+      return fail(NKA_HIP_EINVAL, "accel_update: cannot be captured into a graph with a caller's all-reduce hook or dot product "
+                                  "installed (host callbacks: a replay would not call them); the built-in RCCL hook and the "
+                                  "peer-to-peer exchange can be captured");
   }
   a->list_ub = list_bound_now(a);
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
@@ -1519,7 +1505,7 @@ int nka_hip_accel_update_host(nka_hip_t a, double *f_host) {
   if (int rc = nka_hip_accel_update(a, a->f_stage)) return rc;
   HIP_TRY(hipMemcpyAsync(f_host, a->f_stage, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
-  return 0;
+  return p2p_status_after_sync(a);
 }
 
 // The buffers the last out-of-place update displaced become the spares of the next one.  They are known on the device
@@ -1532,7 +1518,10 @@ static int collect_spares(nka_hip_t a) {
       return a->list_word && !a->word_off &&
              (int64_t)__atomic_load_n(a->list_word + 3, __ATOMIC_ACQUIRE) == a->swap_seq;
     };
-    if (!fresh()) HIP_TRY(hipStreamSynchronize(a->stream));
+    if (!fresh()) {
+      HIP_TRY(hipStreamSynchronize(a->stream));
+      if (int rc = p2p_status_after_sync(a)) return rc;
+    }
     long long ow = kNoBuffer, ov = kNoBuffer;
     if (fresh()) {
       ow = (long long)a->list_word[1];
@@ -1560,7 +1549,7 @@ static int collect_spares(nka_hip_t a) {
         return fail(NKA_HIP_ENOMEM, std::string("accel_update_swap: hipMalloc of a spare buffer: ") + hipGetErrorString(e));
       }
       a->extra_allocs.push_back(q);
-      a->taken.insert(static_cast<const double *>(q));
+      a->book.taken.insert(static_cast<const double *>(q));
       *p = static_cast<double *>(q);
     }
   }
@@ -1592,12 +1581,18 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
   a->swapped = true;
   if (int rc = update_impl(a, in, buffer_offset(a, in), buffer_offset(a, vnew))) return rc;
   if (in) {
-    a->lent.erase(in);
+    a->book.lent.erase(in);
     const int64_t block = a->vs.stride * (int64_t)(a->mvec + 1);
     const bool inside = (in >= a->vs.w && in < a->vs.w + block) || (in >= a->vs.v && in < a->vs.v + block);
-    if (!inside) a->taken.insert(in);
+    if (!inside) a->book.taken.insert(in);
   }
-  if (give_w) a->lent.insert(give_w);
+  if (give_w) {
+    a->book.lent.insert(give_w);
+    // what is handed out is no longer "taken over" -- otherwise the set only grows (a caller that hands in a fresh
+    // buffer per iteration), and a later foreign buffer overlapping a FREED one's old range would be refused.  The library's
+    // own extra allocations stay (freed at destroy; they come back through `lent`).
+    if (std::find(a->extra_allocs.begin(), a->extra_allocs.end(), (void *)give_w) == a->extra_allocs.end()) a->book.taken.erase(give_w);
+  }
   a->swap_pending = true;
   a->swap_seq = a->seq;
   a->spare_w = a->spare_v = nullptr;
@@ -1609,6 +1604,20 @@ int nka_hip_accel_update_swap(nka_hip_t a, double **f_io, const double **f_acc) 
 
 // ---- queries --------------------------------------------------------------------
 
+// A gather of the peer-to-peer exchange that gave up stored NaNs and raised the status word; the scalar step and PB then ran
+// on the NaNs.  Checked wherever the host has just synchronised the stream anyway (a caller that loops on
+// accel_update_host, the out-of-place entry or get_timing alone must not go on with NaNs and NKA_HIP_OK); the handle is
+// poisoned: every later update returns NKA_HIP_ESTATE.
+static int p2p_status_after_sync(nka_hip_t a) {
+  if (!a->p2p.base) return 0;
+  int st = 0;
+  HIP_TRY(hipMemcpy(&st, a->p2p.status, sizeof st, hipMemcpyDeviceToHost));
+  if (st == 0) return 0;
+  a->poisoned = true;
+  return fail(NKA_HIP_ECOMM, "peer-to-peer exchange: a rank's sums did not arrive in time (nka_hip_p2p_attach); "
+                             "the state of this handle is not usable any more");
+}
+
 static int fetch_state(nka_hip_t a, std::vector<int32_t> &ic, std::vector<double> &dc) {
   HIP_TRY(hipSetDevice(a->device));
   ic.resize(a->ctl.ic_count());
@@ -1616,13 +1625,7 @@ static int fetch_state(nka_hip_t a, std::vector<int32_t> &ic, std::vector<double
   HIP_TRY(hipMemcpyAsync(ic.data(), a->ctl.ic, sizeof(int32_t) * ic.size(), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipMemcpyAsync(dc.data(), a->ctl.dc, sizeof(double) * dc.size(), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
-  if (a->p2p.base) {           // a gather of the peer-to-peer exchange that gave up stored NaNs and raised the status word
-    int st = 0;
-    HIP_TRY(hipMemcpy(&st, a->p2p.status, sizeof st, hipMemcpyDeviceToHost));
-    if (st != 0) return fail(NKA_HIP_ECOMM, "peer-to-peer exchange: a rank's sums did not arrive in time (nka_hip_p2p_attach); "
-                                           "the state of this handle is not usable any more");
-  }
-  return 0;
+  return p2p_status_after_sync(a);
 }
 
 int nka_hip_num_vec(nka_hip_t a) {
@@ -2019,6 +2022,7 @@ int nka_hip_get_timing(nka_hip_t a, int32_t back, float ms[4]) {
     return fail(NKA_HIP_ESTATE, "no such timed update recorded");
   HIP_TRY(hipSetDevice(a->device));
   HIP_TRY(hipStreamSynchronize(a->stream));
+  if (int rc = p2p_status_after_sync(a)) return rc;
   const int slot = (int)((a->timing_count - 1 - back) % a->timing_cap);
   hipEvent_t *e = a->ev.data() + (size_t)slot * kTimingEvents;
   HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
@@ -2058,9 +2062,6 @@ int nka_hip_set_grid(nka_hip_t a, int32_t pa, int32_t pb) {
   return 0;
 }
 
-// Measurement aid: the PA launches of the NEXT update, `reps` times back to back on the
-// handle's stream, timed with HIP events (mean ms per repetition).  PA only writes
-// scratch (partials, red[]), so the state is unchanged.
 // start + x[0]*y[0] + x[1]*y[1] + ... as the per-sum reference-order kernel forms it (k_chain_sums on one workgroup),
 // over ANY two device arrays: the test bench of chain_block_summary / _apply (walk = 1: every block element after element).
 int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64_t n, double start, int32_t walk, double *sum,
@@ -2070,7 +2071,11 @@ int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64
   Vecs vs = a->vs;
   vs.n = n;
   double *slot = a->ctl.red() + 2 + a->mvec;
-  hipEvent_t e0, e1;
+  struct Events {          // (destroyed on EVERY exit)
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~Events() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
+  } ev;
+  hipEvent_t &e0 = ev.e[0], &e1 = ev.e[1];
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipMemcpyAsync(slot, &start, sizeof(double), hipMemcpyHostToDevice, a->stream));
@@ -2098,11 +2103,12 @@ int nka_hip_debug_chain_sum(nka_hip_t a, const double *x, const double *y, int64
   HIP_TRY(hipMemcpyAsync(sum, slot, sizeof(double), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
   if (ms) HIP_TRY(hipEventElapsedTime(ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   return 0;
 }
 
+// Measurement aid: the PA launches of the NEXT update, `reps` times back to back on the
+// handle's stream, timed with HIP events (mean ms per repetition).  PA only writes
+// scratch (partials, red[]), so the state is unchanged.
 int nka_hip_debug_time_pa(nka_hip_t a, const double *f, int32_t reps, float *ms_mean) {
   if (!a || !f || !ms_mean || reps < 1) return fail(NKA_HIP_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(a->device));

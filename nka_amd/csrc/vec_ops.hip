@@ -9,7 +9,10 @@
 // with -ffp-contract=off so  a*x + b*y + z  rounds as the Fortran expression
 // ((a*x) + (b*y)) + z  does.
 #include "../../include/nka_hip.h"
+#include "../../include/nka_hip_ext.h"
+#include "../../include/nka_hip_vec.h"
 #include "nka_kernels.hpp"
+#include "host_logic.hpp"
 #include "rccl_dl.hpp"
 
 #include <hip/hip_runtime.h>
@@ -18,6 +21,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 
 using namespace nka;
@@ -198,20 +203,31 @@ static int launch_dot_ordered(hipStream_t s, int64_t n, const double *x, const d
     hipLaunchKernelGGL(k_dot_ordered, dim3(1), dim3(kBlock), 0, s, n, x, y, partials);
     return 0;
   }
-  static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dot_chain),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);
-  if (raised != hipSuccess)
-    return nka_detail::set_error(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+  // (per DEVICE, not once per process -- a process may drive several GPUs through several workspaces)
+  static std::mutex raised_lock;
+  static std::set<int> raised_on;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  {
+    std::lock_guard<std::mutex> g(raised_lock);
+    if (!raised_on.count(dev)) {
+      const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dot_chain),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);
+      if (raised != hipSuccess)
+        return nka_detail::set_error(NKA_HIP_EHIP, std::string("raising the dynamic LDS limit failed: ") + hipGetErrorString(raised));
+      raised_on.insert(dev);
+    }
+  }
   hipLaunchKernelGGL(k_dot_chain, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, n, x, y, partials);
   return 0;
 }
 
 // ---- batched hooks: one pass for many dots / many axpys -----------
-constexpr int kManyMax = 24;   // vectors per launch (unroll widths 4, 8, ..., 24; window kernels: every width 1..24); longer lists run several launches
+constexpr int kManyMax = nka_host::kManyMax;   // = 24 vectors per launch (unroll widths 4, 8, ..., 24; window kernels: every width 1..24); longer lists run several launches
 // ... of BALANCED widths (round 5; 25 = 13 + 12, not 24 + 1: a launch that is nearly all padding costs as much as a full one --
 // profiles/r05/multipass.txt): group p of a list of `count` entries
-static inline int many_groups(int count) { return count <= kManyMax ? 1 : (count + kManyMax - 1) / kManyMax; }
-static inline int many_group_width(int count, int p) { const int np = many_groups(count); return count / np + (p < count % np ? 1 : 0); }
+using nka_host::many_groups;            // host_logic.hpp (pure arithmetic, checked under sanitizers on the CPU)
+using nka_host::many_group_width;
 struct ManyArgs {
   const double *x[kManyMax];
   const double *y[kManyMax];

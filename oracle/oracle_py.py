@@ -38,8 +38,10 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "libnka_oracle.so")
-        if not os.path.exists(path):
+        path = os.environ.get("NKA_ORACLE_LIB") or os.path.join(HERE, "libnka_oracle.so")     # (NKA_ORACLE_LIB: the sanitizer
+        if not os.path.exists(path):                                                          #  build, oracle/Makefile `asan`)
+            if os.environ.get("NKA_ORACLE_LIB"):
+                raise FileNotFoundError(path)
             build(ref=False)
         L = C.CDLL(path)
         L.nka_oracle_init.restype = C.c_void_p

@@ -34,7 +34,7 @@ shows what that distance consists of (at n = 61 698 it is the REFERENCE's sequen
 are 2.8e-9 from the truth, the device 1.7e-11).  A test that supplies neither truth nor spread
 keeps the pivot rule (base above a smallest pivot of 0.5, base / pivot^2 below) and is labelled so.
 Every check records what it saw; the worst per test is printed at the end of the run and written
-to gpurun_out/parity_worst.json (err_dev_exact and err_ref_exact side by side).
+to parity_worst.json under dump_dir() -- gpurun_out/ on a GPU box -- (err_dev_exact and err_ref_exact side by side).
 """
 import json
 import os
@@ -289,10 +289,25 @@ def record(err, tol, key):
     return err
 
 
+def dump_dir(root):
+    """Where the worst-error record goes: $NKA_PARITY_OUT if set (os.devnull: nowhere); <root>/gpurun_out on a GPU box
+    (gpurun exports GRAFT_REPO_ROOT there and merges that directory back); otherwise a directory under the system's temp
+    dir -- a CPU run of the suite leaves the tree as it found it."""
+    env = os.environ.get("NKA_PARITY_OUT")
+    if env:
+        return None if env == os.devnull else env
+    if os.environ.get("GRAFT_REPO_ROOT"):
+        return os.path.join(root, "gpurun_out")
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), "nka_parity")
+
+
 def dump(root):
     if not WORST:
         return None
-    out = os.path.join(root, "gpurun_out")
+    out = dump_dir(root)
+    if out is None:
+        return None
     try:
         os.makedirs(out, exist_ok=True)
         path = os.path.join(out, "parity_worst.json")

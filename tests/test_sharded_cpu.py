@@ -49,21 +49,35 @@ def test_sharded_contract_world_size_n_gloo(world):
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """include/nka_hip.h vs the built library: loadable on a CPU-only box and
-    exporting every entry point the header declares (no compute calls here)."""
+    """include/nka_hip.h (core) + nka_hip_ext.h + nka_hip_vec.h vs the built library: loadable on a CPU-only box and
+    exporting every entry point the headers declare (no compute calls here)."""
     import re
     import nka_amd
     from nka_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "nka_hip.h")).read() + \
-        open(os.path.join(ROOT, "include", "nka_example_dev.h")).read()
-    declared = set(re.findall(r"\b(nka_(?:hip|ex)_[a-z0-9_]+)\s*\(", hdr)) - {"nka_hip_allreduce_fn", "nka_hip_host_allreduce_fn", "nka_hip_host_dot_fn"}
+    def names(*hdrs):
+        text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in hdrs)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)                    # declarations only, not the prose
+        return set(re.findall(r"\b(nka_(?:hip|ex)_[a-z0-9_]+)\s*\(", text))
+    # the CORE (what a caller of the reference needs: VERDICT r5 item 6) is small and holds no optional machinery
+    core = names("nka_hip.h")
+    assert len(core) <= 30, sorted(core)
+    assert not any(n.startswith(("nka_hip_p2p_", "nka_hip_vec_", "nka_hip_get_", "nka_hip_set_timing")) or
+                   n in ("nka_hip_accel_update_swap", "nka_hip_capture_safe", "nka_hip_list_bound")
+                   for n in core - {"nka_hip_vec_len", "nka_hip_vec_tol"}), sorted(core)      # (the accessors vec_len / vec_tol of F08:238-246)
+    for need in ("nka_hip_create", "nka_hip_destroy", "nka_hip_clone", "nka_hip_accel_update", "nka_hip_accel_update_host",
+                 "nka_hip_restart", "nka_hip_relax", "nka_hip_set_vec_tol", "nka_hip_num_vec", "nka_hip_max_vec", "nka_hip_vec_len",
+                 "nka_hip_vec_tol", "nka_hip_defined", "nka_hip_set_host_dot", "nka_hip_set_allreduce", "nka_hip_comm_init_rank",
+                 "nka_hip_set_sum_order", "nka_hip_last_error"):
+        assert need in core, need
+    assert sum(1 for _ in open(os.path.join(ROOT, "include", "nka_hip.h"))) <= 250
+    declared = names("nka_hip.h", "nka_hip_ext.h", "nka_hip_vec.h", "nka_example_dev.h")
+    assert not core & names("nka_hip_ext.h") and not core & names("nka_hip_vec.h")          # each entry declared once
     L = nka_amd.load()
     for name in sorted(declared):
         assert hasattr(L, name), f"libnka_hip.so lacks {name}"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     # the builder's lab is NOT in the product: include/nka_hip_diag.h <-> libnka_hip_diag.so only
-    dh = open(os.path.join(ROOT, "include", "nka_hip_diag.h")).read()
-    lab = set(re.findall(r"\b(nka_hip_[a-z0-9_]+)\s*\(", dh))
+    lab = names("nka_hip_diag.h")
     assert lab == set(_lib.DIAG_SIGNATURES), lab ^ set(_lib.DIAG_SIGNATURES)
     D = _lib.load_diag()
     for name in sorted(lab):
@@ -107,3 +121,30 @@ def test_public_headers_compile_as_c_and_cxx(tmp_path):
             p = subprocess.run([comp, std, "-Wall", "-Werror", "-Wno-unused-function", "-fsyntax-only", f"-I{inc}", str(src)],
                                capture_output=True, text=True)
             assert p.returncode == 0, (hdr, lang, p.stderr[-2000:])
+
+
+def test_integration_md_c_binding_compiles_against_the_core_header_alone(tmp_path):
+    """the binding a maintainer of the reference adds (the C front end) needs
+    include/nka_hip.h and nothing else; the opt-in out-of-place loop shown after it needs include/nka_hip_ext.h.  Both
+    snippets are taken from the document and compiled (syntax only); include/nka_c_compat.h -- the shipped form of the
+    first -- must not pull the optional headers in either."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```c\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 2 and '#include "nka_hip.h"' in blocks[0] and "nka_hip_accel_update_swap" in blocks[1]
+    inc = os.path.join(ROOT, "include")
+    core = tmp_path / "core_only.c"
+    core.write_text("#define NKA_HIP_EXT_H\n#define NKA_HIP_VEC_H\n"            # (the optional headers, had they been included, would be empty)
+                    "static void nka_compat_check_(int rc, const char *what) { (void)rc; (void)what; }\n"
+                    "#include <stdint.h>\nstatic double nka_compat_dp_trampoline_(void *c, int64_t n, const double *x, const double *y)"
+                    " { (void)c; (void)n; (void)x; (void)y; return 0.0; }\n" + blocks[0] + "\nint main(void) { return 0; }\n")
+    ext = tmp_path / "with_ext.c"
+    ext.write_text('#include "nka_hip_ext.h"\nextern double *my_device_buffer; extern double *x; extern nka_hip_t a;\n'
+                   "void compute_correction(double *, double *); void update_solution(double *, const double *);\n"
+                   "void loop(void) {\n" + blocks[1] + "}\n")
+    for src in (core, ext):
+        p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-unused-function", "-fsyntax-only", f"-I{inc}", str(src)],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, (src.name, p.stderr[-2000:])
+    compat = open(os.path.join(inc, "nka_c_compat.h")).read()
+    assert '#include "nka_hip.h"' in compat and "nka_hip_ext.h" not in compat and "nka_hip_vec.h" not in compat

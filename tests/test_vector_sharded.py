@@ -110,10 +110,16 @@ def host_driver(tmp_path_factory):
     test-only vector type (no libnka_hip.so, no GPU)."""
     out = tmp_path_factory.mktemp("sharded_host")
     vec = os.path.join(ROOT, "nka_amd", "fortran", "vector")
-    subprocess.run(["gcc", "-O2", "-c", "-o", str(out / "shm_allreduce.o"), os.path.join(ROOT, "tests", "c", "shm_allreduce.c")],
+    # NKA_TEST_SANITIZE=1 (tests/test_sanitizers_cpu.py): the C all-reduce instrumented with AddressSanitizer + UBSan (clang:
+    # the same runtime amdflang links) and the allocator of the whole executable interposed.  flang itself emits no
+    # instrumentation for Fortran statements (probed in round 6: an out-of-bounds store goes unreported), so this covers
+    # tests/c/shm_allreduce.c, the heap and the libc calls of the run, not the array statements of the Fortran modules.
+    san = ["-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if os.environ.get("NKA_TEST_SANITIZE") == "1" else []
+    cc = ["/opt/rocm/lib/llvm/bin/clang", "-O1"] + san if san else ["gcc", "-O2"]
+    subprocess.run(cc + ["-c", "-o", str(out / "shm_allreduce.o"), os.path.join(ROOT, "tests", "c", "shm_allreduce.c")],
                    check=True)
     exe = out / "sharded_host_driver"
-    subprocess.run([FC, "-O2", "-ffp-contract=off", "-cpp", "-module-dir", str(out), "-o", str(exe),
+    subprocess.run([FC, "-O2", "-ffp-contract=off", "-cpp"] + san + ["-module-dir", str(out), "-o", str(exe),
                     os.path.join(vec, "vector_class.F90"), os.path.join(vec, "nka_type.F90"),
                     os.path.join(ROOT, "tests", "fortran", "host_slice_vector_type.F90"),
                     os.path.join(ROOT, "tests", "fortran", "sharded_host_driver.F90"), str(out / "shm_allreduce.o")],
