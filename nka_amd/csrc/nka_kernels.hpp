@@ -1334,8 +1334,12 @@ __device__ __forceinline__ ChainSum chain_decode(const Ctl &ctl, const Vecs &vs,
 // i.e. 1 KiB per wave instruction ...
 constexpr int kChainPairs = kChainLaneElems / 2;       // 16-byte loads per thread and vector
 static_assert(kChainPairs == 8, "the pair mapping of chain_load_block / chain_store_block assumes 16 elements per lane");
+// xf = f; xb = the SECOND operand of the kind -- the older w (kind FW) or the pending w1 (every other kind); xc = the older w
+// of kind W1W.  (Round 6: three arrays named after the vectors, each written under its own branch, made the compiler sink the
+// stores of two branches into one store through a pointer phi -- the arrays then lived partly in scratch, 48-80 bytes per
+// lane in k_chain_sums / k_chain_blocks / k_chain_apply.  One destination per load, the ADDRESS selected instead.)
 struct ChainBlockRegs {
-  typename VecT<2>::type xf[kChainPairs], xw1[kChainPairs], xw[kChainPairs];
+  typename VecT<2>::type xf[kChainPairs], xb[kChainPairs], xc[kChainPairs];
 };
 __device__ __forceinline__ void chain_load_block(const ChainSum &cs, ChainBlockRegs &r, int64_t e0, int lane, bool full) {
   using V2 = typename VecT<2>::type;
@@ -1349,17 +1353,12 @@ __device__ __forceinline__ void chain_load_block(const ChainSum &cs, ChainBlockR
     return v;
   };
   const int64_t i0 = e0 + 2 * lane;
-  if (cs.kind == kChainKindFW) {
+  const double *const second = cs.kind == kChainKindFW ? cs.wk : cs.w1;
 #pragma unroll
-    for (int j = 0; j < kChainPairs; j++) { r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw[j] = ldpair(cs.wk, i0 + j * 128); }
-  } else if (cs.kind == kChainKindW1W) {
+  for (int j = 0; j < kChainPairs; j++) { r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xb[j] = ldpair(second, i0 + j * 128); }
+  if (cs.kind == kChainKindW1W) {
 #pragma unroll
-    for (int j = 0; j < kChainPairs; j++) {
-      r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw1[j] = ldpair(cs.w1, i0 + j * 128); r.xw[j] = ldpair(cs.wk, i0 + j * 128);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kChainPairs; j++) { r.xf[j] = ldpair(cs.f, i0 + j * 128); r.xw1[j] = ldpair(cs.w1, i0 + j * 128); }
+    for (int j = 0; j < kChainPairs; j++) r.xc[j] = ldpair(cs.wk, i0 + j * 128);
   }
 }
 // ... and their rounded products where the lane that owns them reads them (blk: the block's kChainBlockLds doubles of LDS)
@@ -1370,14 +1369,14 @@ __device__ __forceinline__ void chain_store_block(const ChainSum &cs, const Chai
 #pragma unroll
   for (int j = 0; j < kChainPairs; j++) {
     V2 p;
-    if (cs.kind == kChainKindFW) { p.x = r.xf[j].x * r.xw[j].x; p.y = r.xf[j].y * r.xw[j].y; }
+    if (cs.kind == kChainKindFW) { p.x = r.xf[j].x * r.xb[j].x; p.y = r.xf[j].y * r.xb[j].y; }
     else {
-      const double d0 = r.xw1[j].x - r.xf[j].x, d1 = r.xw1[j].y - r.xf[j].y;   // F08:266 ((-1)*f + w1 in F08V:237: same bits)
+      const double d0 = r.xb[j].x - r.xf[j].x, d1 = r.xb[j].y - r.xf[j].y;   // F08:266 ((-1)*f + w1 in F08V:237: same bits)
       if (cs.kind == kChainKindNorm) { p.x = d0 * d0; p.y = d1 * d1; }
       else {
         const double n0 = cs.rcp ? rs * d0 : d0 / s, n1 = cs.rcp ? rs * d1 : d1 / s;   // the value PB stores as w1' (F08:283; F08V:256)
         if (cs.kind == kChainKindFW1) { p.x = r.xf[j].x * n0; p.y = r.xf[j].y * n1; }
-        else { p.x = n0 * r.xw[j].x; p.y = n1 * r.xw[j].y; }
+        else { p.x = n0 * r.xc[j].x; p.y = n1 * r.xc[j].y; }
       }
     }
     // pair j*64 + lane of the block = elements 2 (j*64 + lane), +1: lane (j*64 + lane) / 8 of the chain, pair row lane % 8

@@ -63,6 +63,22 @@ def test_abstract_vector_flavour_soak_case(oracle, tmp_path, case):
     _judge(case, rec["err_dev_exact"], rec["err_ref_exact"])
 
 
+LAUNCHER_ERRORS = ("EADDRINUSE", "address already in use", "RendezvousConnectionError", "failed to listen on", "RendezvousTimeoutError")
+
+
+def _run_rank_group(cmd, env):
+    """One rank group of the sharded soak tool.  A second attempt is made ONLY when the first died in the LAUNCHER -- the local
+    port found free was taken before torch.distributed.run bound it, the rendezvous did not come up (as tests/launch_util.py
+    does) -- never on any other failure: an intermittent defect of the peer-to-peer mailboxes or of the rank-to-rank sum chain
+    must fail the test the first time it shows."""
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    words = p.stdout + p.stderr
+    if p.returncode != 0 and any(w in words for w in LAUNCHER_ERRORS) and "FAIL seed" not in words:
+        print("LAUNCH REPEATED (rc %d, a launcher error); its last words:\n%s" % (p.returncode, words[-3000:]), flush=True)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    return p
+
+
 @pytest.mark.parametrize("case", _ids("sharded"))
 def test_sharded_array_flavour_soak_case(case, tmp_path):
     """`world` ranks sharing the GPU, the sums staged through gloo (tools/fuzz_gpu.py --sharded): one record per rank."""
@@ -70,13 +86,7 @@ def test_sharded_array_flavour_soak_case(case, tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--sharded", str(case["world"]), "--first-seed",
            str(case["seed"]), "--seeds", "1", "--out", out]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    if p.returncode != 0:
-        # One more attempt, LOUDLY: a rank group of three processes that rendezvous over a local port, share the box's one GPU
-        # and (seeds >= 100 000) map each other's mailboxes can fail for reasons that are not the arithmetic's (seen once in
-        # round 5, not reproducible: the same case passed in every other run).  A defect of the library fails twice.
-        print("FIRST ATTEMPT FAILED (rc %d); its last words:\n%s" % (p.returncode, (p.stdout[-1500:] + p.stderr[-3000:])), flush=True)
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    p = _run_rank_group(cmd, env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     worst = 0.0
     for r in range(case["world"]):
@@ -98,10 +108,7 @@ def test_sharded_soak_cases_beyond_one_tile_stay_within_the_rule_with_the_rounde
     cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--sharded", str(case["world"]), "--first-seed",
            str(case["seed"]), "--seeds", "1", "--out", out]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NKA_FUZZ_FORCE_ROUNDED="1")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    if p.returncode != 0:
-        print("FIRST ATTEMPT FAILED (rc %d); its last words:\n%s" % (p.returncode, (p.stdout[-1500:] + p.stderr[-3000:])), flush=True)
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    p = _run_rank_group(cmd, env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     for r in range(case["world"]):
         text = open(f"{out}.rank{r}").read()

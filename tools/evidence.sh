@@ -16,7 +16,6 @@
 #   reforder                    whole GPU suite, cost table of the reference-order sums, soak over the three sum modes
 #   rank-rehearsal              bench.py --gpus 4 in the plain form, ranks sharing the GPU: staged asked / rccl asked
 #   scale                       one-GPU rehearsal of every shard size + sweep                   (tools/scale_rehearsal.sh, sweep.sh)
-#   tree-ab OTHER_TREE          two trees of the repository timed alternately (git worktree of an earlier round, built)
 #   mall                        round 5: Infinity-Cache reuse between the passes (needs `make -C nka_amd/csrc ftemporal`)
 #   p2p                         round 5: the peer-to-peer exchange, latency as far as one GPU can tell
 #   lib-ab ROUNDS "ARGS" LIBS   interleaved bench.py A/B of several builds of libnka_hip.so     (tools/ab_bench.sh)
@@ -117,14 +116,6 @@ rank-rehearsal)
 scale)
   bash tools/scale_rehearsal.sh > /dev/null 2>&1; cat gpurun_out/scale_rehearsal.txt
   bash tools/sweep.sh c > gpurun_out/sweep_n_mvec.txt 2>&1; cat gpurun_out/sweep_n_mvec.txt ;;
-tree-ab)
-  other=${1:?tree-ab: path of the other (built) tree, e.g. a git worktree of an earlier round}
-  for spec in "1.25e7 20 3 120" "1e7 10 2 120" "1e8 20 2 200"; do
-    set -- $spec
-    for rep in $(seq $3); do for tree in . $other; do
-      timeout -k 10 $4 python tools/tree_ab.py $tree $1 $2 2>&1 | grep -v amdgpu.ids || exit 1
-    done; done | tee gpurun_out/tree_ab_$1_$2.txt
-  done ;;
 mall)
   # (a) temporal loads for the vectors both passes read (libnka_hip_diag_ft<bits>.so: 1 = in PA, 2 = in PB, 3 = both),
   # (b) PB in the reverse of PA's tile order (pb_reverse), (c) both: profiles/r05/ab_mall_reuse.txt

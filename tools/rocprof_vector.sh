@@ -14,6 +14,16 @@ S=$(ls "$OUT"/trace/*/*_kernel_stats.csv | head -1)
 { head -1 "$S"; grep -E "k_[a-z_0-9]+<|nka::" "$S"; } > "$ROOT/gpurun_out/profiles_$TAG/kernel_stats_vector_compact$CP.csv"
 cp "$OUT/bench.log" "$ROOT/gpurun_out/profiles_$TAG/vector_bench_under_trace_compact$CP.log"
 cat "$ROOT/gpurun_out/profiles_$TAG/kernel_stats_vector_compact$CP.csv"
+# HBM traffic by the PMC counters: two more runs, one counter each (never combined with other trace domains), summarised per kernel
+# family against the byte model of bench.py's config5_abstract_vector (tools/pmc_vector_summary.py)
+if [ "${NKA_VECTOR_PMC:-1}" = "1" ]; then
+  for pass in "FETCH_SIZE pmc_fetch" "WRITE_SIZE pmc_write"; do
+    set -- $pass
+    rocprofv3 --kernel-trace --pmc $1 --output-format csv -d "$OUT/$2" -- "$ROOT/nka_amd/fortran/build/nka_vector_driver" bench 4 10000000 20 6 $CP > "$OUT/$2.log" 2>&1
+    echo "$1 rc=$?"
+  done
+  python3 "$ROOT/tools/pmc_vector_summary.py" "$OUT" "$ROOT/gpurun_out/profiles_$TAG/pmc_traffic_vector_compact$CP.json" --n 40000000 --mvec 20 --compact $CP
+fi
 # timeline of two steady-state updates: kernel starts/ends relative to the first
 python3 - "$OUT" <<'PY'
 import csv, glob, re, sys
