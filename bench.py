@@ -60,8 +60,11 @@ Prints ONE JSON line (rank 0) with the driver's keys plus
                  widths, physical roofline at the actual list length with PMC traffic.
   out_of_place_entry (N = 1, headline run only): the headline workload through the opt-in nka_hip_accel_update_swap
                  (two store streams less in PB; bit-identical results).
-  sum_mode_blocked_rounded (N = 1, headline run only): the headline workload in the opt-in sum mode NKA_HIP_SUMS_BLOCKED_ROUNDED
-                 (the norm first, the Gram row on the rounded w1': the closest to the reference the fast passes get).
+  sum_mode_blocked (N = 1, headline run only): the headline workload in the OTHER fast sum mode.  Since round 6 `value` is
+                 quoted in the DEFAULT sums (the norm first, then PA on the rounded w1' = the Gram row as the reference
+                 defines it: re-decided from 23 000 paired soak records, profiles/r06/soak_paired.txt); this entry is the
+                 opt-in single-pass mode NKA_HIP_SUMS_BLOCKED (raw-sum Gram row: 2 words per element and one exchange
+                 less).  With --sums blocked the roles are swapped (sum_mode_rounded).
   config2_n1e7_m10 (N = 1, headline run only): BASELINE configs[1] (n = 1e7, m = 10) measured in the same
                  run on the first 1e7 elements of the resident inputs (updates/s, whole-update fraction).
   config5_abstract_vector (N = 1, headline size only): BASELINE configs[4], the
@@ -105,6 +108,10 @@ def parse(argv=None):
     ap.add_argument("--flavor", choices=["default", "c", "f08", "f08vec"], default=os.environ.get("NKA_BENCH_FLAVOR", "default"),
                     help="'default' = what `call a%%init(vlen, mvec)` of the drop-in Fortran module runs (compact storage "
                          "unless NKA_HIP_FLAVOR says otherwise); or name the reference rounding mirrored")
+    ap.add_argument("--sums", choices=["default", "rounded", "blocked"], default=os.environ.get("NKA_BENCH_SUMS", "default"),
+                    help="how the fast passes form the Gram row (nka_hip_set_sum_order).  default = what every front end runs "
+                         "since round 6: the norm first, then PA on the ROUNDED w1' (NKA_HIP_SUMS_BLOCKED_ROUNDED: 2 words per "
+                         "element and one exchange more); blocked = the opt-in single-pass fast mode (raw-sum Gram row)")
     ap.add_argument("--allreduce", choices=["p2p", "rccl", "torch", "staged"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"),
                     help="the one exchange of a sharded update.  rccl (default): the library's RCCL communicator on the kernel "
                          "stream; p2p: the opt-in peer-to-peer exchange (mailboxes mapped through hipIpc, no communication "
@@ -218,6 +225,12 @@ def config5_abstract_vector(steps: int = 20):
                                       + ": update_norm2_dots 2+m (ONE pure-read pass for the norm and both inner-product "
                                       "rows; the normalisation of the new pair deferred to the combine), "
                                       "update/axpy_many_keep " + ("6+2m" if compact == "0" else "7+m")}
+            pmv = pmc_traffic_vector(compact, n, m)       # counter evidence: committed PMC summary of the same workload
+            if pmv:
+                out[key]["traffic"] = pmv[0]["hbm_bytes_per_update"]
+                out[key]["traffic_over_bytes_moved"] = pmv[0]["hbm_bytes_per_update"] / moved
+                out[key]["traffic_per_kernel_over_model"] = {k: round(v["traffic_over_model"], 4) for k, v in pmv[0]["kernels"].items()}
+                out[key]["traffic_source"] = "committed file, not this run: " + pmv[1]
             if compact == "0":      # B_alg bounds the traffic of the reference rounding only (ratio 1.04): the BASELINE.md-style rate
                 out[key]["contract_bytes_ratio"] = 8.0 * n * (11 + 3 * m) / moved
                 out[key]["contract_GBps"] = 8.0 * n * (11 + 3 * m) / (ms * 1e-3) / 1e9
@@ -268,20 +281,22 @@ FLAVOR_TEXT = {"c": "src-C rounding f += c*(v-w), compact storage (v slot keeps 
                "f08vec": "src-F08-vector rounding ((-c)*w + c*v) + f, normalise by reciprocal"}
 
 
-def words_moved(flavor: str, L: int, k: int, out_of_place: bool = False):
+def words_moved(flavor: str, L: int, k: int, out_of_place: bool = False, norm_pass: bool = False):
     """8-byte words per element each launch of the two-pass schedule really moves
     (confirmed by the PMC passes under profiles/): PA reads w1, f and the L stored
     w; PB reads f and the k pairs (one vector per pair with compact storage, the
     pending pair always as two) and writes w1', v1', w_new, v_new, f -- out of place
-    (nka_hip_accel_update_swap) w1', v1', v_new only."""
+    (nka_hip_accel_update_swap) w1', v1', v_new only.  norm_pass (the default sums
+    since round 6): the norm of d = w1 - f in a short pass of its own before PA
+    (k_norm_diff: w1 and f once more) -- counted with the PA phase, whose events span it."""
     # lists longer than 32 take the multi-pass kernels (k_dots / k_combine in passes of 32): every further pass of PA reads
     # f and w1 again, every further pass of PB reads the running f and stores it once more
     npa, npb = max(1, -(-L // 32)), max(1, -(-k // 32))
     pb_reads = (1 + k) if flavor == "c" else (2 * k)
-    return {"PA_k_dots": L + 2 * npa, "PB_k_combine": pb_reads + npb + (2 if out_of_place else 4) + npb}
+    return {"PA_k_dots": L + 2 * npa + (2 if norm_pass else 0), "PB_k_combine": pb_reads + npb + (2 if out_of_place else 4) + npb}
 
 
-def pmc_traffic(flavor: str, n_local: int, m: int):
+def pmc_traffic(flavor: str, n_local: int, m: int, norm_pass: bool = False):
     """HBM bytes per launch from the newest rocprofv3 PMC summary of THIS workload
     (tools/rocprof_bench.sh + tools/pmc_summary.py, committed under profiles/)."""
     import glob
@@ -291,11 +306,27 @@ def pmc_traffic(flavor: str, n_local: int, m: int):
         try:
             with open(cand) as fh:
                 pm = json.load(fh)
-            if pm.get("n") == n_local and pm.get("mvec") == m and pm.get("hbm_bytes_per_update"):
+            if pm.get("n") == n_local and pm.get("mvec") == m and pm.get("hbm_bytes_per_update") and \
+                    ("k_norm_diff" in pm.get("kernels", {})) == norm_pass:         # (a summary of the same sum mode)
                 return pm, os.path.relpath(cand, ROOT)
         except Exception:
             pass
     return None, None
+
+
+def pmc_traffic_vector(compact: str, n: int, m: int):
+    """HBM bytes per update of the abstract-vector kernels from the newest committed PMC summary of config 5
+    (tools/rocprof_vector.sh + tools/pmc_vector_summary.py -> profiles/rNN/pmc_traffic_vector_compact<c>.json)."""
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_vector_compact{compact}.json")), reverse=True):
+        try:
+            with open(cand) as fh:
+                pm = json.load(fh)
+            if pm.get("n") == n and pm.get("mvec") == m and pm.get("hbm_bytes_per_update"):
+                return pm, os.path.relpath(cand, ROOT)
+        except Exception:
+            pass
+    return None
 
 
 def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170, extra_args=()):
@@ -346,7 +377,7 @@ def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170, extra_ar
 
 
 def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=None, pm_live=None, L=None, k=None,
-                   out_of_place=False):
+                   out_of_place=False, norm_pass=False):
     """`roofline` object of the JSON line.  Every `achieved`/`frac` in it is
     PHYSICAL: bytes the launch really moves (byte model above, confirmed by the
     PMC counters) / mean launch duration (HIP events on the kernel stream during
@@ -358,13 +389,13 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
     useful work, not a bandwidth (it may exceed the peak and is never `frac`)."""
     L = m if L is None else L          # stored vectors PA reads / pairs PB combines: mvec with the subspace full,
     k = m if k is None else k          # fewer after dependence drops (--workload drops)
-    words = words_moved(flavor, L, k, out_of_place)
-    ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}
+    words = words_moved(flavor, L, k, out_of_place, norm_pass)
+    ms = {"PA_k_dots": mean[0], "PB_k_combine": mean[2]}      # (PA phase: k_norm_diff + k_dots with the default sums)
     if pm_live:
         pm, pm_src = pm_live, ("same run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child process of "
                                "this script after the timed region; FETCH_SIZE x 2 on gfx950")
     else:
-        pm, pm_src = pmc_traffic(flavor, n_local, m) if (L, k) == (m, m) and not out_of_place else (None, None)
+        pm, pm_src = pmc_traffic(flavor, n_local, m, norm_pass) if (L, k) == (m, m) and not out_of_place else (None, None)
     pmk = {"PA_k_dots": "k_dots", "PB_k_combine": "k_combine"}
     kernels = {}
     for name, w in words.items():
@@ -374,6 +405,8 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
         if pm and pmk[name] in pm.get("kernels", {}):
             kk = pm["kernels"][pmk[name]]
             tr = kk["read_bytes"] + kk["write_bytes"]
+            if name == "PA_k_dots" and norm_pass and "k_norm_diff" in pm["kernels"]:
+                tr += pm["kernels"]["k_norm_diff"]["read_bytes"] + pm["kernels"]["k_norm_diff"]["write_bytes"]
         kernels[name] = {"bytes_moved": b, "words_per_element": w, "mean_ms": ms[name],
                          "achieved": (b / t / 1e9) if t > 0 else None,
                          "frac": (b / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else None,
@@ -395,6 +428,8 @@ def roofline_block(flavor: str, n_local: int, m: int, mean, probe=None, stats=No
                          "traffic": pm["hbm_bytes_per_update"] if pm else None,
                          "what": "PA + scalar step + PB, first kernel start .. last kernel end"},
         "kernels": kernels,
+        "sum_mode": "default: norm pass (k_norm_diff) + PA on the rounded w1' (NKA_HIP_SUMS_BLOCKED_ROUNDED)" if norm_pass
+                    else "NKA_HIP_SUMS_BLOCKED: one pure-read pass, raw-sum Gram row",
         "bytes_moved_per_update": moved,
         "probe_ceiling": probe,
         "device_time_stats_ms": stats,
@@ -449,7 +484,7 @@ def reference_rounding_entry(also):
 ROOFLINE_FIRST = ("bound", "unit", "peak", "kernel", "achieved", "frac", "traffic",
                   "whole_update_frac", "PA_k_dots_frac", "PB_k_combine_frac", "frac_of_probe_ceiling",
                   "reference_rounding_updates_per_s", "reference_rounding_contract_frac_of_peak", "reference_rounding_PB_frac",
-                  "reference_rounding_physical_frac", "probe_ceiling_dominant_mix_GBps", "whole_update_ms", "traffic_source")
+                  "sum_mode_blocked_updates_per_s", "probe_ceiling_dominant_mix_GBps", "whole_update_ms", "traffic_source", "reference_rounding_physical_frac")
 SHORT = 100          # characters of a string that a truncating record keeps for certain
 
 
@@ -698,8 +733,11 @@ def main(argv=None):
     FLAVOR_NAMES = {nka_amd.FLAVOR_F08: "f08", nka_amd.FLAVOR_F08_VECTOR: "f08vec", nka_amd.FLAVOR_C: "c"}
     hook_box = ["none"]
 
+    SUMS = {"default": nka_amd.SUMS_AUTO, "rounded": nka_amd.SUMS_BLOCKED_ROUNDED, "blocked": nka_amd.SUMS_BLOCKED}
+    norm_pass = args.sums != "blocked"        # (the default resolves to the rounded passes beyond 64 elements: include/nka_hip.h)
+
     def make_acc(flavor_name):
-        acc = nka_amd.nka().init(n_local, m, flavor=FLAVORS[flavor_name])
+        acc = nka_amd.nka().init(n_local, m, flavor=FLAVORS[flavor_name]).set_sum_order(SUMS[args.sums])
         if world > 1 or os.environ.get("NKA_BENCH_FORCE_HOOK") == "1":
             if not dist.is_initialized():          # single-process rehearsal of the N > 1 plumbing
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -921,7 +959,7 @@ def main(argv=None):
         n2, m2 = 10**7, 10
         if n_local < n2 or P < m2 + 4 + 8:
             return None
-        a2 = nka_amd.nka().init(n2, m2, flavor=FLAVORS[args.flavor])
+        a2 = nka_amd.nka().init(n2, m2, flavor=FLAVORS[args.flavor]).set_sum_order(SUMS[args.sums])
         try:
             views = [pool[j][:n2] for j in range(P)]
             for j in range(P):
@@ -943,7 +981,7 @@ def main(argv=None):
             ph = [a2.timing_ms(b) for b in range(nrec)]
             mean2 = [sum(p[i] for p in ph) / nrec for i in range(4)]
             fl2 = FLAVOR_NAMES[a2.flavor()]
-            w2 = words_moved(fl2, m2, m2)
+            w2 = words_moved(fl2, m2, m2, norm_pass=norm_pass)
             moved = 8.0 * n2 * sum(w2.values())
             return {"workload": "BASELINE configs[1]: n=1e7, mvec=10, fp64, 1 GPU, subspace full", "flavor": FLAVOR_TEXT[fl2],
                     "value": 1.0 / dt, "unit": "updates/s", "us_per_update": 1e6 * dt, "steps": steps,
@@ -991,7 +1029,7 @@ def main(argv=None):
         length from the list word and launches PA at exactly L = k; PB is launched one wider than it turns out to need
         (its width is fixed before the device decides the drop of this very update) -- one dead ring slot."""
         D = min(args.drop_dim, m)
-        a3 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor])
+        a3 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor]).set_sum_order(SUMS[args.sums])
         try:
             e3, mean3, nv3, nv3_end, _, stats3 = measure(a3, "drops")
             fl3 = FLAVOR_NAMES[a3.flavor()]
@@ -1025,7 +1063,7 @@ def main(argv=None):
                     "mean_k": float(nv3 + nv3_end) / 2.0, "steady_state": bool(nv3 == D and nv3_end == D),
                     "host_list_bound_after_the_run": lb, "list_length_on_device": nv3_end + 1,
                     "launch_widths": {"PA": lb - 1, "PB": min(lb, m)},
-                    "roofline": roofline_block(fl3, n_local, m, mean3, None, stats3, None, L=D, k=D)}
+                    "roofline": roofline_block(fl3, n_local, m, mean3, None, stats3, None, L=D, k=D, norm_pass=norm_pass)}
         finally:
             a3.delete()
             basis_box[0] = None
@@ -1043,20 +1081,25 @@ def main(argv=None):
                              "once (as v_new) and lent to the caller",
                     "flavor": FLAVOR_TEXT[fl4], "value": K / e4, "unit": "updates/s", "ms_per_step": 1e3 * e4 / K,
                     "steady_state": bool(nv4 == m and nv4_end == m),
-                    "roofline": roofline_block(fl4, n_local, m, mean4, None, stats4, None, out_of_place=True)}
+                    "roofline": roofline_block(fl4, n_local, m, mean4, None, stats4, None, out_of_place=True, norm_pass=norm_pass)}
         finally:
             a4.delete()                 # (before the input rows it holds are released)
 
-    def rounded_mode_extra():
-        """The opt-in sum mode NKA_HIP_SUMS_BLOCKED_ROUNDED on the headline workload: the norm in a pass of its own, then PA on the
-        rounded w1' (the Gram row as the reference defines it): 51 instead of 49 words per element and one kernel pair more."""
-        a6 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor]).set_sum_order(nka_amd.SUMS_BLOCKED_ROUNDED)
+    def other_sum_mode_extra():
+        """The headline workload in the sum mode the line is NOT quoted in: with the default sums (the norm first, PA on the rounded
+        w1': 51 words per element with compact storage) the opt-in single-pass fast mode NKA_HIP_SUMS_BLOCKED (49 words), and
+        the other way round."""
+        other = "rounded" if args.sums == "blocked" else "blocked"
+        a6 = nka_amd.nka().init(n_local, m, flavor=FLAVORS[args.flavor]).set_sum_order(SUMS[other])
         try:
             e6, mean6, nv6, nv6_end, _, stats6 = measure(a6, "full")
-            return {"mode": "nka_hip_set_sum_order(NKA_HIP_SUMS_BLOCKED_ROUNDED): norm pass + PA on the rounded w1' (include/nka_hip.h)",
-                    "value": K / e6, "unit": "updates/s", "ms_per_step": 1e3 * e6 / K, "steady_state": bool(nv6 == m and nv6_end == m),
-                    "phase_ms": {"norm_pass_and_PA": mean6[0], "k_solve": mean6[1], "PB_k_combine": mean6[2]},
-                    "words_per_element": 2 + sum(words_moved(FLAVOR_NAMES[a6.flavor()], m, m).values())}
+            return {"mode": "nka_hip_set_sum_order(NKA_HIP_SUMS_BLOCKED): ONE pure-read pass forms every sum, the Gram row from raw sums "
+                            "(include/nka_hip.h); opt-in" if other == "blocked" else
+                            "nka_hip_set_sum_order(NKA_HIP_SUMS_BLOCKED_ROUNDED): norm pass + PA on the rounded w1' (the default)",
+                    "sums": other, "value": K / e6, "unit": "updates/s", "ms_per_step": 1e3 * e6 / K,
+                    "steady_state": bool(nv6 == m and nv6_end == m),
+                    "phase_ms": {"PA_phase": mean6[0], "k_solve": mean6[1], "PB_k_combine": mean6[2]},
+                    "words_per_element": sum(words_moved(FLAVOR_NAMES[a6.flavor()], m, m, norm_pass=(other != "blocked")).values())}
         finally:
             a6.delete()
 
@@ -1067,10 +1110,10 @@ def main(argv=None):
             drops = with_drops_extra()
         except Exception as exc:           # an extra, never the measured path
             drops = {"value": None, "error": repr(exc)}
-    rounded = None
+    rounded = None                          # (the name of round 5: the measurement in the OTHER sum mode)
     if headline and os.environ.get("NKA_BENCH_SECONDARY", "1") != "0":
         try:
-            rounded = rounded_mode_extra()
+            rounded = other_sum_mode_extra()
         except Exception as exc:           # an extra, never the measured path
             rounded = {"value": None, "error": repr(exc)}
     oop = None
@@ -1090,11 +1133,11 @@ def main(argv=None):
         also = {"flavor": FLAVOR_TEXT["f08"],
                 "value": K / e2, "unit": "updates/s", "ms_per_step": 1e3 * e2 / K,
                 "steady_state": bool(nv2 == m and nv2_end == m),
-                "roofline": roofline_block("f08", n_local, m, mean2, None, stats2)}
+                "roofline": roofline_block("f08", n_local, m, mean2, None, stats2, norm_pass=norm_pass)}
 
     if rank == 0:
         Lk = k_steady
-        rl = roofline_block(flavor, n_local, m, mean, None, stats, None, L=Lk, k=Lk)
+        rl = roofline_block(flavor, n_local, m, mean, None, stats, None, L=Lk, k=Lk, norm_pass=norm_pass)
         wl = (f"BASELINE configs[{2 if world == 1 else 3}]: synthetic n={n_global} (global), mvec={m}, fp64, subspace full "
               f"(num_vec={nv})") if args.workload == "full" else \
              (f"NOT a BASELINE config: inputs in a {args.drop_dim}-dim span, n={n_global}, mvec={m}, one drop + one sync per "
@@ -1109,6 +1152,8 @@ def main(argv=None):
             "config": {"workload": wl, "inputs": "uniform(-1,1) fp64, counter-based generator keyed on (seed, call, global index)",
                        "n_global": n_global, "n_local": n_local, "mvec": m,
                        "flavor": FLAVOR_TEXT[flavor],
+                       "sums": ("default: norm pass + PA on the rounded w1' (NKA_HIP_SUMS_BLOCKED_ROUNDED)" if norm_pass
+                                else "NKA_HIP_SUMS_BLOCKED (opt-in): one pure-read pass, raw-sum Gram row"),
                        "flavor_is_front_end_default": bool(is_default),
                        "flavor_note": "the flavour `call a%init(vlen, mvec)` (Fortran), nka_init (F95) and nka().init "
                                       "(Python) run when the caller names none (include/nka_hip.h: NKA_HIP_FLAVOR_DEFAULT)"
@@ -1146,9 +1191,9 @@ def main(argv=None):
         if oop is not None:
             out["out_of_place_entry"] = oop
         if rounded is not None:
-            out["sum_mode_blocked_rounded"] = rounded
+            out["sum_mode_" + rounded.get("sums", "other")] = rounded
             if rounded.get("value"):
-                out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]      # (flat: survives a scalars-only record)
+                out["roofline"][f"sum_mode_{rounded.get('sums', 'other')}_updates_per_s"] = rounded["value"]      # (flat: survives a scalars-only record)
         if headline:
             try:
                 c2 = config2_line()
@@ -1254,15 +1299,15 @@ def main(argv=None):
             torch.cuda.empty_cache()
             probe = probe_ceilings(min(n_local, 10**8))
             # HBM traffic of the dominant kernels by the PMC counters, measured in this run (child process under rocprofv3)
-            pm_live = pmc_same_run(flavor, n_local, m) if headline else None
-            out["roofline"] = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live, L=Lk, k=Lk)
+            pm_live = pmc_same_run(flavor, n_local, m, extra_args=("--sums", args.sums)) if headline else None
+            out["roofline"] = roofline_block(flavor, n_local, m, mean, probe, stats, pm_live, L=Lk, k=Lk, norm_pass=norm_pass)
             if also is not None:
                 also["roofline"]["probe_ceiling"] = probe
                 nested, flat = reference_rounding_entry(also)
                 out["roofline"]["reference_rounding"] = nested
                 out["roofline"].update(flat)
             if rounded is not None and rounded.get("value"):
-                out["roofline"]["sum_mode_blocked_rounded_updates_per_s"] = rounded["value"]
+                out["roofline"][f"sum_mode_{rounded.get('sums', 'other')}_updates_per_s"] = rounded["value"]
             if drops is not None and (drops.get("reference_order") or {}).get("value"):
                 out["roofline"]["reference_order_with_drops_updates_per_s"] = drops["reference_order"]["value"]
             dro = (out.get("cpu_baseline") or {}).get("device_reference_order")
@@ -1276,12 +1321,12 @@ def main(argv=None):
                     if isinstance(host_arr.get(kind), dict):      # flat, so that a scalars-only record keeps it
                         out["roofline"][f"host_array_entry_n1e7_m10_{kind}_updates_per_s"] = host_arr[kind]["value"]
             if drops is not None and drops.get("roofline") and headline:
-                pm_d = pmc_same_run(flavor, n_local, m, extra_args=("--workload", "drops", "--drop-dim", str(args.drop_dim)))
+                pm_d = pmc_same_run(flavor, n_local, m, extra_args=("--workload", "drops", "--drop-dim", str(args.drop_dim), "--sums", args.sums))
                 if pm_d:
                     D = min(args.drop_dim, m)
                     ph = drops["roofline"]["device_time_stats_ms"]
                     mean_d = [ph[nm]["mean"] for nm in ("PA_k_dots", "k_solve", "PB_k_combine", "whole_update")]
-                    drops["roofline"] = roofline_block(flavor, n_local, m, mean_d, None, ph, pm_d, L=D, k=D)
+                    drops["roofline"] = roofline_block(flavor, n_local, m, mean_d, None, ph, pm_d, L=D, k=D, norm_pass=norm_pass)
             if not args.no_config5 and headline:
                 out["config5_abstract_vector"] = config5_abstract_vector()
         print(json.dumps(finish_line(out)), flush=True)

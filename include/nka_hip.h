@@ -62,8 +62,8 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  *     pivot within rounding distance of vtol^2 could in principle fall the other way.
  *  2. REFERENCE-ORDER SUMS (NKA_HIP_SUMS_REFERENCE_ORDER; the default up to n = 64): the returned f -- and h, c, every
  *     stored vector -- carry the BITS of the reference flavour the handle runs, at any n, on one rank or sharded.
- *  3. FAST PASSES (the default beyond n = 64): sums in blocks with fma -- other last bits than the reference's sequential
- *     sums, and closer to f_exact than those from n ~ 1e3 up.  Over a call sequence
+ *  3. FAST PASSES (the default beyond n = 64, both forms): sums in blocks with fma -- other last bits than the reference's
+ *     sequential sums, and closer to f_exact than those from n ~ 1e3 up.  Over a call sequence
  *         TYPICAL  max err(f_device) <= max(base, F * max err(f_reference)),  base = 1e-12 (1e-10 for n >= 1e7),
  *                  F = 2 for n > 512, 4 within one tile of the kernels (n <= 512): within the stated tolerance wherever
  *                  the reference is, else within F times the reference's own worst distance from the truth on the same
@@ -77,7 +77,14 @@ enum { NKA_HIP_FLAVOR_DEFAULT = -1 };
  *     (f - c*w) + c*v: last-bit differences, inside every bound above; NKA_HIP_FLAVOR_F08 gives the src-F08 statement.
  *  5. Sharded runs return the same bits on every rank (one reduction result, added in one order), and -- fast passes --
  *     bits that depend on the number of ranks like any blocked sum; the bounds of 3 hold unchanged.
- *  6. THE RECORD.  See profiles/r06/soak_paired.txt for the two fast sum modes on the same seeds, side by side.
+ *  6. THE RECORD (profiles/r06/soak_paired.txt: the two fast modes on the SAME 8 104 random call sequences, 23 104 rank
+ *     records each; profiles/r04, r05/fuzz_soak.txt: about 75 000 records of the raw-sum form).  Beyond the TYPICAL bar:
+ *                               n <= 16     17..512    513..2048    > 2048      (records of 7 969 / 3 110 / 3 679 / 8 346)
+ *         default (rounded)        14           0           0           1       largest ratio beyond one tile 2.26 x
+ *         NKA_HIP_SUMS_BLOCKED     28           0           5           2       largest ratio beyond one tile 3.07 x
+ *     -- 7 records beyond one tile against 1: why the default was changed in round 6.  The HARD line was exceeded by no
+ *     record of either mode (largest ratios: 27.9 within one tile at err > 1e-11; 5.5 x beyond, abstract-vector flavour,
+ *     round 5).  Exceedances beyond one tile are fixtures (tests/golden/soak_cases.json) replayed by the suite.
  */
 
 /* ---- lifecycle --------------------------------------------------------- */
@@ -116,15 +123,19 @@ int nka_hip_relax(nka_hip_t a);
 int nka_hip_set_vec_tol(nka_hip_t a, double vtol);
 
 /* How the inner products are summed (part of the numerical contract; the long note is in nka_hip_ext.h):
- *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing (one rank, n <= 64), the fast passes otherwise
+ *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing (one rank, n <= 64), otherwise _BLOCKED_ROUNDED
  *   NKA_HIP_SUMS_REFERENCE_ORDER  every sum as the reference forms it: accel_update returns the reference's BITS at any n,
  *                                 sharded too (needs nka_hip_set_shard); validation speed beyond a few thousand elements
- *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n: ONE pure-read pass forms every sum of an update; the Gram row
- *                                 of the normalised difference is taken from raw sums, fl(<d,w_k>/s)
  *   NKA_HIP_SUMS_BLOCKED_ROUNDED  the fast passes with the norm first (a short pass of its own, a second exchange when
- *                                 sharded) and the Gram row as the inner product of the STORED fl(d/s), as the reference
- *                                 defines it (F08:282-290): +5-9 % time
- * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates. */
+ *                                 sharded), then every other sum in one pure-read pass on the ROUNDED w1' = fl(d/s): the
+ *                                 Gram row is the inner product of the STORED vector, as the reference defines it
+ *                                 (F08:282-290).  What every front end runs since round 6 (contract item 6)
+ *   NKA_HIP_SUMS_BLOCKED          opt-in FAST mode: ONE pure-read pass forms every sum of an update, the Gram row of the
+ *                                 normalised difference is taken from raw sums, fl(<d,w_k>/s): 2 words per element and one
+ *                                 exchange less (5-9 % faster), the same typical distance from the truth, a heavier tail
+ * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates.  The environment variable
+ * NKA_HIP_SUMS = auto | rounded | blocked | reference sets what a new handle starts with (for callers that cannot call
+ * this function: the reference's own programs relinked against the front ends). */
 enum { NKA_HIP_SUMS_AUTO = 0, NKA_HIP_SUMS_REFERENCE_ORDER = 1, NKA_HIP_SUMS_BLOCKED = 2, NKA_HIP_SUMS_BLOCKED_ROUNDED = 3 };
 int nka_hip_set_sum_order(nka_hip_t a, int32_t order);
 

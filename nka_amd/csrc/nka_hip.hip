@@ -623,6 +623,21 @@ int nka_hip_create(nka_hip_t *out, int64_t vlen_local, int32_t mvec, double vtol
   //  nka_hip_set_grid exist for in-process A/B measurements and for the tests that hold every variant to
   //  the same bits -- since round 3 no environment variable selects a variant)
   a->debug = env_int("NKA_HIP_DEBUG", 0) != 0;
+  // NKA_HIP_SUMS = auto | rounded | blocked | reference: the sum order a handle starts with, for callers that cannot call
+  // nka_hip_set_sum_order (the reference's own programs relinked against the front ends); like NKA_HIP_FLAVOR
+  if (const char *e = getenv("NKA_HIP_SUMS")) {
+    std::string v(e);
+    for (char &ch : v) ch = (char)tolower((unsigned char)ch);
+    if (v == "auto" || v.empty()) a->sum_order = NKA_HIP_SUMS_AUTO;
+    else if (v == "rounded") a->sum_order = NKA_HIP_SUMS_BLOCKED_ROUNDED;
+    else if (v == "blocked" || v == "fast") a->sum_order = NKA_HIP_SUMS_BLOCKED;
+    else if (v == "reference") a->sum_order = NKA_HIP_SUMS_REFERENCE_ORDER;
+    else {
+      delete a;
+      return fail(NKA_HIP_EINVAL, "NKA_HIP_SUMS: expected auto, rounded, blocked or reference, got '" + v + "'");
+    }
+    if (a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER && mvec > kOrdMaxMvec) a->sum_order = NKA_HIP_SUMS_AUTO;
+  }
 
   // NULL is HIP's default (null) stream, as everywhere in HIP: work is ordered
   // with whatever else the caller enqueues there.
@@ -1417,7 +1432,10 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
       HIP_TRY(hipGetLastError());
     }
     mode |= kSolvePrenorm;
-  } else if (a->sum_order == NKA_HIP_SUMS_BLOCKED_ROUNDED && (a->pending || older_ub > 0)) {
+  } else if (a->sum_order != NKA_HIP_SUMS_BLOCKED && (a->pending || older_ub > 0)) {
+    // THE DEFAULT since round 6 (NKA_HIP_SUMS_AUTO beyond 64 elements or sharded, and NKA_HIP_SUMS_BLOCKED_ROUNDED): on the same
+    // 8 104 soak sequences the raw-sum Gram row ended beyond the rule's factor in 7 records of more than 512 elements, this
+    // form in 1 (profiles/r06/soak_paired.txt).  NKA_HIP_SUMS_BLOCKED (the branch below) is the opt-in single-pass fast mode.
     // The fast passes with the Gram row AS THE REFERENCE DEFINES IT: first the norm in a pass of its own (two streams: +2 of
     // 49 words), then PA on the ROUNDED w1' = fl(d/s) -- the vector PB stores -- so that <w1',w_k> and <f,w1'> are inner
     // products of stored vectors (F08:283-290, 371), summed in blocks with fma.  What is left of the device's deviations

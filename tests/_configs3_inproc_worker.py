@@ -8,9 +8,10 @@ The exchange of the 2 + 2 mvec sums (NKA_C3_TRANSPORT):
   hook   nka_hip_set_allreduce with an in-process hook: every thread parks its row, the threads meet at a barrier, and
          every one adds the eight rows IN RANK ORDER (0, 1, ... 7) into its own buffer, on its own stream;
   p2p    the peer-to-peer mailboxes (struct P2P with n = 8) attached in-process: nka_hip_p2p_export on every handle,
-         nka_hip_p2p_attach_local with the eight mailbox addresses -- the final sums of slice p go straight into every
-         slice's mailbox and the scalar step of slice q waits ON THE DEVICE for the eight rows and adds them in rank order.
-         Needs one hardware queue per stream: GPU_MAX_HW_QUEUES is raised by the test before this process starts HIP.
+         nka_hip_p2p_attach_local with the eight mailbox addresses.  NKA_C3_SUMS=blocked (the single-pass fast mode): the
+         final sums of slice p go straight into every slice's mailbox and the scalar step of slice q waits ON THE DEVICE for
+         the eight rows and adds them in rank order; default sums: the same mailboxes through the send-and-gather kernel,
+         twice per update.  Needs one hardware queue per stream: GPU_MAX_HW_QUEUES is raised by the test.
 
 Inputs and truth as tests/_sharded_ngpu_worker.py (the tiled-oracle construction of tests/test_hip_fullsize.py): the global
 vector is F = tile(x, R), R = 4^k, so the oracle runs the n0-element problem.  After EVERY call: num_vec and the list order
@@ -102,6 +103,7 @@ def main():
     R = int(os.environ.get("NKA_C3_R", "1024"))
     m = int(os.environ.get("NKA_C3_MVEC", "20"))
     flavors = [int(v) for v in os.environ.get("NKA_C3_FLAVORS", "2,0").split(",")]
+    sums = {"auto": nka_amd.SUMS_AUTO, "blocked": nka_amd.SUMS_BLOCKED}[os.environ.get("NKA_C3_SUMS", "auto")]
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     n = n0 * R
@@ -112,11 +114,11 @@ def main():
     idx = [torch.arange(lo, hi, device=dev, dtype=torch.int64) % n0 for lo, hi in bounds]          # F[i] = x[i mod n0]
     calls = m + 8
     X = small_inputs(n0, calls, seed=321)
-    report = {"transport": transport, "world": world, "n_global": n, "mvec": m, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+    report = {"transport": transport, "sums": os.environ.get("NKA_C3_SUMS", "auto"), "world": world, "n_global": n, "mvec": m, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
               "flavors": {}}
     for flavor in flavors:
-        tag = f"configs[3] in one process x{world} ({transport}) n={n} m={m} flavor {flavor}"
-        accs = [nka_amd.nka().init(hi - lo, m, flavor=flavor, device=0, stream=streams[r].cuda_stream)
+        tag = f"configs[3] in one process x{world} ({transport}, sums {os.environ.get('NKA_C3_SUMS', 'auto')}) n={n} m={m} flavor {flavor}"
+        accs = [nka_amd.nka().init(hi - lo, m, flavor=flavor, device=0, stream=streams[r].cuda_stream).set_sum_order(sums)
                 for r, (lo, hi) in enumerate(bounds)]
         for r, a in enumerate(accs):
             a.set_shard(r, world)

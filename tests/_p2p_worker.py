@@ -44,10 +44,15 @@ def main():
             acc += rows[r]                       # rank order: the order of the peer-to-peer gather
         dev.copy_(acc)
 
-    for (n, m, flavor, calls) in ((200003, 6, 2, 18), (65536, 20, 0, 30), (1000, 40, 2, 12)):
+    # sums: NKA_HIP_SUMS_BLOCKED = the single-pass fast mode, whose final sums go STRAIGHT into the mailboxes and whose scalar
+    # step gathers them (the fused exchange); the default (round 6: the norm first, then the rows on the rounded w1') makes its
+    # two exchanges per update through the same mailboxes with the send-and-gather kernel
+    for (n, m, flavor, calls, sums) in ((200003, 6, 2, 18, nka_amd.SUMS_BLOCKED), (65536, 20, 0, 30, nka_amd.SUMS_BLOCKED),
+                                         (1000, 40, 2, 12, nka_amd.SUMS_BLOCKED), (200003, 6, 2, 18, nka_amd.SUMS_AUTO),
+                                         (65536, 20, 0, 24, nka_amd.SUMS_AUTO)):
         lo, hi = nd.slice_bounds(n, world, rank)
-        a = nka_amd.nka().init(hi - lo, m, flavor=flavor)
-        b = nka_amd.nka().init(hi - lo, m, flavor=flavor)
+        a = nka_amd.nka().init(hi - lo, m, flavor=flavor).set_sum_order(sums)
+        b = nka_amd.nka().init(hi - lo, m, flavor=flavor).set_sum_order(sums)
         hook = nd.attach_allreduce(a, rank, world, prefer="p2p", ladder=("p2p", "staged"))
         assert hook == "p2p", hook
         b.set_dot_prod(rank_ordered_staged)
@@ -83,9 +88,9 @@ def main():
     side = torch.cuda.Stream()
     static = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
     with torch.cuda.stream(side):
-        a = nka_amd.nka().init(hi - lo, m)
+        a = nka_amd.nka().init(hi - lo, m).set_sum_order(nka_amd.SUMS_BLOCKED)      # (the fused exchange: the gather inside the scalar step)
         assert nd.attach_allreduce(a, rank, world, prefer="p2p", ladder=("p2p",)) == "p2p"
-        b = nka_amd.nka().init(hi - lo, m)
+        b = nka_amd.nka().init(hi - lo, m).set_sum_order(nka_amd.SUMS_BLOCKED)
         b.set_dot_prod(rank_ordered_staged)
         for t in range(m + 3):
             x = synth.fill_numpy(31, t, 0, n, n)

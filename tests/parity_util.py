@@ -196,6 +196,7 @@ def tolerance(state, base=1e-12, spread=None, truth=None):
     return base / (piv * piv), piv, "conditioning (no spread supplied)"
 
 
+HARD_BEYOND = []   # (key, err_dev, hard tolerance, err_ref) of sequences beyond the contract's HARD line (finish())
 STOPS = []      # (key, where, err_dev, tol) of per-call stops tripped under check(stop=False): the soak tool's record
 
 
@@ -255,7 +256,7 @@ def check(err, state, key, base=1e-12, where=None, spread=None, truth=None, stop
 def finish(keys=None, strict=True):
     """End of a call sequence (a test, a soak seed): THE rule for every key checked with `truth` since the last call --
     max err_dev <= max(base, TRUTH_FACTOR * max err_ref) over the sequence.  Records the share of the allowance used."""
-    bad = []
+    bad, hard_bad = [], []
     for key in sorted(TOUCHED if keys is None else keys):
         rec = WORST.get(key)
         if not rec or "seq_dev" not in rec:
@@ -268,10 +269,18 @@ def finish(keys=None, strict=True):
         rec["tol"], rec["rule"] = float(tol), ("stated" if tol == base else f"{fac:g} x reference-vs-exact (per sequence)")
         if dev > tol:
             bad.append((key, dev, tol, ref))
+        # THE HARD LINE of the numerical contract (include/nka_hip.h, item 3), per sequence: F = 8 beyond one tile, 32 with a base
+        # of 1e-11 within -- exceeded by no record of any soak so far (profiles/r06/soak_paired.txt).  Asserted whatever `strict`
+        # says: the soak tool records exceedances of the TYPICAL bar and goes on, but this one ends the run.
+        hard = max(base * (10.0 if fac == TRUTH_FACTOR_TINY and base <= 1e-12 else 1.0), truth_hard(rec.get("n")) * ref)
+        if dev > hard:
+            hard_bad.append((key, dev, hard, ref))
+            HARD_BEYOND.append((key, dev, hard, ref))
     if keys is None:
         TOUCHED.clear()
     else:
         TOUCHED.difference_update(keys)
+    assert not hard_bad, ("device beyond the HARD line of the numerical contract (never exceeded before)", hard_bad)
     if strict:
         assert not bad, ("device further from the extended-precision trajectory than the rule allows", bad)
     return bad

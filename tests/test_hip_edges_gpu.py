@@ -220,3 +220,79 @@ def test_capture_safe_is_never_true_where_an_update_touches_the_host(torch_cuda,
     dbg = nka_amd.nka().init(n, m)
     fill(dbg)
     assert not dbg.capture_safe()
+
+
+def test_an_update_with_a_host_callback_refuses_to_be_captured(torch_cuda):
+    """Round 6 (include/nka_hip_ext.h, table of supported combinations): a caller's all-reduce hook is a HOST callback -- a
+    captured update would call it once, at capture time, and every replay would run on stale sums with NKA_HIP_OK.  The
+    update now refuses (NKA_HIP_EINVAL) while the stream is capturing; eager updates on the same handle go on working, and a
+    handle without the hook captures as before."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    n, m = 4099, 3
+    calls = [0]
+
+    def hook(ptr, count, stream):
+        calls[0] += 1                        # (one rank: the sum of one contribution is the contribution)
+
+    acc = nka_amd.nka().init(n, m)
+    acc.set_dot_prod(hook)
+    side = torch.cuda.Stream()
+    static = torch.empty(n, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(m + 3):
+            static.copy_(torch.from_numpy(rng.standard_normal(n)))
+            acc.accel_update(static)
+    torch.cuda.synchronize()
+    assert calls[0] >= m + 3 - 1 and not acc.capture_safe()      # (one exchange per update in the fast mode, two by default)
+    per_update = calls[0] // (m + 3 - 1)
+    before = calls[0]
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(nka_amd.NKAError, match="cannot be captured"):
+        with torch.cuda.graph(g, stream=side):
+            acc.accel_update(static)
+    assert calls[0] == before                # refused BEFORE the hook ran
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):            # eager updates carry on (the failed call changed nothing)
+        static.copy_(torch.from_numpy(rng.standard_normal(n)))
+        acc.accel_update(static)
+    torch.cuda.synchronize()
+    assert calls[0] == before + per_update and acc.num_vec() == m and acc.defined()
+
+
+def test_a_buffer_lent_back_to_the_caller_is_no_longer_held_by_the_library(torch_cuda):
+    """the host's set of buffers it has taken over only ever grew.  A caller's buffer X that was handed in, later
+    displaced and LENT BACK for the caller's next input belongs to the caller again; a different buffer Y that overlaps X's
+    range at another base address was then refused as "held by the library".  Now X leaves the set when it is handed out: Y is
+    accepted, X itself (still lent) is accepted, and a buffer the library really holds is still refused."""
+    import nka_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    n, m = 2048, 2
+    acc = nka_amd.nka().init(n, m)
+    big = torch.zeros(n + 64, dtype=torch.float64, device="cuda")
+    X = big[:n]
+    X.copy_(torch.from_numpy(rng.standard_normal(n)))
+    x_addr = X.data_ptr()
+    held = [X]
+    buf, _ = acc.accel_update_swap(X, views=False)
+    came_back = False
+    for _ in range(3 * (m + 2)):
+        t = acc._view(buf)
+        t.copy_(torch.from_numpy(rng.standard_normal(n)))
+        held.append(t)
+        buf, _ = acc.accel_update_swap(t, views=False)
+        if buf == x_addr:
+            came_back = True
+            break
+    assert came_back, "the caller's first buffer never came back as the free buffer"
+    torch.cuda.synchronize()
+    Y = big[2:n + 2]                          # overlaps X, other base, 16-byte aligned; X is the caller's again
+    Y.copy_(torch.from_numpy(rng.standard_normal(n)))
+    buf2, _ = acc.accel_update_swap(Y, views=False)          # was: NKAError "already held by the library"
+    assert buf2 != Y.data_ptr()
+    torch.cuda.synchronize()
+    with pytest.raises(nka_amd.NKAError, match="held by the library"):
+        acc.accel_update_swap(big[4:n + 4], views=False)    # overlaps Y, which the library holds NOW
+    assert acc.defined() and acc.num_vec() == m

@@ -514,7 +514,7 @@ def test_failed_allreduce_leaves_the_update_undone_and_the_call_repeatable(torch
     calls = {"n": 0, "fail_at": 7}
 
     def good(ptr, count, stream):          # one rank: the global sum is the local one
-        assert count == 2 + 2 * m
+        assert count in (1, 1 + 2 * m, 2 + 2 * m)      # (default sums since round 6: the norm, then the rows; NKA_HIP_SUMS_BLOCKED: all at once)
 
     def flaky(ptr, count, stream):
         calls["n"] += 1

@@ -64,19 +64,20 @@ def test_sharded_worker_rehearsed_with_ranks_sharing_the_gpu(world, r_tile):
 INPROC_WORKER = os.path.join(ROOT, "tests", "_configs3_inproc_worker.py")
 
 
-@pytest.mark.parametrize("transport", ["hook", "p2p"])
-def test_configs3_partition_8_ranks_one_process(transport):
+@pytest.mark.parametrize("transport,sums", [("hook", "auto"), ("p2p", "auto"), ("p2p", "blocked"), ("hook", "blocked")])
+def test_configs3_partition_8_ranks_one_process(transport, sums):
     """configs[3] on its own workload, on the one GPU of this pool: n_global = 1024 * 97 656 =
     99 999 744, m = 20 in EIGHT slices -- eight handles of libnka_hip.so in one child process (8 x 4.2 GB of slots), each on
     its own stream and driven by its own host thread.  `hook`: nka_hip_set_allreduce with an in-process hook that adds the
     eight rows in rank order; `p2p`: the peer-to-peer mailboxes with n = 8, attached in-process
     (nka_hip_p2p_attach_local; the scalar step of each slice waits on the device for the other seven, so the child gets
-    one hardware queue per stream: GPU_MAX_HW_QUEUES).  Per call: decisions of all eight = the oracle's on the 97 656-
+    one hardware queue per stream: GPU_MAX_HW_QUEUES).  `sums`: the default (the norm first, then the rows on the rounded w1': two
+    exchanges per update) and NKA_HIP_SUMS_BLOCKED (one exchange; with the mailboxes fused into the final sums).  Per call: decisions of all eight = the oracle's on the 97 656-
     element problem, eight identical state digests, global error against the tiled oracle under the truth rule at 1e-10;
     both storage flavours; before that an all-reduce whose result depends on the order of the additions.  What this does
     NOT exercise: a transport between GPUs (RCCL over N > 1 ranks, the mailboxes over xGMI) -- the test above."""
-    report = os.path.join(ROOT, "gpurun_out", f"configs3_inproc_{transport}.json")
-    env = dict(os.environ, OMP_NUM_THREADS="1", GPU_MAX_HW_QUEUES="16", NKA_C3_TRANSPORT=transport, NKA_C3_WORLD="8",
+    report = os.path.join(ROOT, "gpurun_out", f"configs3_inproc_{transport}_{sums}.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", GPU_MAX_HW_QUEUES="16", NKA_C3_TRANSPORT=transport, NKA_C3_SUMS=sums, NKA_C3_WORLD="8",
                NKA_C3_N0="97656", NKA_C3_R="1024", NKA_C3_MVEC="20", NKA_C3_REPORT=report)
     p = subprocess.run([sys.executable, INPROC_WORKER], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
