@@ -1158,13 +1158,12 @@ def main(argv=None):
                        "flavor_note": "the flavour `call a%init(vlen, mvec)` (Fortran), nka_init (F95) and nka().init "
                                       "(Python) run when the caller names none (include/nka_hip.h: NKA_HIP_FLAVOR_DEFAULT)"
                                       if is_default else "NOT the front ends' default: selected on the command line",
-                       "parallelism": f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}"
+                       "parallelism": ("REHEARSAL (ranks share one GPU); " if share_gpu else "")
+                                      + f"contiguous n-slices over {world} GPU(s); all-reduce={hook_box[0]}"
                                       + ("" if hook_box[0] == args.allreduce or hook_box[0] == "none" else
                                          f" (FALLBACK: '{args.allreduce}' was asked for and failed its set-up or self-test)")
-                                      + ("; the 2+2*mvec sums are staged through the host over gloo (two PCIe hops and a host "
-                                         "collective per update: slower than RCCL)" if hook_box[0] == "staged" else "")
-                                      + ("; REHEARSAL: ranks share one GPU -- the numbers of this line mean nothing"
-                                         if share_gpu else ""),
+                                      + ("; the sums are staged through the host over gloo (two PCIe hops and a host "
+                                         "collective per exchange: slower than RCCL)" if hook_box[0] == "staged" else ""),
                        "control_plane": "torch.distributed gloo (decisions, barriers, timing, digests)" if world > 1 else None,
                        "steady_state": bool(steady and nv_end == k_steady), "prime_steps": prime,
                        "phase_events": f"HIP events recorded on every {ev_stride}{'st' if ev_stride == 1 else 'th'} timed update",

@@ -12,8 +12,8 @@
  * SUPPORTED combinations of (sum order x transport); DESIGN.md section 6 names the test that holds each cell, and a
  * combination outside the table returns NKA_HIP_EINVAL / NKA_HIP_ESTATE instead of running:
  *   sum order \ transport        none   set_allreduce hook   RCCL (comm_init_rank)   p2p mailboxes
- *   AUTO / BLOCKED                yes    yes                  yes                     yes (opt-in)
- *   BLOCKED_ROUNDED               yes    yes (2 exchanges)    yes (2 exchanges)       validation only
+ *   AUTO = BLOCKED_ROUNDED        yes    yes (2 exchanges)    yes (2 exchanges)       yes (opt-in; send-and-gather kernel, twice)
+ *   BLOCKED (opt-in fast mode)    yes    yes (1 exchange)     yes (1 exchange)        yes (opt-in; fused into the final sums)
  *   REFERENCE_ORDER               yes    validation only: 2N exchanges per update through any hook that sums; mvec <= 250
  *   user dot product (core)       yes    the user's dp IS the global reduction: hooks are not applied on top
  *   out-of-place entry            every row above except the user dot product; not capturable into a graph
@@ -51,15 +51,17 @@ extern "C" {
  *       sums) hands the prefix on: N rounds for the norm (w1' = d/s needs the GLOBAL s before it can be rounded), N for the
  *       rows, 2N small exchanges per update.  An N-rank run then returns the bits of the SINGLE-rank compiled reference.
  *       The handle must know where its slice lies: nka_hip_set_shard (nka_hip_comm_init_rank does it), else NKA_HIP_ESTATE.
- *   NKA_HIP_SUMS_BLOCKED          the fast passes at every n.
  *   NKA_HIP_SUMS_AUTO (default)   reference order where it costs nothing -- a single rank and n <= 64 (every golden
- *       scenario of the reference among them) -- blocked otherwise.
- *   NKA_HIP_SUMS_BLOCKED_ROUNDED  (round 5) the fast passes, but the norm first, in a short pass of its own (two streams: 51 instead
+ *       scenario of the reference among them) -- NKA_HIP_SUMS_BLOCKED_ROUNDED otherwise (round 6).
+ *   NKA_HIP_SUMS_BLOCKED_ROUNDED  the fast passes with the norm first, in a short pass of its own (two streams: 51 instead
  *       of 49 words per element, one more exchange when sharded), and PA then on the ROUNDED w1' = fl(d/s) -- the vector that is
  *       stored: <w1',w_k> and <f,w1'> are then inner products of the stored vectors, as the reference defines them (F08:283-290,
  *       371), instead of fl(<d,w_k>/s).  That removes the one deviation of the fast passes that is not "a more accurate sum":
- *       what remains is the blocked order and the fma.  For callers who put parity before 5-9 % of speed
- *       (profiles/r05/rounded_gram_row.txt); the bounds of the numerical contract are the same.
+ *       what remains is the blocked order and the fma (profiles/r05/rounded_gram_row.txt).  Made the default in round 6: on the
+ *       same 8 104 soak sequences 1 record beyond one tile ended beyond the typical bar against 7 (profiles/r06/soak_paired.txt).
+ *   NKA_HIP_SUMS_BLOCKED          the single-pass FAST mode at every n (the default of rounds 1-5): ONE pure-read pass forms every
+ *       sum of an update, the Gram row from raw sums; 5-9 % faster, one exchange per update; with the peer-to-peer mailboxes
+ *       the final sums go straight into them and the scalar step gathers (no communication kernel at all).
  * A user dot product (nka_hip_set_host_dot) overrides them all.  Can be changed between updates.  REFERENCE_ORDER is
  * offered up to mvec = 250 (NKA_HIP_EINVAL beyond).
  * (The constants and nka_hip_set_sum_order / nka_hip_set_shard themselves are declared in the core header: the sum order is

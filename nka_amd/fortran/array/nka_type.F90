@@ -275,10 +275,10 @@ contains
 
   !! How the inner products are summed (nka_hip_set_sum_order, include/nka_hip.h): NKA_HIP_SUMS_REFERENCE_ORDER = every sum
   !! as the reference forms it (an update then returns the reference's bits at any n; single rank; slow beyond a few
-  !! thousand elements), NKA_HIP_SUMS_BLOCKED = the fast passes at every n, NKA_HIP_SUMS_BLOCKED_ROUNDED = the fast passes with
-  !! the norm first and the Gram row on the rounded w1' (+4-5 % time, the closest to the reference the fast passes get),
-  !! NKA_HIP_SUMS_AUTO (default) = reference order
-  !! where it costs nothing (n <= 64).
+  !! thousand elements), NKA_HIP_SUMS_BLOCKED_ROUNDED = the fast passes with the norm first and the Gram row on the rounded
+  !! w1' (the closest to the reference the fast passes get), NKA_HIP_SUMS_AUTO (default) = reference order where it costs
+  !! nothing (n <= 64), _BLOCKED_ROUNDED otherwise (since round 6), NKA_HIP_SUMS_BLOCKED = the opt-in single-pass fast mode
+  !! (raw-sum Gram row: 5-9 % faster, one exchange per update; also selected by the environment variable NKA_HIP_SUMS=blocked).
   subroutine set_sum_order(this, order)
     class(nka), intent(inout) :: this
     integer, intent(in) :: order

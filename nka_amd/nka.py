@@ -333,7 +333,9 @@ class nka:  # noqa: N801  (the reference's type name)
     def set_sum_order(self, order: int):
         """How the inner products are summed (nka_hip_set_sum_order): SUMS_REFERENCE_ORDER = every sum as the reference forms
         it, so that an update returns the reference's bits at any n (single rank; slow beyond a few thousand elements);
-        SUMS_BLOCKED = the fast passes at every n; SUMS_AUTO (default) = reference order where it costs nothing (n <= 64)."""
+        SUMS_AUTO (default) = reference order where it costs nothing (n <= 64), else SUMS_BLOCKED_ROUNDED = the fast passes with
+        the norm first and the Gram row on the rounded w1' (what every front end runs since round 6); SUMS_BLOCKED = the opt-in
+        single-pass fast mode (raw-sum Gram row; one exchange per update)."""
         _check(self._L.nka_hip_set_sum_order(self._handle(), int(order)), "set_sum_order", self._L)
         return self
 

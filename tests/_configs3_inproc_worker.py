@@ -103,7 +103,7 @@ def main():
     R = int(os.environ.get("NKA_C3_R", "1024"))
     m = int(os.environ.get("NKA_C3_MVEC", "20"))
     flavors = [int(v) for v in os.environ.get("NKA_C3_FLAVORS", "2,0").split(",")]
-    sums = {"auto": nka_amd.SUMS_AUTO, "blocked": nka_amd.SUMS_BLOCKED}[os.environ.get("NKA_C3_SUMS", "auto")]
+    sum_mode = {"auto": nka_amd.SUMS_AUTO, "blocked": nka_amd.SUMS_BLOCKED}[os.environ.get("NKA_C3_SUMS", "auto")]
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     n = n0 * R
@@ -118,7 +118,7 @@ def main():
               "flavors": {}}
     for flavor in flavors:
         tag = f"configs[3] in one process x{world} ({transport}, sums {os.environ.get('NKA_C3_SUMS', 'auto')}) n={n} m={m} flavor {flavor}"
-        accs = [nka_amd.nka().init(hi - lo, m, flavor=flavor, device=0, stream=streams[r].cuda_stream).set_sum_order(sums)
+        accs = [nka_amd.nka().init(hi - lo, m, flavor=flavor, device=0, stream=streams[r].cuda_stream).set_sum_order(sum_mode)
                 for r, (lo, hi) in enumerate(bounds)]
         for r, a in enumerate(accs):
             a.set_shard(r, world)

@@ -93,7 +93,7 @@ def main():
         assert acc.defined()
         acc.delete()
     if not use_rccl:
-        assert set(counts) == {2 + 2 * m}
+        assert set(counts) <= {1, 1 + 2 * m, 2 + 2 * m} and counts      # (default sums: the norm, then the rows; NKA_HIP_SUMS_BLOCKED: one exchange)
     print(f"rank {rank}/{world} slice [{lo},{hi}) hook={'rccl' if use_rccl else 'gloo-staged'} OK", flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -181,8 +181,10 @@ def test_medium_fixture_of_the_compiled_f08_reference_bit_for_bit(torch_cuda):
         assert np.array_equal(out[g["idx"]], g["out_samples"][t]), t
 
 
-def test_auto_is_blocked_beyond_64_elements_and_for_sharded_accelerators(torch_cuda, oracle):
-    """What NKA_HIP_SUMS_AUTO chooses shows in red[1]: <f,d> (raw, blocked) or <f,w1'> (reference order)."""
+def test_auto_is_the_rounded_passes_beyond_64_elements_and_for_sharded_accelerators(torch_cuda, oracle):
+    """What NKA_HIP_SUMS_AUTO chooses shows in red[1]: <f,d> (raw sums: the opt-in NKA_HIP_SUMS_BLOCKED only, since round 6) or
+    <f,w1'> on the normalised pair (reference order up to 64 elements; beyond that and for every sharded handle the ROUNDED
+    fast passes -- which make TWO exchanges per update: the norm, then the rows)."""
     import nka_amd
     rng = np.random.default_rng(9)
 
@@ -197,12 +199,22 @@ def test_auto_is_blocked_beyond_64_elements_and_for_sharded_accelerators(torch_c
         return abs(red[1] - raw) < abs(red[1] - normed)
 
     assert not red1_is_raw(nka_amd.nka().init(64, 3), 64)
-    assert red1_is_raw(nka_amd.nka().init(65, 3), 65)
+    assert not red1_is_raw(nka_amd.nka().init(65, 3), 65)            # the rounded passes (the default since round 6)
+    assert not red1_is_raw(nka_amd.nka().init(65, 3).set_sum_order(nka_amd.SUMS_BLOCKED_ROUNDED), 65)
+    assert red1_is_raw(nka_amd.nka().init(65, 3).set_sum_order(nka_amd.SUMS_BLOCKED), 65)      # the opt-in single-pass fast mode
     assert red1_is_raw(nka_amd.nka().init(64, 3).set_sum_order(nka_amd.SUMS_BLOCKED), 64)
     assert not red1_is_raw(nka_amd.nka().init(3001, 3).set_sum_order(nka_amd.SUMS_REFERENCE_ORDER), 3001)
     sharded = nka_amd.nka().init(64, 3)
-    sharded.set_dot_prod(lambda ptr, count, stream: None)          # "a global sum": the accelerator is one slice of many
+    counts = []
+    sharded.set_dot_prod(lambda ptr, count, stream: counts.append(count))      # "a global sum": the accelerator is one slice of many
+    assert not red1_is_raw(sharded, 64)
+    assert counts == [1, 2 + 2 * 3 - 1], counts                      # second update: the norm alone, then everything behind it
+    sharded.set_sum_order(nka_amd.SUMS_BLOCKED)
+    sharded.restart()
+    del counts[:]
     assert red1_is_raw(sharded, 64)
+    assert counts == [2 + 2 * 3], counts                             # the fast mode: ONE exchange per update
+    sharded.restart()
     sharded.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
     with pytest.raises(nka_amd.NKAError, match="nka_hip_set_shard"):      # the chain over the ranks needs the slice's position
         sharded.accel_update(torch_cuda.zeros(64, dtype=torch_cuda.float64, device="cuda"))
