@@ -359,8 +359,13 @@ def pmc_same_run(flavor: str, n_local: int, m: int, timeout: int = 170, extra_ar
         write = ps.load_counter(os.path.join(out, "pmc_write"), "WRITE_SIZE")
         res = {"n": n_local, "mvec": m, "kernels": {}}
         total = 0.0
-        for stem in ("k_dots", "k_combine"):
-            kf, kw = ps.widest(fetch, stem), ps.widest(write, stem)
+        def plain(agg, stem):           # (not a template: the norm pass of the default sums)
+            ks = [k for k in agg if k.startswith("nka::" + stem)]
+            return max(ks, key=lambda k: len(agg[k])) if ks else None
+        for stem in ("k_norm_diff", "k_dots", "k_combine"):
+            kf, kw = (plain(fetch, stem), plain(write, stem)) if stem == "k_norm_diff" else (ps.widest(fetch, stem), ps.widest(write, stem))
+            if stem == "k_norm_diff" and (not kf or not kw):
+                continue                  # (--sums blocked: there is no norm pass)
             if not kf or not kw:
                 return None
             fv = sorted(fetch[kf])[-max(1, len(fetch[kf]) // 2):]      # steady state: the launches with the most traffic

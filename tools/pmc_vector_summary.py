@@ -8,9 +8,9 @@
 gfx950 for wide coalesced streaming reads.  Per kernel family the steady-state instance (the widest template instance,
 launched most often) is averaged over the upper half of its launches and set against the byte MODEL bench.py's
 config5_abstract_vector uses (until round 6 that fraction rested on the model alone):
-   pure-read stage   k_diff_norm_dot_pair_many*   2 + m words per element (x, z and the m stored w)
-   combine stage     k_update_many_keep*          6 + 2m  (reference rounding: f, 2m stored vectors, the raw pair twice; 5 stores)
-                     k_axpy_many_keep*            7 + m   (compact storage)
+   pure-read stage   k_scale_dot_pair_many_win<L, false, true, true, W>   2 + m words per element (x, z and the m stored w)
+   combine stage     k_update_many_keep_win<L, true, W>    6 + 2m  (reference rounding: f, 2m stored vectors, the raw pair; 5 stores)
+                     k_update_many_keep_win<L, false, W>   7 + m   (compact storage)
 """
 import argparse
 import collections
@@ -26,8 +26,9 @@ def load(path, counter):
     for f in glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                name = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
-                agg[name].append(float(r["Counter_Value"]))
+                mt = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Kernel_Name"])      # "void (anonymous namespace)::k_x<20, true, 2>(long, ...)"
+                if mt:
+                    agg[mt.group(1)].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -51,8 +52,13 @@ def main():
     fetch = load(os.path.join(a.prof_dir, "pmc_fetch"), "FETCH_SIZE")
     write = load(os.path.join(a.prof_dir, "pmc_write"), "WRITE_SIZE")
     n, m = a.n, a.mvec
-    model = {"k_diff_norm_dot_pair_many": 2 + m, "k_update_norm2_dots": 2 + m, "k_scale_dot_pair_many": 4 + m, "k_dot_pair_many_scaled": 2 + m,
-             "k_update_norm2": 3, "k_update_many_keep": 6 + 2 * m, "k_axpy_many_keep": 7 + m}
+    # the kernels config 5 runs in steady state (fused norm stage): k_scale_dot_pair_many_win<L, false, true, true, W> is the
+    # PURE-READ form of the scale-and-dot stage (d and w1' formed in registers only: x, z and the m stored w = 2 + m words);
+    # k_update_many_keep_win<L, true, W> combines with two stored vectors per pair (6 + 2m), <L, false, W> is the compact
+    # (axpy) form with one (7 + m)
+    combine = (6 + 2 * m) if a.compact == 0 else (7 + m)
+    model = {"k_diff_norm_dot_pair_many": 2 + m, "k_update_norm2_dots": 2 + m, "k_scale_dot_pair_many": 2 + m, "k_dot_pair_many_scaled": 2 + m,
+             "k_update_many_keep": combine, "k_axpy_many_keep": combine}
     out = {"workload": f"nka_vector_driver bench 4 x {int(n) // 4}, mvec {m}, compact {a.compact}", "n": int(n), "mvec": m,
            "unit": "bytes per launch", "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 halves wide coalesced reads); WRITE_SIZE [KiB] x 1024",
            "kernels": {}, "all_kernels_seen": sorted(set(fetch) | set(write))[:80]}

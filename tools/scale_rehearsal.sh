@@ -10,15 +10,16 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$ROOT/gpurun_out/scale_rehearsal.txt}
 HOOK=${2:-rccl}          # rccl (default) | p2p: the hook forced on the one rank (round 5: the peer-to-peer exchange with its own mailbox)
+SUMS=${3:-default}       # default (round 6: the norm first, two exchanges per update) | blocked (the single-pass fast mode, one exchange)
 cd "$ROOT"
 : > "$OUT"
-echo "# one MI355X running the shard of an N-GPU job (n_global = 1e8, mvec = 20, default flavour); hook '$HOOK' forced, one rank" | tee -a "$OUT"
+echo "# one MI355X running the shard of an N-GPU job (n_global = 1e8, mvec = 20, default flavour, sums $SUMS); hook '$HOOK' forced, one rank" | tee -a "$OUT"
 PORT=29600
 for N in 1 2 4 8; do
   NL=$((100000000 / N))
   PORT=$((PORT + 1))
   NKA_BENCH_FORCE_HOOK=1 NKA_BENCH_SECONDARY=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
-      --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 1 --vlen $NL --steps 40 --no-cpu-baseline --allreduce $HOOK 2>/dev/null | grep '^{' | tail -1 > /tmp/scale_$N.json
+      --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 1 --vlen $NL --steps 40 --no-cpu-baseline --allreduce $HOOK --sums $SUMS 2>/dev/null | grep '^{' | tail -1 > /tmp/scale_$N.json
   python3 - "$N" /tmp/scale_$N.json <<'PY' | tee -a "$OUT"
 import json, sys
 N, path = int(sys.argv[1]), sys.argv[2]
