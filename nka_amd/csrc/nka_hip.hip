@@ -1365,26 +1365,28 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   const bool aligned = (reinterpret_cast<uintptr_t>(f) % 16) == 0;
   const int vec = aligned ? 2 : 1;
   int mode = (a->flavor == NKA_HIP_FLAVOR_F08_VECTOR) ? kSolveRcp : 0;
-  if (int rc = record(a, 0)) return rc;
-  if (!a->captured) {
-    // a captured update is replayed with the widths, the update number and the kernel ARGUMENTS of the capture: the list
-    // word can neither describe the replays nor tighten them (capture_safe() asks for the full width anyway), and the
-    // scalar step must find the slot -> buffer tables in memory (enqueue_solve)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
-    else if (cs != hipStreamCaptureStatusNone) a->captured = a->word_off = true;
-  }
-  if (a->captured) {
-    // NOT SUPPORTED (nka_hip_ext.h, table of combinations): a capture of an update whose sums pass through the HOST -- a
-    // caller's all-reduce hook or dot product is a host callback that a replay would not call again, silently wrong results
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+  {
+    // Is this launch being captured into a graph?  (A handle that once was stops asking -- unless it carries a host callback.)
     const bool user_hook = a->allreduce && a->allreduce != rccl_allreduce && a->allreduce != p2p_allreduce;
-    if (cs != hipStreamCaptureStatusNone && (user_hook || a->host_dot))
-      return fail(NKA_HIP_EINVAL, "accel_update: cannot be captured into a graph with a caller's all-reduce hook or dot product "
-                                  "installed (host callbacks: a replay would not call them); the built-in RCCL hook and the "
-                                  "peer-to-peer exchange can be captured");
+    if (!a->captured || user_hook || a->host_dot) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+      else if (cs != hipStreamCaptureStatusNone) {
+        // NOT SUPPORTED (nka_hip_ext.h, table of combinations): a capture of an update whose sums pass through the HOST -- a
+        // caller's all-reduce hook or dot product is a host callback that a replay would not call again: silently wrong
+        // results.  Refused before anything of the handle has changed.
+        if (user_hook || a->host_dot)
+          return fail(NKA_HIP_EINVAL, "accel_update: cannot be captured into a graph with a caller's all-reduce hook or dot product "
+                                      "installed (host callbacks: a replay would not call them); the built-in RCCL hook and the "
+                                      "peer-to-peer exchange can be captured");
+        // a captured update is replayed with the widths, the update number and the kernel ARGUMENTS of the capture: the list
+        // word can neither describe the replays nor tighten them (capture_safe() asks for the full width anyway), and the
+        // scalar step must find the slot -> buffer tables in memory (enqueue_solve)
+        a->captured = a->word_off = true;
+      }
+    }
   }
+  if (int rc = record(a, 0)) return rc;
   a->list_ub = list_bound_now(a);
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
 
