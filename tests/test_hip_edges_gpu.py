@@ -1,9 +1,12 @@
 """Edge cases of the C ABI beyond the scenario fixtures (round 3): a copy of an accelerator whose scalar state
 lives in global memory (mvec > 140), a stream change in mid-sequence, the host-array entry at n = 0 / 1 / 3, the
 wrap of the timing ring, storms of relax / restart -- each against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -296,3 +299,27 @@ def test_a_buffer_lent_back_to_the_caller_is_no_longer_held_by_the_library(torch
     with pytest.raises(nka_amd.NKAError, match="held by the library"):
         acc.accel_update_swap(big[4:n + 4], views=False)    # overlaps Y, which the library holds NOW
     assert acc.defined() and acc.num_vec() == m
+
+
+def test_the_environment_chooses_the_sum_order_a_handle_starts_with(torch_cuda):
+    """NKA_HIP_SUMS = auto | rounded | blocked | reference (round 6): for callers that cannot call nka_hip_set_sum_order -- the
+    reference's own programs relinked against the front ends.  Seen through the exchanges a one-slice 'sharded' handle makes
+    per update: two by default (the norm, then the rows), one in the fast mode; an unknown word is refused at create."""
+    import subprocess
+    import sys
+    prog = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import nka_amd\n"
+            "counts = []\n"
+            "a = nka_amd.nka().init(4099, 3)\n"
+            "a.set_dot_prod(lambda ptr, count, stream: counts.append(count))\n"
+            "rng = np.random.default_rng(1)\n"
+            "for _ in range(2): a.accel_update(torch.from_numpy(rng.standard_normal(4099)).cuda())\n"
+            "torch.cuda.synchronize(); print('COUNTS', counts)\n" % ROOT)
+    want = {None: "[1, 7]", "auto": "[1, 7]", "rounded": "[1, 7]", "blocked": "[8]", "BLOCKED": "[8]"}
+    for value, text in want.items():
+        env = {k: v for k, v in os.environ.items() if k != "NKA_HIP_SUMS"}
+        if value is not None:
+            env["NKA_HIP_SUMS"] = value
+        p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "COUNTS " + text in p.stdout, (value, p.stdout[-500:], p.stderr[-1500:])
+    p = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, NKA_HIP_SUMS="fastest"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "NKA_HIP_SUMS" in p.stderr, (p.stdout[-300:], p.stderr[-1500:])

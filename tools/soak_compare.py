@@ -3,7 +3,7 @@
 
     tools/soak_compare.py OUT.txt DIR        (DIR = gpurun_out/paired: fuzz_<kind>_<first>_{blocked,rounded}.txt[.rank<r>])
 
-`tools/evidence.sh soak-paired` runs every seed of a span once with NKA_FUZZ_FORCE_SUMS=blocked (the default fast passes: the
+`tools/evidence.sh soak-paired` runs every seed of a span once with NKA_FUZZ_FORCE_SUMS=blocked (the fast passes as rounds 1-5 ran them by default: the
 Gram row taken as fl(<d,w_k>/s) from raw sums) and once with =rounded (NKA_HIP_SUMS_BLOCKED_ROUNDED: the norm first, the Gram
 row as the inner product of the STORED fl(d/s), /root/reference/src-F08/nka_type.F90:282-290).  A record = one sequence on one
 rank, paired by (kind, seed, rank).  Judged as tests/parity_util.py judges: per sequence, err_dev <= max(1e-12, F err_ref)
@@ -65,8 +65,8 @@ def main():
         pairs.setdefault((kind, first, rank), {})[mode] = parse(f)
     L = []
     L.append("# tools/soak_compare.py: the two fast sum modes on the same seeds (tools/evidence.sh soak-paired; NKA_FUZZ_FORCE_SUMS)")
-    L.append("#   blocked = NKA_HIP_SUMS_BLOCKED, the default fast passes: Gram row fl(<d,w_k>/s) from raw sums, one pass, one exchange")
-    L.append("#   rounded = NKA_HIP_SUMS_BLOCKED_ROUNDED: the norm first, Gram row = inner product of the stored fl(d/s) (F08:282-290)")
+    L.append("#   blocked = NKA_HIP_SUMS_BLOCKED, the default of rounds 1-5 (opt-in fast mode since): Gram row fl(<d,w_k>/s) from raw sums, one pass, one exchange")
+    L.append("#   rounded = NKA_HIP_SUMS_BLOCKED_ROUNDED (the default since round 6): the norm first, Gram row = inner product of the stored fl(d/s) (F08:282-290)")
     L.append(f"# rule per sequence: err_dev <= max({BASE:g}, F x err_ref) against the extended-precision trajectory, F = {P.TRUTH_FACTOR:g} beyond "
              f"{P.TINY_N} elements, {P.TRUTH_FACTOR_TINY:g} within; a record = one sequence on one rank")
     L.append("")
