@@ -1446,7 +1446,8 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
     RoctxRange range("nka:norm pass + PA on the rounded w1'");
     if (a->pending) {
       const int g = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)a->num_cu, std::max<int64_t>(a->n / (kBlock * 2), 1)));
-      hipLaunchKernelGGL(k_norm_diff, dim3(g), dim3(kBlock), 0, s, a->ctl, a->vs, f, a->partials, a->tickets + kNormTicketWord);
+      hipLaunchKernelGGL(k_norm_diff, dim3(g), dim3(kBlock), 0, s, a->ctl, a->vs, f, a->partials);
+      hipLaunchKernelGGL(k_norm_fin, dim3(1), dim3(64), 0, s, a->ctl, a->partials, g);
       HIP_TRY(hipGetLastError());
       if (a->allreduce)
         if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");

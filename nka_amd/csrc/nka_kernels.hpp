@@ -492,15 +492,9 @@ __global__ __launch_bounds__(kBlock) void k_dots(Ctl ctl, Vecs vs, const double 
 }
 
 // The norm pass of NKA_HIP_SUMS_BLOCKED_ROUNDED: sum d^2 with d = w1 - f (F08:266-267) over this rank's slice, two streams,
-// per-block partial sums in column 0 of `partials`, added in a fixed order.
-constexpr int kTicketStrideFwd = 32, kTicketGroupsMaxFwd = 8;          // (= kTicketStride, kTicketGroupsMax: defined with PB below)
-// Round 6: the final sum is formed by whichever block finishes LAST (a ticket in device memory; k_norm_fin, a launch of one
-// wavefront, is gone: 4-5 us per update, a tenth of one at n <= 1e5) -- in k_norm_fin's order (lane b adds partials b, b + 64,
-// ..., then wave_sum), hence the same bits.  Every block publishes its partial sum with a release fence at agent scope before it
-// takes its ticket; the last one reads the partial sums with agent-scope loads behind an acquire fence (the XCDs' L2s are not
-// coherent with one another for plain loads); it leaves the ticket at zero for the next launch.
+// per-block partial sums in column 0 of `partials` (k_norm_fin adds them in a fixed order).
 static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_norm_diff(Ctl ctl, Vecs vs, const double *__restrict__ f,
-                                                                                         double *__restrict__ partials, unsigned *ticket) {
+                                                                                         double *__restrict__ partials) {
   const int G = gridDim.x;
   const double *w1 = vs.w + ctl.pc[PC_FIRST_W];
   const bool v2 = (reinterpret_cast<uintptr_t>(f) % 16) == 0;      // (slot bases are 256-byte aligned)
@@ -555,26 +549,15 @@ static __global__ __launch_bounds__(kBlock) __attribute__((unused)) void k_norm_
     }
   }
   const double one[1] = {acc};
-  block_reduce_store<1>(one, partials, G);           // (thread 0 stores partials[blockIdx.x])
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    __threadfence();                                 // release: the store above, device-wide, before the ticket
-    s_last = atomicAdd(ticket, 1u) == (unsigned)G - 1u;
-  }
-  __syncthreads();
-  if (s_last && threadIdx.x < 64) {
-    // ... the final sum, one wavefront, into red[0] (zero without a pending pair: nothing stale reaches the exchange)
-    __threadfence();                                 // acquire
-    double r = 0.0;
-    for (int b = threadIdx.x; b < G; b += 64) r += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r = wave_sum(r);
-    if (threadIdx.x == 0) {
-      ctl.red()[0] = ctl.ic[IC_PLAN_PENDING] ? r : 0.0;
-      atomicExch(ticket, 0u);
-    }
-  }
+  block_reduce_store<1>(one, partials, G);
 }
-constexpr int kNormTicketWord = kTicketGroupsMaxFwd * kTicketStrideFwd + 16;      // (a word of PB's `done` line that PB does not use)
+// ... and its final sum, one wavefront, into red[0] (zero without a pending pair: nothing stale reaches the exchange)
+static __global__ __launch_bounds__(64) __attribute__((unused)) void k_norm_fin(Ctl ctl, const double *__restrict__ partials, int G) {
+  double r = 0.0;
+  for (int b = threadIdx.x; b < G; b += 64) r += partials[b];
+  r = wave_sum(r);
+  if (threadIdx.x == 0) ctl.red()[0] = ctl.ic[IC_PLAN_PENDING] ? r : 0.0;
+}
 
 // PA with a SMALL ROLLING WINDOW of loads.  tools/hbm_probe (mode f) showed that a
 // pure-read kernel with the arithmetic of this pass runs at 7.15 TB/s when each wave
@@ -1808,7 +1791,6 @@ __global__ __launch_bounds__(kBlock) void k_combine(Ctl ctl, Vecs vs, double *f,
 // always finds them zero.  Elementwise pass: which block handles a tile changes no bit.
 constexpr int kTicketStride = 32;                 // uint32 words between counters (128 B)
 constexpr int kTicketGroupsMax = 8;
-static_assert(kTicketStride == kTicketStrideFwd && kTicketGroupsMax == kTicketGroupsMaxFwd, "kNormTicketWord out of step");
 constexpr int kTicketWords = kTicketStride * (kTicketGroupsMax + 1);   // ng counters + `done`
 constexpr unsigned kNoTicket = 0xffffffffu;
 
