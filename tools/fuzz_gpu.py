@@ -318,13 +318,17 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
     rounded = seed >= 300_000 and same_bits and (seed // 4) % 2 == 1
     if os.environ.get("NKA_FUZZ_FORCE_ROUNDED") == "1" and not same_bits:
         rounded = True           # (the regression test replays recorded blocked-mode seeds with the Gram row on the rounded w1')
-    if FORCE_SUMS:               # the paired soak: every seed in one fast mode, transports rotating as before
-        same_bits, rounded = False, FORCE_SUMS == "rounded"
     if rounded:
         same_bits = False
+    # Round 6: the default sums ARE the rounded passes now; so that the single-pass fast mode stays under soak, every other
+    # remaining sequence (seeds from 100 000 on) selects NKA_HIP_SUMS_BLOCKED explicitly, the others run the default
+    blocked = seed >= 100_000 and not same_bits and not rounded and (seed // 2) % 4 == 0
+    if FORCE_SUMS:               # the paired soak: every seed in one fast mode (set explicitly), transports rotating as before
+        same_bits, rounded, blocked = False, FORCE_SUMS == "rounded", FORCE_SUMS == "blocked"
     key = f"fuzz sharded seed {seed} world {world} n={n} m={m} flavor {flavor}" + \
-          ((" p2p" if p2p else " staged") + (" sums rounded" if rounded else " sums reference" if same_bits else " sums blocked")
-           if seed >= 100_000 else (" sums rounded" if rounded else ""))
+          ((" p2p" if p2p else " staged") + (" sums rounded" if rounded else " sums reference" if same_bits else " sums blocked" if blocked
+                                             else " sums default")
+           if seed >= 100_000 else (" sums rounded" if rounded else " sums blocked" if blocked else ""))
     lo, hi = nd.slice_bounds(n, world, rank)
 
     def hook(ptr, count, stream):
@@ -343,6 +347,8 @@ def one_seed_sharded(seed, torch, dist, oracle, P, nka_amd, nd, steps=60, strict
             a.set_sum_order(nka_amd.SUMS_REFERENCE_ORDER)
         if rounded:
             a.set_sum_order(nka_amd.SUMS_BLOCKED_ROUNDED)
+        if blocked:
+            a.set_sum_order(nka_amd.SUMS_BLOCKED)
         return a
 
     acc = attach(nka_amd.nka().init(hi - lo, m, flavor=flavor))
