@@ -15,8 +15,9 @@ path of /root/reference/src-F08/nka_type.F90:249-419 in steady state (subspace
 full: L = k = mvec), inputs already resident in HBM when the timed region
 starts.  Workload at N=1: BASELINE.json configs[2], n=1e8, mvec=20, fp64.
 With N>1 the SAME global vector is sharded by contiguous slices (strong
-scaling, BASELINE configs[3]); the only exchange is ONE RCCL all-reduce of
-2+2*mvec doubles per update (the norm and both Gram rows), on the kernel stream.
+scaling, BASELINE configs[3]); the only exchanges are two small RCCL all-reduces
+per update on the kernel stream -- the norm (1 double), then both Gram rows (1+2*mvec)
+-- or ONE of 2+2*mvec doubles in the opt-in fast sum mode (--sums blocked).
 
 Prints ONE JSON line (rank 0) with the driver's keys plus
   roofline     : PHYSICAL fractions only.  Top level = the dominant kernel (PB
@@ -113,7 +114,7 @@ def parse(argv=None):
                          "since round 6: the norm first, then PA on the ROUNDED w1' (NKA_HIP_SUMS_BLOCKED_ROUNDED: 2 words per "
                          "element and one exchange more); blocked = the opt-in single-pass fast mode (raw-sum Gram row)")
     ap.add_argument("--allreduce", choices=["p2p", "rccl", "torch", "staged"], default=os.environ.get("NKA_BENCH_ALLREDUCE", "rccl"),
-                    help="the one exchange of a sharded update.  rccl (default): the library's RCCL communicator on the kernel "
+                    help="the transport of the exchanges of a sharded update.  rccl (default): the library's RCCL communicator on the kernel "
                          "stream; p2p: the opt-in peer-to-peer exchange (mailboxes mapped through hipIpc, no communication "
                          "kernel; falls through to rccl where IPC is refused); torch / staged: fallbacks")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NKA_BENCH_BACKEND", "nccl"),
@@ -714,7 +715,7 @@ def main(argv=None):
         import datetime
         # CONTROL plane on gloo, always: the collective decisions about the all-reduce hook, the barriers around the
         # timed region, the max-over-ranks time and the replica digests must work when RCCL is the thing that is
-        # broken.  The DATA path (the one all-reduce of 2+2*mvec doubles per update) is RCCL: the library's own
+        # broken.  The DATA path (the all-reduces of an update: 1 + (1+2*mvec) doubles, or 2+2*mvec at once in the fast mode) is RCCL: the library's own
         # communicator, else torch.distributed's nccl group created on demand, else staged through the host.
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=min(limit, 200)))
 
@@ -869,7 +870,7 @@ def main(argv=None):
     k_steady = m if args.workload == "full" else min(m, args.drop_dim)     # vectors the subspace holds in steady state
     steady = (nv == k_steady)
 
-    # the ONE exchange of a sharded update by itself: 2 + 2 mvec doubles through the installed hook, back to back on the kernel
+    # an exchange of a sharded update by itself: 2 + 2 mvec doubles through the installed hook (the larger of the default's two), back to back on the kernel
     # stream (device events; max over ranks) -- the latency figure that decides between RCCL and the peer-to-peer exchange
     exchange = None
     if world > 1 or hook_box[0] != "none":

@@ -172,7 +172,8 @@ int nka_hip_set_host_dot(nka_hip_t a, nka_hip_host_dot_fn fn, void *ctx);
  * both Gram rows; twice with NKA_HIP_SUMS_BLOCKED_ROUNDED).  NULL restores the single-rank default (no reduction). */
 typedef int (*nka_hip_allreduce_fn)(void *ctx, double *buf, int32_t count, void *stream);
 int nka_hip_set_allreduce(nka_hip_t a, nka_hip_allreduce_fn fn, void *ctx);
-/* Built-in hook: ONE RCCL all-reduce over xGMI on the handle's stream.  nka_hip_comm_unique_id fills 128 bytes (an
+/* Built-in hook: RCCL all-reduces over xGMI on the handle's stream (per update: 8 B + 328 B at mvec = 20; one of 336 B in the
+ * fast sum mode).  nka_hip_comm_unique_id fills 128 bytes (an
  * ncclUniqueId) on one rank; the caller broadcasts it by any means; every rank then calls comm_init_rank (collective,
  * blocking).  RCCL is bound at first use (dlopen): the librccl.so.1 already mapped into the process if there is one, else
  * the ROCm installation's; nka_hip_comm_library reports the file.  comm_info: what the communicator itself reports

@@ -187,7 +187,7 @@ contains
     call nka_hip_check(nka_hip_set_allreduce(this%handle, fn, ctx), 'nka%set_allreduce')
   end subroutine
 
-  !! Built-in hook: one RCCL all-reduce per update over xGMI.
+  !! Built-in hook: the RCCL all-reduces of an update over xGMI (two small ones with the default sums, one in the fast mode).
   subroutine use_rccl(this, id128, nranks, rank)
     class(nka), intent(inout) :: this
     character(kind=c_char), intent(in) :: id128(128)

@@ -183,7 +183,8 @@ class nka:  # noqa: N801  (the reference's type name)
         _check(self._L.nka_hip_set_host_dot(self._handle(), self._hd, None), "set_host_dot", self._L)
 
     def use_rccl(self, unique_id: bytes, nranks: int, rank: int):
-        """Built-in hook: ONE RCCL all-reduce per update on the object's stream."""
+        """Built-in hook: the RCCL all-reduces of an update on the object's stream (two small ones with the default sums -- the norm,
+        then the rows --, one in the fast mode SUMS_BLOCKED)."""
         buf = C.create_string_buffer(unique_id, 128)
         _check(self._L.nka_hip_comm_init_rank(self._handle(), buf, nranks, rank), "comm_init_rank", self._L)
 
