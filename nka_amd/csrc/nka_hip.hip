@@ -1328,6 +1328,128 @@ static int ordered_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
   return 0;
 }
 
+// ---- the sums of an update, one function per mode (include/nka_hip.h: nka_hip_set_sum_order; nka_hip_ext.h: table of supported
+// combinations).  A failure up to and including the all-reduce leaves the update NOT done: only scratch (partials, red[]) has
+// been written; f, the stored vectors, the lists and the host-side bookkeeping are untouched, so the same call may be repeated.
+enum class SumsStage { HostDot, ReferenceChain, ReferenceOrder, Rounded, Blocked };
+struct SumsResult {
+  int rc = 0;              // != 0: the update is not done
+  int mode_bits = 0;       // kSolvePrenorm: the sums were formed on the normalised pair, the scalar step takes them as they are
+  bool solved = false;     // the scalar step has run already (user dot product: it is interleaved with the dp calls)
+  bool gather = false;     // the scalar step starts by gathering the sums from the peer-to-peer mailboxes
+};
+static int hook_failed(int rc) { return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed"); }
+
+static SumsStage pick_sums_stage(const nka_hip_state *a) {
+  if (a->host_dot) return SumsStage::HostDot;                                                   // the user's dp overrides everything
+  if (a->sum_order == NKA_HIP_SUMS_REFERENCE_ORDER && a->allreduce) return SumsStage::ReferenceChain;
+  if (ordered_sums(a)) return SumsStage::ReferenceOrder;               // asked for, or free (one rank, n <= 64)
+  return a->sum_order == NKA_HIP_SUMS_BLOCKED ? SumsStage::Blocked : SumsStage::Rounded;        // AUTO resolves to Rounded (round 6)
+}
+
+// the user's dot product on host copies, in the reference's order, interleaved with the scalar step (nka_hip_set_host_dot)
+static SumsResult sums_host_dot(nka_hip_t a, const double *f, int mode) {
+  RoctxRange range("nka:host dot products + scalar step");
+  SumsResult r;
+  r.rc = host_dot_update_scalars(a, f, mode);
+  r.solved = true;
+  return r;
+}
+
+// reference order, sharded: the slices of the global vector walked rank after rank (ordered_chain): 2N exchanges
+static SumsResult sums_reference_chain(nka_hip_t a, const double *f, int mode, int older_ub) {
+  RoctxRange range("nka:PA dots in the reference's order, rank after rank");
+  SumsResult r;
+  if (a->pending || older_ub > 0) r.rc = ordered_chain(a, f, mode, older_ub);
+  r.mode_bits = kSolvePrenorm;
+  return r;
+}
+
+// reference order, one rank: every sum as the reference forms it -- the update returns the reference's bits
+static SumsResult sums_reference_order(nka_hip_t a, const double *f, int mode, int older_ub) {
+  RoctxRange range("nka:PA dots in the reference's order");
+  SumsResult r;
+  r.mode_bits = kSolvePrenorm;
+  if (!(a->pending || older_ub > 0)) return r;
+  hipStream_t s = a->stream;
+  auto hip = [&](hipError_t e) { if (e != hipSuccess && !r.rc) r.rc = fail(NKA_HIP_EHIP, std::string("accel_update: ") + hipGetErrorString(e)); return e == hipSuccess; };
+  const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
+  if (chain_per_sum(a, rows)) {
+    // long vectors: one workgroup per sum; the norm alone first (one chain: every other sum of the update would wait
+    // for it on idle compute units if it shared a launch with sums twice as long), then everything else side by side
+    if (!hip(hipMemsetAsync(a->ctl.red(), 0, sizeof(double) * (size_t)a->ctl.red_count(), s))) return r;
+    if (chain_many_ready(a, 1 + 2 * a->mvec)) {
+      // the longest vectors: every block of every sum summarised by the whole device, one wavefront per sum applies
+      if (a->pending && (r.rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, 1))) return r;
+      if ((r.rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainRows, 1, older_ub, 1 + 2 * older_ub))) return r;
+    } else {
+      if (a->pending)
+        hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                           (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
+      hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
+                         (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
+    }
+  } else {
+    hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
+                       ord_chunk(rows), (int)kOrdAll, 0);
+  }
+  hip(hipGetLastError());
+  return r;
+}
+
+// THE DEFAULT since round 6 (NKA_HIP_SUMS_AUTO beyond 64 elements or sharded, and NKA_HIP_SUMS_BLOCKED_ROUNDED): on the same
+// soak sequences the raw-sum Gram row ended beyond the rule's factor in 7 records of more than 512 elements, this form in 1
+// (profiles/r06/soak_paired.txt).  The fast passes with the Gram row AS THE REFERENCE DEFINES IT: first the norm in a pass of
+// its own (two streams: +2 of 49 words), then PA on the ROUNDED w1' = fl(d/s) -- the vector PB stores -- so that <w1',w_k> and
+// <f,w1'> are inner products of stored vectors (F08:283-290, 371), summed in blocks with fma.  What is left of the device's
+// deviations is the summation order and the fma, both CLOSER to the exact sums than the reference's sequential ones.  Sharded:
+// two exchanges per update (the norm, then the rows) through the installed hook.
+static SumsResult sums_rounded(nka_hip_t a, const double *f, int vec, int mode, int older_ub) {
+  SumsResult r;
+  if (!(a->pending || older_ub > 0)) return r;             // (the first update after init / restart: nothing to sum)
+  RoctxRange range("nka:norm pass + PA on the rounded w1'");
+  hipStream_t s = a->stream;
+  auto hip = [&](hipError_t e) { if (e != hipSuccess && !r.rc) r.rc = fail(NKA_HIP_EHIP, std::string("accel_update: ") + hipGetErrorString(e)); return e == hipSuccess; };
+  if (a->pending) {
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)a->num_cu, std::max<int64_t>(a->n / (kBlock * 2), 1)));
+    hipLaunchKernelGGL(k_norm_diff, dim3(g), dim3(kBlock), 0, s, a->ctl, a->vs, f, a->partials);
+    hipLaunchKernelGGL(k_norm_fin, dim3(1), dim3(64), 0, s, a->ctl, a->partials, g);
+    if (!hip(hipGetLastError())) return r;
+    if (a->allreduce)
+      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) { r.rc = hook_failed(rc); return r; }
+  }
+  a->pa_normed = (mode & kSolveRcp) ? 3 : 1;
+  enqueue_pa(a, f, vec, older_ub);
+  a->pa_normed = 0;
+  if (!hip(hipGetLastError())) return r;
+  if (a->allreduce)
+    if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red() + 1, a->ctl.red_count() - 1, s)) { r.rc = hook_failed(rc); return r; }
+  r.mode_bits = kSolvePrenorm;
+  return r;
+}
+
+// NKA_HIP_SUMS_BLOCKED, the opt-in single-pass fast mode: ONE pure-read pass forms every sum (F08:266-267, 286-290, 371), the
+// Gram row of the normalised difference is taken from raw sums in the scalar step; ONE exchange when sharded
+static SumsResult sums_blocked(nka_hip_t a, const double *f, int vec, int older_ub) {
+  SumsResult r;
+  if (!(a->pending || older_ub > 0)) return r;
+  RoctxRange range("nka:PA dots + all-reduce");
+  // peer-to-peer exchange: the final sums go straight into every rank's mailbox and the scalar step gathers them -- no
+  // kernel in between (nka_kernels.hpp: struct P2P)
+  r.gather = a->allreduce == p2p_allreduce && a->p2p.base != nullptr;
+  a->p2p_fused = r.gather;
+  enqueue_pa(a, f, vec, older_ub);
+  a->p2p_fused = false;
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+    r.rc = fail(NKA_HIP_EHIP, std::string("accel_update: ") + hipGetErrorString(e));
+    return r;
+  }
+  // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
+  if (a->allreduce && !r.gather)
+    if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), a->ctl.red_count(), a->stream)) r.rc = hook_failed(rc);
+  return r;
+}
+
 static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_v);
 static int p2p_status_after_sync(nka_hip_t a);
 
@@ -1390,88 +1512,21 @@ static int update_impl(nka_hip_t a, double *f, long long swap_w, long long swap_
   a->list_ub = list_bound_now(a);
   const int older_ub = a->pending ? std::max(a->list_ub - 1, 0) : a->list_ub;
 
-  // ---- PA: all inner products in one pure-read pass (F08:266-267, 286-290, 371) ----
-  // Unaligned f (not 16-B aligned) takes scalar loads with the narrow unroll.
-  // A failure up to and including the all-reduce leaves the update NOT done: only
-  // scratch (partials, red[]) has been written; f, the stored vectors, the lists and
-  // the host-side bookkeeping are untouched, so the same call may be repeated.
-  bool solved = false, gather = false;
-  if (a->host_dot) {
-    RoctxRange range("nka:host dot products + scalar step");
-    if (int rc = host_dot_update_scalars(a, f, mode)) return rc;
-    solved = true;
-  } else if (chain) {
-    // ... the same sums with the slices of the global vector walked rank after rank (ordered_chain): 2N exchanges
-    RoctxRange range("nka:PA dots in the reference's order, rank after rank");
-    if (a->pending || older_ub > 0)
-      if (int rc = ordered_chain(a, f, mode, older_ub)) return rc;
-    mode |= kSolvePrenorm;
-  } else if (ordered_sums(a)) {
-    // every sum in the reference's order on one workgroup: the update returns the reference's bits (k_dots_ordered)
-    RoctxRange range("nka:PA dots in the reference's order");
-    if (a->pending || older_ub > 0) {
-      const int rows = 2 + older_ub;                               // (older_ub bounds the device's count from above)
-      if (chain_per_sum(a, rows)) {
-        // long vectors: one workgroup per sum; the norm alone first (one chain: every other sum of the update would wait
-        // for it on idle compute units if it shared a launch with sums twice as long), then everything else side by side
-        HIP_TRY(hipMemsetAsync(a->ctl.red(), 0, sizeof(double) * (size_t)a->ctl.red_count(), s));
-        if (chain_many_ready(a, 1 + 2 * a->mvec)) {
-          // the longest vectors: every block of every sum summarised by the whole device, one wavefront per sum applies
-          if (a->pending)
-            if (int rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainNorm, 0, older_ub, 1)) return rc;
-          if (int rc = chain_many_stage(a, f, mode & kSolveRcp, (int)kChainRows, 1, older_ub, 1 + 2 * older_ub)) return rc;
-        } else {
-          if (a->pending)
-            hipLaunchKernelGGL(k_chain_sums, dim3(1), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                               (int)kChainNorm, 0, older_ub, a->chain_walk, (const double *)nullptr);
-          hipLaunchKernelGGL(k_chain_sums, dim3(1 + 2 * older_ub), dim3(kChainThreads), kChainLdsBytes, s, a->ctl, a->vs, f, mode & kSolveRcp,
-                             (int)kChainRows, 1, older_ub, a->chain_walk, (const double *)nullptr);
-        }
-      } else {
-        hipLaunchKernelGGL(k_dots_ordered, dim3(1), dim3(kOrdThreads), ord_lds_bytes(rows), s, a->ctl, a->vs, f, mode & kSolveRcp,
-                           ord_chunk(rows), (int)kOrdAll, 0);
-      }
-      HIP_TRY(hipGetLastError());
-    }
-    mode |= kSolvePrenorm;
-  } else if (a->sum_order != NKA_HIP_SUMS_BLOCKED && (a->pending || older_ub > 0)) {
-    // THE DEFAULT since round 6 (NKA_HIP_SUMS_AUTO beyond 64 elements or sharded, and NKA_HIP_SUMS_BLOCKED_ROUNDED): on the same
-    // 8 104 soak sequences the raw-sum Gram row ended beyond the rule's factor in 7 records of more than 512 elements, this
-    // form in 1 (profiles/r06/soak_paired.txt).  NKA_HIP_SUMS_BLOCKED (the branch below) is the opt-in single-pass fast mode.
-    // The fast passes with the Gram row AS THE REFERENCE DEFINES IT: first the norm in a pass of its own (two streams: +2 of
-    // 49 words), then PA on the ROUNDED w1' = fl(d/s) -- the vector PB stores -- so that <w1',w_k> and <f,w1'> are inner
-    // products of stored vectors (F08:283-290, 371), summed in blocks with fma.  What is left of the device's deviations
-    // is the summation order and the fma, both CLOSER to the exact sums than the reference's sequential ones.  Sharded: two
-    // exchanges per update (the norm, then the rows) through the installed hook.
-    RoctxRange range("nka:norm pass + PA on the rounded w1'");
-    if (a->pending) {
-      const int g = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)a->num_cu, std::max<int64_t>(a->n / (kBlock * 2), 1)));
-      hipLaunchKernelGGL(k_norm_diff, dim3(g), dim3(kBlock), 0, s, a->ctl, a->vs, f, a->partials);
-      hipLaunchKernelGGL(k_norm_fin, dim3(1), dim3(64), 0, s, a->ctl, a->partials, g);
-      HIP_TRY(hipGetLastError());
-      if (a->allreduce)
-        if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
-    }
-    a->pa_normed = (mode & kSolveRcp) ? 3 : 1;
-    enqueue_pa(a, f, vec, older_ub);
-    a->pa_normed = 0;
-    HIP_TRY(hipGetLastError());
-    if (a->allreduce)
-      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red() + 1, a->ctl.red_count() - 1, s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
-    mode |= kSolvePrenorm;
-  } else if (a->pending || older_ub > 0) {
-    RoctxRange range("nka:PA dots + all-reduce");
-    // peer-to-peer exchange: the final sums go straight into every rank's mailbox and the scalar step gathers them -- no
-    // kernel in between (nka_kernels.hpp: struct P2P)
-    gather = a->allreduce == p2p_allreduce && a->p2p.base != nullptr;
-    a->p2p_fused = gather;
-    enqueue_pa(a, f, vec, older_ub);
-    a->p2p_fused = false;
-    HIP_TRY(hipGetLastError());
-    // the ONE exchange of a sharded update: sum d^2, <f,d> and both Gram rows
-    if (a->allreduce && !gather)
-      if (int rc = a->allreduce(a->allreduce_ctx, a->ctl.red(), a->ctl.red_count(), s)) return rc < 0 ? rc : fail(NKA_HIP_ECOMM, "allreduce hook failed");
+  // ---- the inner products (F08:266-267, 286-290, 371): ONE function per way of forming them (round 6: update_impl used to
+  // branch over all of them in line); each leaves the reduced sums in red[] -- or, with a user dot product, the whole scalar
+  // step done -- and says what the scalar step must know.  Unaligned f (not 16-B aligned) takes scalar loads with the narrow
+  // unroll.  A failure up to and including the all-reduce leaves the update NOT done (see above the stage functions).
+  SumsResult sums{};
+  switch (pick_sums_stage(a)) {
+    case SumsStage::HostDot:        sums = sums_host_dot(a, f, mode); break;
+    case SumsStage::ReferenceChain: sums = sums_reference_chain(a, f, mode, older_ub); break;
+    case SumsStage::ReferenceOrder: sums = sums_reference_order(a, f, mode, older_ub); break;
+    case SumsStage::Rounded:        sums = sums_rounded(a, f, vec, mode, older_ub); break;
+    case SumsStage::Blocked:        sums = sums_blocked(a, f, vec, older_ub); break;
   }
+  if (sums.rc) return sums.rc;
+  mode |= sums.mode_bits;
+  const bool solved = sums.solved, gather = sums.gather;
   if (int rc = record(a, 1)) return rc;
 
   // ---- scalar part on one wavefront (F08:267-275, 295-358, 366-392, 406-417) ----
