@@ -175,8 +175,9 @@ int nka_hip_p2p_detach(nka_hip_t a);
  * nka_hip_p2p_attach_local takes the nranks addresses in rank order (entry `rank` must be the handle's own).  Nothing is
  * mapped, so detach frees only the handle's own mailbox: synchronise every handle before the first detach.  The scalar
  * step of a slice WAITS on the device for the sums of the others: every handle's stream must own a hardware queue
- * (GPU_MAX_HW_QUEUES >= nranks in the environment before HIP starts; the default of 4 makes streams share queues and a
- * wait then sits in front of the kernel it waits for until the timeout). */
+ * (GPU_MAX_HW_QUEUES >= the number of slices on one device, in the environment before HIP starts; the default of 4 makes
+ * streams share queues and a wait then sits in front of the kernel it waits for until the timeout): attach_local returns
+ * NKA_HIP_ESTATE when more slices share the handle's device than GPU_MAX_HW_QUEUES (default 4) allows. */
 int nka_hip_p2p_mailbox(nka_hip_t a, void **mailbox);
 int nka_hip_p2p_attach_local(nka_hip_t a, void *const *mailboxes, int32_t nranks, int32_t rank);
 

@@ -1871,6 +1871,22 @@ static int p2p_attach_impl(nka_hip_t a, const void *handles, void *const *local,
   if (rank < 0 || rank >= nranks) return fail(NKA_HIP_EINVAL, "p2p_attach: bad rank");
   if (local && local[rank] != a->p2p_mail) return fail(NKA_HIP_EINVAL, "p2p_attach_local: entry `rank` is not this handle's own mailbox");
   HIP_TRY(hipSetDevice(a->device));
+  if (local) {
+    // Slices that share a DEVICE wait for one another on that device: each of their streams must own a hardware queue, or a
+    // wait sits in front of the kernel it waits for until the timeout (measured in round 6: profiles/r06/configs3_inproc.txt).
+    // The runtime maps streams onto GPU_MAX_HW_QUEUES queues (default 4), read when HIP starts: refuse what cannot work.
+    int here = 0;
+    for (int q = 0; q < nranks; q++) {
+      hipPointerAttribute_t at{};
+      if (local[q] && hipPointerGetAttributes(&at, local[q]) == hipSuccess) here += at.device == a->device;
+      else (void)hipGetLastError();
+    }
+    const int queues = env_int("GPU_MAX_HW_QUEUES", 4);
+    if (here > queues)
+      return fail(NKA_HIP_ESTATE, "p2p_attach_local: " + std::to_string(here) + " slices share device " + std::to_string(a->device) +
+                                  " but the HIP runtime maps streams onto " + std::to_string(queues) + " hardware queues: set "
+                                  "GPU_MAX_HW_QUEUES >= " + std::to_string(here) + " in the environment before HIP starts");
+  }
   const int cap = std::max(a->ctl.red_count(), 64);
   std::vector<long long> off((size_t)nranks, 0);
   for (int q = 0; q < nranks; q++) {

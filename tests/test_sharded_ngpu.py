@@ -85,6 +85,20 @@ def test_configs3_partition_8_ranks_one_process(transport, sums):
     print(p.stdout[-1500:])
 
 
+def test_in_process_mailboxes_are_refused_when_the_streams_cannot_own_hardware_queues():
+    """Eight slices on one device with the HIP runtime's default of 4 hardware queues: a device-side wait would sit in front of
+    the kernel it waits for (round 6 measured exactly that: a timeout, NaNs, a failed self-test).  nka_hip_p2p_attach_local now
+    refuses up front and says which variable to set."""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env.update(OMP_NUM_THREADS="1", NKA_C3_TRANSPORT="p2p", NKA_C3_WORLD="8", NKA_C3_N0="97656", NKA_C3_R="4", NKA_C3_MVEC="5",
+               NKA_C3_FLAVORS="2")
+    p = subprocess.run([sys.executable, INPROC_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "GPU_MAX_HW_QUEUES >= 8" in p.stderr, (p.returncode, p.stdout[-1000:], p.stderr[-3000:])
+    env["GPU_MAX_HW_QUEUES"] = "8"                      # ... and with it, the same small run goes through
+    p = subprocess.run([sys.executable, INPROC_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "configs3 in one process OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 REFORDER_WORKER = os.path.join(ROOT, "tests", "_sharded_reforder_worker.py")
 
 
